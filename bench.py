@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path: the fused pseudo-transient pressure-Poisson iteration.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): Mcells·PT-iter/s (+ achieved HBM GB/s) on the 512³ lid-driven-cavity Poisson-only
+configuration (BASELINE.json configs[2]; synthetic, SURVEY.md §8d Config 3).  One "step" = one PT iteration
+{update_dPrdτ!; update_Pr!; set_bc_Pr!} (multi.jl:459-463) over the whole grid = one launch of the fused sweep
+kernel; fields are resident in HBM before the timed region.  For N>1 every rank owns one 512×512×512 z-slab of an
+implicit global grid 512×512×(N·510+2) (weak scaling, the reference's own model: local size fixed,
+multi.jl:325,338), with the two seam planes exchanged over RCCL/xGMI each iteration behind the interior sweep.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E nominal, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(nx, ny, nz, itemsize):
+    """read Pr, read ∇V, read+write dPrdτ, write Pr = itemsize·(N + 4·N_inner) per PT iteration
+    (≈40 B/cell fp64)."""
+    return itemsize * (nx * ny * nz + 4 * (nx - 2) * (ny - 2) * (nz - 2))
+
+
+def cpu_baseline(n, nzs, iters, dtype):
+    """C/OpenMP restatement of the reference CPU (Threads) path — the oracle's UNFUSED loop — timed on the host cores
+    of this box on a bounded slab sample of the same workload."""
+    from oracle import oracle as O
+    from navierstokes3d_amd.params import cavity_params
+    cores = len(os.sched_getaffinity(0))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    p = cavity_params(n, nzs)
+    npdt = np.float64 if dtype == "f64" else np.float32
+    rng = np.random.Generator(np.random.MT19937(12345))
+    Pr = O.zeros((p.nx, p.ny, p.nz), npdt)
+    d = O.zeros((p.nx - 2, p.ny - 2, p.nz - 2), npdt)
+    rhs = np.asfortranarray((rng.random((p.nz, p.ny, p.nx), dtype=np.float64).transpose(2, 1, 0) * 2e-3 - 1e-3).astype(npdt))
+    Rp = O.zeros((p.nx - 2, p.ny - 2, p.nz - 2), npdt)
+    args = (p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, 0, False, 0.0, 0.0, -1.0)
+    O.pt_solve(Pr, d, rhs, Rp, *args, 2, 0, 1.0)  # warm-up / page-in
+    t0 = time.perf_counter()
+    O.pt_solve(Pr, d, rhs, Rp, *args, iters, 0, 1.0)
+    t = time.perf_counter() - t0
+    cells = p.nx * p.ny * p.nz
+    return {
+        "value": cells * iters / t / 1e6, "unit": "Mcells*iter/s", "cores": cores, "kind": "port",
+        "sample": "%dx%dx%d slab of the 512^3 workload, %d unfused PT iterations (oracle C/OpenMP restatement of the "
+                  "reference Threads path, %s), %.1f s" % (p.nx, p.ny, p.nz, iters, dtype, t),
+        "gbps_algorithmic": algorithmic_bytes(p.nx, p.ny, p.nz, np.dtype(npdt).itemsize) * iters / t / 1e9,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=512, help="local grid is n x n x nz")
+    ap.add_argument("--nz", type=int, default=None)
+    ap.add_argument("--mode", default=os.environ.get("NS3D_BENCH_MODE", "strict"), choices=["strict", "fast"])
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--variant", type=int, default=int(os.environ.get("NS3D_PT_VARIANT", "0")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=12)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from navierstokes3d_amd import build
+    if rank == 0:
+        build.build()
+    if world > 1:
+        dist.barrier()
+    from navierstokes3d_amd import kernels as K
+    from navierstokes3d_amd import lib as L
+    from navierstokes3d_amd.halo import ZSlabGrid
+    from navierstokes3d_amd.params import cavity_params
+
+    p = cavity_params(a.n, a.nz)
+    nx, ny, nz = p.nx, p.ny, p.nz
+    tdt = torch.float64 if a.dtype == "f64" else torch.float32
+    dev = torch.device("cuda", local_rank)
+    ctx = K.Context(local_rank, a.mode, async_=True)
+    ctx.set_pt_variant(a.variant)
+    grid = ZSlabGrid(nx, ny, nz)
+
+    # synthetic right-hand side ∇V = U(-1e-3,1e-3), seeded per rank; Pr = dPrdτ = 0 (SURVEY §8d Config 3)
+    gen = torch.Generator(device=dev); gen.manual_seed(12345 + rank)
+    Pr = K.zeros((nx, ny, nz), tdt, dev)
+    Pb = K.zeros((nx, ny, nz), tdt, dev)
+    D = K.zeros((nx - 2, ny - 2, nz - 2), tdt, dev)
+    rhs = K.zeros((nx, ny, nz), tdt, dev)
+    rhs.permute(2, 1, 0).uniform_(-1e-3, 1e-3, generator=gen)
+    pt = K.pt_params(Pr, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, L.NS3D_BC_MULTI, False, 0.0, 0.0,
+                     grid.z_lo_is_halo(), grid.z_hi_is_halo())
+
+    def step(Pa, Pq):
+        if world == 1:
+            K.pt_sweep(Pa, Pq, D, rhs, pt, 1, nz - 1, ctx=ctx)
+        else:  # seam planes first, exchange behind the interior sweep
+            K.pt_sweep(Pa, Pq, D, rhs, pt, 1, 2, ctx=ctx)
+            K.pt_sweep(Pa, Pq, D, rhs, pt, nz - 2, nz - 1, ctx=ctx)
+            work = grid.start_halo(Pq)
+            K.pt_sweep(Pa, Pq, D, rhs, pt, 2, nz - 2, ctx=ctx)
+            grid.finish_halo(work)
+
+    def run(n):
+        nonlocal Pr, Pb
+        for _ in range(n):
+            step(Pr, Pb)
+            Pr, Pb = Pb, Pr
+
+    run(a.warmup)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run(a.steps)
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, dev_ms = t[0].item(), t[1].item()
+    err = grid.max_g(K.residual_max(Pr, rhs, pt, ctx=ctx)) * p.err_scale
+    finite = bool(np.isfinite(err))
+
+    if rank == 0:
+        cells_g = nx * ny * grid.nz_g()
+        itemsize = 8 if a.dtype == "f64" else 4
+        kern_ms = dev_ms / a.steps                   # HIP events around the timed launches on the launch stream
+        abytes = algorithmic_bytes(nx, ny, nz, itemsize)
+        achieved = abytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pt_sweep_traffic.json")
+        if world == 1 and os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                key = "%dx%dx%d_%s_%s" % (nx, ny, nz, a.dtype, a.mode)
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mcells*PT-iter/s, fused pseudo-transient Poisson iteration, %dx%dx%d per GPU" % (nx, ny, nz),
+            "value": cells_g * a.steps / wall / 1e6,
+            "unit": "Mcells*iter/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": wall / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "lid-driven-cavity Poisson-only PT iteration (BASELINE configs[2])",
+                       "local_grid": [nx, ny, nz], "global_grid": [nx, ny, grid.nz_g()],
+                       "decomposition": "z-slabs x%d" % world, "arith_mode": a.mode, "variant": a.variant,
+                       "residual_after_run": err, "finite": finite},
+            "hbm_gbps_algorithmic": achieved * world,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "k_pt_sweep_zmarch", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": abytes},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(a.n, 128, a.cpu_iters, a.dtype)
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "Mcells*iter/s", "cores": 0, "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    ctx.sync()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

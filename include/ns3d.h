@@ -1,0 +1,179 @@
+/*
+ * ns3d.h — C ABI of libns3d.so: hand-written HIP (gfx950 / MI355X) kernels for the hot path of
+ * mattbuergler/NavierStokes3D, behind the reference's own kernel call signatures.
+ *
+ * The reference has no FFI: its "operator API" is ParallelStencil's calling convention
+ *     @parallel kernel!(arrays…, scalars…)
+ * used by the time loops scripts/NavierStokes3D_gpu.jl:119-142 ("gpu.jl") and
+ * scripts/NavierStokes3D_multi_gpu.jl:446-477 ("multi.jl").  Every entry point below replaces one of
+ * those kernels (cited per function) with the SAME positional argument order, followed by the cell grid
+ * (nx,ny,nz) that ParallelStencil derives from the array sizes.  INTEGRATION.md shows the Julia `ccall`
+ * stubs that bind them so the reference time loops run unchanged.
+ *
+ * Conventions
+ *  - All field pointers are DEVICE pointers to packed column-major arrays (x fastest) with exactly the
+ *    reference shapes (multi.jl:343-360):
+ *        Pr,C,C_o,τxx,τyy,τzz,∇V : (nx,ny,nz)      Vx,Vx_o : (nx+1,ny,nz)   Vy,Vy_o : (nx,ny+1,nz)
+ *        Vz,Vz_o : (nx,ny,nz+1)    τxy,τxz,τyz : (nx-1,ny-1,nz-1)           dPrdτ,Rp : (nx-2,ny-2,nz-2)
+ *    The caller owns every field buffer.  The library owns only its context (stream, reduction scratch,
+ *    a lazily allocated ping-pong Pr buffer for the fused PT path).
+ *  - Suffix _f64 / _f32 = element type of the arrays; scalar parameters are always C double (Julia
+ *    Float64 host values) and are converted to the element type on entry.
+ *  - Every function returns 0 (NS3D_OK) or a non-zero status; the message is available from
+ *    ns3d_last_error().  Nothing throws or aborts across the boundary.
+ *  - Like `@parallel`, every call is synchronous to the caller unless the context was created with
+ *    NS3D_ASYNC (then calls only enqueue on the context's stream; use ns3d_sync()).
+ *  - One host thread per context (as in the reference: one thread per rank); contexts are not
+ *    thread-safe.
+ *  - Arithmetic modes: NS3D_STRICT reproduces the reference's operation order with IEEE division and no
+ *    FMA contraction (bit-identical to the CPU oracle); NS3D_FAST uses reciprocal constants and FMA
+ *    (≤1e-6 relative L2 at equal iteration counts).
+ */
+#ifndef NS3D_H
+#define NS3D_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ns3d_ctx ns3d_ctx;
+
+enum {
+    NS3D_OK = 0,
+    NS3D_ERR_ARG = 1,   /* bad argument (null pointer, extent too small, …) */
+    NS3D_ERR_HIP = 2,   /* a HIP runtime call or kernel launch failed */
+    NS3D_ERR_STATE = 3  /* context misuse */
+};
+
+enum {
+    NS3D_STRICT = 0x0,
+    NS3D_FAST = 0x1,
+    NS3D_ASYNC = 0x2
+};
+
+/* bc_kind for the pressure / velocity boundary sequences */
+enum {
+    NS3D_BC_MULTI = 0, /* multi.jl:175-181 / :156-166 */
+    NS3D_BC_GPU = 1    /* gpu.jl:281-286 / :264-279 */
+};
+
+#define NS3D_VERSION 1
+int ns3d_version(void);
+const char *ns3d_last_error(void);
+
+/* Context = device + stream + scratch.  Replaces @init_parallel_stencil (gpu.jl:4-8). */
+ns3d_ctx *ns3d_create(int device, int flags);
+void ns3d_destroy(ns3d_ctx *ctx);
+int ns3d_flags(const ns3d_ctx *ctx);
+/* Use an existing hipStream_t (e.g. PyTorch's current stream); NULL = the context's own stream. */
+int ns3d_set_stream(ns3d_ctx *ctx, void *hip_stream);
+void *ns3d_get_stream(ns3d_ctx *ctx);
+int ns3d_sync(ns3d_ctx *ctx);
+/* Tuning knob for the fused PT sweep (0 = default); see DESIGN.md. */
+int ns3d_set_pt_variant(ns3d_ctx *ctx, int variant);
+
+/* Parameters of the fused pseudo-transient path (ns3d_pt_iterate / ns3d_pt_solve). */
+typedef struct ns3d_pt_params {
+    double rho, dt, dtau, damp; /* update_dPrdτ!(…,ρ,dt,dτ,damp,…)  multi.jl:70 */
+    double dx, dy, dz;
+    int nx, ny, nz;             /* local cell grid */
+    int bc_kind;                /* NS3D_BC_MULTI | NS3D_BC_GPU */
+    int owns_outlet;            /* multi.jl:179  `xve_g == lx/2`  → Pr[end,:,:] = outlet_val */
+    double outlet_val;          /* multi.jl:463  0.0 */
+    double g;                   /* gpu.jl:284 bc_xhydstatic!(Pr,dz,nz,g,ρ) */
+    int z_lo_is_halo;           /* z-slab seams: plane 1 / plane nz belong to the neighbour rank and are */
+    int z_hi_is_halo;           /*   filled by the halo exchange instead of bc_z! (multi.jl:182)        */
+} ns3d_pt_params;
+
+#define NS3D_DECL(T, S)                                                                                     \
+    /* update_τ!(τxx,τyy,τzz,τxy,τxz,τyz,Vx,Vy,Vz,μ,dx,dy,dz)      multi.jl:36-44   gpu.jl:177-185 */         \
+    int ns3d_update_tau_##S(ns3d_ctx *, T *txx, T *tyy, T *tzz, T *txy, T *txz, T *tyz, const T *Vx,         \
+                            const T *Vy, const T *Vz, double mu, double dx, double dy, double dz, int nx,    \
+                            int ny, int nz);                                                                 \
+    /* predict_V!(Vx,Vy,Vz,τxx,τyy,τzz,τxy,τxz,τyz,ρ,g,dt,dx,dy,dz) multi.jl:50-55   gpu.jl:187-192 */        \
+    int ns3d_predict_V_##S(ns3d_ctx *, T *Vx, T *Vy, T *Vz, const T *txx, const T *tyy, const T *tzz,        \
+                           const T *txy, const T *txz, const T *tyz, double rho, double g, double dt,         \
+                           double dx, double dy, double dz, int nx, int ny, int nz);                         \
+    /* set_cylinder!(C,Vx,Vy,Vz,a2,b2,ox,oy,sinβ,cosβ,xco_g,yco_g,zco_g,lx,ly,lz,dx,dy,dz) multi.jl:249-281 */\
+    int ns3d_set_cylinder_##S(ns3d_ctx *, T *C, T *Vx, T *Vy, T *Vz, double a2, double b2, double ox,        \
+                              double oy, double sinb, double cosb, double xco_g, double yco_g, double zco_g, \
+                              double lx, double ly, double lz, double dx, double dy, double dz, int nx,      \
+                              int ny, int nz);                                                               \
+    /* set_cylinder!(C,Vx,Vy,Vz,a2,b2,ox,oy,sinβ,cosβ,lx,ly,lz,dx,dy,dz)  gpu.jl:336-368 (incl. its dx-for-dy */\
+    int ns3d_set_cylinder_local_##S(ns3d_ctx *, T *C, T *Vx, T *Vy, T *Vz, double a2, double b2, double ox,  \
+                                    double oy, double sinb, double cosb, double lx, double ly, double lz,    \
+                                    double dx, double dy, double dz, int nx, int ny, int nz);                \
+    /* update_∇V!(∇V,Vx,Vy,Vz,dx,dy,dz)                             multi.jl:61-64   gpu.jl:194-197 */        \
+    int ns3d_update_divV_##S(ns3d_ctx *, T *divV, const T *Vx, const T *Vy, const T *Vz, double dx,          \
+                             double dy, double dz, int nx, int ny, int nz);                                  \
+    /* update_dPrdτ!(Pr,dPrdτ,∇V,ρ,dt,dτ,damp,dx,dy,dz)            multi.jl:70-73   gpu.jl:199-202 */        \
+    int ns3d_update_dPrdtau_##S(ns3d_ctx *, const T *Pr, T *dPrdtau, const T *divV, double rho, double dt,   \
+                                double dtau, double damp, double dx, double dy, double dz, int nx, int ny,   \
+                                int nz);                                                                     \
+    /* update_Pr!(Pr,dPrdτ,dτ)                                     multi.jl:79-82   gpu.jl:204-207 */        \
+    int ns3d_update_Pr_##S(ns3d_ctx *, T *Pr, const T *dPrdtau, double dtau, int nx, int ny, int nz);        \
+    /* compute_res!(Rp,Pr,∇V,ρ,dt,dx,dy,dz)                        multi.jl:88-91   gpu.jl:209-212 */        \
+    int ns3d_compute_res_##S(ns3d_ctx *, T *Rp, const T *Pr, const T *divV, double rho, double dt,           \
+                             double dx, double dy, double dz, int nx, int ny, int nz);                       \
+    /* maximum(abs.(A)) — NaN-propagating like Julia's maximum     multi.jl:466     gpu.jl:132 */            \
+    int ns3d_max_abs_##S(ns3d_ctx *, const T *A, long n_elems, double *out_host);                            \
+    /* correct_V!(Vx,Vy,Vz,Pr,dt,ρ,dx,dy,dz)                        multi.jl:97-102  gpu.jl:214-219 */        \
+    int ns3d_correct_V_##S(ns3d_ctx *, T *Vx, T *Vy, T *Vz, const T *Pr, double dt, double rho, double dx,   \
+                           double dy, double dz, int nx, int ny, int nz);                                    \
+    /* bc_x!/bc_y!/bc_z!(A) on an array of extents (sx,sy,sz)       multi.jl:108-132 gpu.jl:221-237 */        \
+    int ns3d_bc_x_##S(ns3d_ctx *, T *A, int sx, int sy, int sz);                                             \
+    int ns3d_bc_y_##S(ns3d_ctx *, T *A, int sx, int sy, int sz);                                             \
+    int ns3d_bc_z_##S(ns3d_ctx *, T *A, int sx, int sy, int sz);                                             \
+    /* bc_zV!(A)                                                    gpu.jl:239-243 */                        \
+    int ns3d_bc_zV_##S(ns3d_ctx *, T *A, int sx, int sy, int sz);                                            \
+    /* bc_xhydstatic!(A,dz,nz,g,ρ)                                  gpu.jl:257-261 */                        \
+    int ns3d_bc_xhydstatic_##S(ns3d_ctx *, T *A, double dz, int nz, double g, double rho, int sx, int sy,    \
+                               int sz);                                                                      \
+    /* bc_x_Vx!(A,V)                                                multi.jl:138-141 */                      \
+    int ns3d_bc_x_Vx_##S(ns3d_ctx *, T *A, double V, int sx, int sy, int sz);                                \
+    /* bc_x_Pr!(A,val)                                              multi.jl:147-150 */                      \
+    int ns3d_bc_x_Pr_##S(ns3d_ctx *, T *A, double val, int sx, int sy, int sz);                              \
+    /* X_o .= X                                                     multi.jl:475     gpu.jl:141 */            \
+    int ns3d_copy_##S(ns3d_ctx *, T *dst, const T *src, long n_elems);                                       \
+    /* advect!(Vx,Vx_o,Vy,Vy_o,Vz,Vz_o,C,C_o,dt,dx,dy,dz)           multi.jl:217-243 gpu.jl:308-334           \
+     * faithful!=0 reproduces the reference (third branch back-tracks Vy, Vz never advected).            */  \
+    int ns3d_advect_##S(ns3d_ctx *, T *Vx, const T *Vx_o, T *Vy, const T *Vy_o, T *Vz, const T *Vz_o, T *C,  \
+                        const T *C_o, double dt, double dx, double dy, double dz, int nx, int ny, int nz,    \
+                        int faithful);                                                                       \
+    /* ---- host sequences of the reference, one call each ---- */                                           \
+    /* set_bc_Pr!  multi.jl:175-181 (kind 0, without the halo update) / gpu.jl:281-286 (kind 1) */           \
+    int ns3d_set_bc_Pr_##S(ns3d_ctx *, T *Pr, int bc_kind, int owns_outlet, double outlet_val, double dz,    \
+                           int nz_arg, double g, double rho, int nx, int ny, int nz);                        \
+    /* set_bc_Vel! multi.jl:156-166 (kind 0, without the halo update) / gpu.jl:264-279 (kind 1) */           \
+    int ns3d_set_bc_Vel_##S(ns3d_ctx *, T *Vx, T *Vy, T *Vz, int bc_kind, int owns_inlet, double vin,        \
+                            int nx, int ny, int nz);                                                         \
+    /* ---- fused fast path (not in the reference; same results) ----                                        \
+     * n_iters × { update_dPrdτ! ; update_Pr! ; set_bc_Pr! }  (multi.jl:459-463 / gpu.jl:127-129) as ONE     \
+     * ping-pong sweep per iteration with the boundary planes folded in.  Pr holds the result on return. */  \
+    int ns3d_pt_iterate_##S(ns3d_ctx *, T *Pr, T *dPrdtau, const T *divV, const ns3d_pt_params *p,           \
+                            int n_iters);                                                                    \
+    /* One sweep Pr_in → Pr_out (distinct buffers; halo planes of Pr_out are NOT written when               \
+     * z_*_is_halo) restricted to interior planes k0 ≤ k < k1 (0-based Pr plane index, 1 ≤ k0, k1 ≤ nz-1).  \
+     * Building block for the z-slab overlap schedule (boundary planes first, interior behind the halo     \
+     * exchange). */                                                                                         \
+    int ns3d_pt_sweep_##S(ns3d_ctx *, const T *Pr_in, T *Pr_out, T *dPrdtau, const T *divV,                  \
+                          const ns3d_pt_params *p, int k0, int k1);                                          \
+    /* max|∇²Pr − ρ/dt ∇V| over the interior = maximum(abs.(Rp)) after compute_res!, without writing Rp.   \
+     * NaN-propagating.  (multi.jl:465-466) */                                                               \
+    int ns3d_residual_max_##S(ns3d_ctx *, const T *Pr, const T *divV, const ns3d_pt_params *p,               \
+                              double *out_host);                                                             \
+    /* The whole inner loop multi.jl:458-471 / gpu.jl:126-137 on one rank: at most niter iterations, every   \
+     * nchk-th computes err = max|Rp|*err_scale, stops on err<eps || !isfinite(err) (eps<0: never stop).     \
+     * err_hist (capacity max_checks) may be NULL. */                                                        \
+    int ns3d_pt_solve_##S(ns3d_ctx *, T *Pr, T *dPrdtau, const T *divV, const ns3d_pt_params *p, double eps, \
+                          int niter, int nchk, double err_scale, int *iters_done, double *err_hist,          \
+                          int max_checks, int *n_checks);
+
+NS3D_DECL(double, f64)
+NS3D_DECL(float, f32)
+#undef NS3D_DECL
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NS3D_H */

@@ -1,0 +1,78 @@
+"""Build libns3d.so (gfx950 only) in-tree with hipcc.
+
+    python -m navierstokes3d_amd.build [--force]
+
+The kernel translation unit is compiled twice: STRICT (-ffp-contract=off: reference operation order, IEEE
+division, no FMA — bit-identical to the CPU oracle) and FAST (-ffp-contract=fast + reciprocal constants).
+hipcc cross-compiles without a GPU; the resulting .so is git-ignored but travels to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libns3d.so")
+ARCH = "gfx950"
+
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+UNITS = [
+    # (source, object, extra flags)
+    ("ns3d_kernels.hip", "ns3d_kernels_strict.o", ["-DNS3D_MODE_STRICT", "-ffp-contract=off"]),
+    ("ns3d_kernels.hip", "ns3d_kernels_fast.o", ["-DNS3D_MODE_FAST", "-ffp-contract=fast"]),
+    ("ns3d_api.cpp", "ns3d_api.o", ["-x", "hip"]),
+]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libns3d.so cannot be built (there is no CPU fallback)")
+    return exe
+
+
+def _sources():
+    out = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    out.append(os.path.join(HERE, "..", "include", "ns3d.h"))
+    return out
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(s) > t for s in _sources())
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    """Compile every HIP translation unit for gfx950 and link libns3d.so. Returns the library path."""
+    if not force and not needs_build():
+        return LIB
+    hipcc = _hipcc()
+    bdir = os.path.join(HERE, "build")
+    os.makedirs(bdir, exist_ok=True)
+    objs = []
+    procs = []
+    for src, obj, flags in UNITS:
+        o = os.path.join(bdir, obj)
+        cmd = [hipcc] + COMMON + list(flags) + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(o)
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), out.decode(errors="replace")))
+        if verbose and out:
+            print(out.decode(errors="replace"))
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

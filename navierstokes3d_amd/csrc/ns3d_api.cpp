@@ -1,0 +1,457 @@
+// ns3d_api.cpp — the extern "C" boundary of libns3d.so (see include/ns3d.h for the contract and the
+// reference file:line each entry point replaces).  Host-only logic: argument checks, mode dispatch
+// (strict / fast kernels), the context (stream, reduction scratch, ping-pong buffer) and the
+// pseudo-transient loop of multi.jl:458-471 / gpu.jl:126-137.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "ns3d_launch.h"
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+struct ns3d_ctx {
+    int device;
+    int flags;
+    hipStream_t own_stream;
+    hipStream_t stream;
+    unsigned long long *key_dev;  // device scratch for max reductions
+    unsigned long long *key_host; // pinned host mirror
+    void *pingpong;               // second Pr buffer of the fused PT path (lazily sized)
+    size_t pingpong_bytes;
+    int pt_variant;
+};
+
+#define HIPCHK(ctx, expr)                                                                                   \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return fail(NS3D_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));            \
+    } while (0)
+
+#define CHECK_CTX(ctx)                                                                                      \
+    do {                                                                                                    \
+        if (!(ctx)) return fail(NS3D_ERR_ARG, "%s: null context", __func__);                                \
+        hipError_t e_ = hipSetDevice((ctx)->device);                                                        \
+        if (e_ != hipSuccess) return fail(NS3D_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e_));         \
+    } while (0)
+
+#define CHECK_PTRS(...)                                                                                     \
+    do {                                                                                                    \
+        const void *ps_[] = {__VA_ARGS__};                                                                  \
+        for (size_t q_ = 0; q_ < sizeof ps_ / sizeof ps_[0]; ++q_)                                          \
+            if (!ps_[q_]) return fail(NS3D_ERR_ARG, "%s: null field pointer (argument %zu)", __func__, q_); \
+    } while (0)
+
+#define CHECK_GRID(nx, ny, nz, m)                                                                           \
+    do {                                                                                                    \
+        if ((nx) < (m) || (ny) < (m) || (nz) < (m))                                                         \
+            return fail(NS3D_ERR_ARG, "%s: grid %dx%dx%d too small (need >= %d per direction)", __func__,   \
+                        (nx), (ny), (nz), (m));                                                             \
+    } while (0)
+
+// launch + (unless NS3D_ASYNC) block like `@parallel` does
+static int finish(ns3d_ctx *ctx, hipError_t e, const char *what)
+{
+    if (e != hipSuccess) return fail(NS3D_ERR_HIP, "%s launch: %s", what, hipGetErrorString(e));
+    if (!(ctx->flags & NS3D_ASYNC)) {
+        e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return fail(NS3D_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    }
+    return NS3D_OK;
+}
+
+#define DISPATCH(ctx, call) (((ctx)->flags & NS3D_FAST) ? ns3d_fast::call : ns3d_strict::call)
+
+extern "C" {
+
+int ns3d_version(void) { return NS3D_VERSION; }
+const char *ns3d_last_error(void) { return g_err; }
+
+ns3d_ctx *ns3d_create(int device, int flags)
+{
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        fail(NS3D_ERR_HIP, "ns3d_create: no HIP device (%s) — libns3d has no CPU path", hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) {
+        fail(NS3D_ERR_ARG, "ns3d_create: device %d out of range [0,%d)", device, ndev);
+        return nullptr;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        fail(NS3D_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+        return nullptr;
+    }
+    ns3d_ctx *c = new ns3d_ctx();
+    c->device = device;
+    c->flags = flags;
+    c->pingpong = nullptr;
+    c->pingpong_bytes = 0;
+    c->pt_variant = 0;
+    c->key_dev = nullptr;
+    c->key_host = nullptr;
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipMalloc((void **)&c->key_dev, 64)) != hipSuccess ||
+        (e = hipHostMalloc((void **)&c->key_host, 64, hipHostMallocDefault)) != hipSuccess) {
+        fail(NS3D_ERR_HIP, "ns3d_create: %s", hipGetErrorString(e));
+        delete c;
+        return nullptr;
+    }
+    c->stream = c->own_stream;
+    return c;
+}
+
+void ns3d_destroy(ns3d_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->pingpong) (void)hipFree(c->pingpong);
+    if (c->key_dev) (void)hipFree(c->key_dev);
+    if (c->key_host) (void)hipHostFree(c->key_host);
+    (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int ns3d_flags(const ns3d_ctx *c) { return c ? c->flags : -1; }
+
+int ns3d_set_stream(ns3d_ctx *c, void *s)
+{
+    if (!c) return fail(NS3D_ERR_ARG, "ns3d_set_stream: null context");
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return NS3D_OK;
+}
+void *ns3d_get_stream(ns3d_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int ns3d_sync(ns3d_ctx *c)
+{
+    CHECK_CTX(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return NS3D_OK;
+}
+
+int ns3d_set_pt_variant(ns3d_ctx *c, int v)
+{
+    if (!c) return fail(NS3D_ERR_ARG, "ns3d_set_pt_variant: null context");
+    if (v < 0 || v >= 700) return fail(NS3D_ERR_ARG, "ns3d_set_pt_variant: unknown variant %d", v);
+    c->pt_variant = v;
+    return NS3D_OK;
+}
+
+} // extern "C"
+
+// read back a reduction key: 8-byte D2H into pinned memory + stream sync (the only host round trip of the PT loop)
+static int fetch_key(ns3d_ctx *c, double *out)
+{
+    HIPCHK(c, hipMemcpyAsync(c->key_host, c->key_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double v;
+    std::memcpy(&v, c->key_host, sizeof v);
+    *out = v;
+    return NS3D_OK;
+}
+
+static int check_pt_params(const ns3d_pt_params *p, const char *fn)
+{
+    if (!p) return fail(NS3D_ERR_ARG, "%s: null params", fn);
+    if (p->nx < 3 || p->ny < 3 || p->nz < 3)
+        return fail(NS3D_ERR_ARG, "%s: grid %dx%dx%d too small for the fused PT sweep (need >= 3)", fn, p->nx, p->ny,
+                    p->nz);
+    if (p->bc_kind != NS3D_BC_MULTI && p->bc_kind != NS3D_BC_GPU) return fail(NS3D_ERR_ARG, "%s: bad bc_kind %d", fn, p->bc_kind);
+    if (p->bc_kind == NS3D_BC_GPU && (p->z_lo_is_halo || p->z_hi_is_halo))
+        return fail(NS3D_ERR_ARG, "%s: gpu.jl boundary set is single-device (no z halos)", fn);
+    return NS3D_OK;
+}
+
+template <class T>
+static int ensure_pingpong(ns3d_ctx *c, const ns3d_pt_params *p, T **buf)
+{
+    const size_t need = (size_t)p->nx * p->ny * p->nz * sizeof(T);
+    if (c->pingpong_bytes < need) {
+        if (c->pingpong) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipFree(c->pingpong));
+            c->pingpong = nullptr;
+            c->pingpong_bytes = 0;
+        }
+        HIPCHK(c, hipMalloc(&c->pingpong, need));
+        c->pingpong_bytes = need;
+    }
+    *buf = (T *)c->pingpong;
+    return NS3D_OK;
+}
+
+// n_iters fused sweeps, result left in Pr (one D2D copy when n_iters is odd).  With z halos the scratch
+// buffer's halo planes are seeded from Pr first (a sweep never writes them).
+template <class T>
+static int pt_iterate_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_params *p, int n_iters)
+{
+    if (n_iters <= 0) return NS3D_OK;
+    T *other = nullptr;
+    int rc = ensure_pingpong<T>(c, p, &other);
+    if (rc) return rc;
+    const size_t plane = (size_t)p->nx * p->ny;
+    if (p->z_lo_is_halo) HIPCHK(c, hipMemcpyAsync(other, Pr, plane * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+    if (p->z_hi_is_halo)
+        HIPCHK(c, hipMemcpyAsync(other + plane * (p->nz - 1), Pr + plane * (p->nz - 1), plane * sizeof(T),
+                                 hipMemcpyDeviceToDevice, c->stream));
+    T *src = Pr, *dst = other;
+    for (int it = 0; it < n_iters; ++it) {
+        hipError_t e = DISPATCH(c, pt_sweep<T>(c->stream, c->pt_variant, src, dst, D, divV, *p, 1, p->nz - 1));
+        if (e != hipSuccess) return fail(NS3D_ERR_HIP, "pt_sweep launch: %s", hipGetErrorString(e));
+        T *t = src; src = dst; dst = t;
+    }
+    if (src != Pr)
+        HIPCHK(c, hipMemcpyAsync(Pr, src, plane * p->nz * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+    return NS3D_OK;
+}
+
+template <class T>
+static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_params *p, double eps, int niter,
+                         int nchk, double err_scale, int *iters_done, double *err_hist, int max_checks, int *n_checks)
+{
+    T *other = nullptr;
+    int rc = ensure_pingpong<T>(c, p, &other);
+    if (rc) return rc;
+    const size_t plane = (size_t)p->nx * p->ny;
+    T *src = Pr, *dst = other;
+    int checks = 0, iter = 0, done = niter;
+    for (iter = 1; iter <= niter; ++iter) {
+        hipError_t e = DISPATCH(c, pt_sweep<T>(c->stream, c->pt_variant, src, dst, D, divV, *p, 1, p->nz - 1));
+        if (e != hipSuccess) return fail(NS3D_ERR_HIP, "pt_sweep launch: %s", hipGetErrorString(e));
+        T *t = src; src = dst; dst = t;
+        if (nchk > 0 && iter % nchk == 0) { // multi.jl:464-469
+            e = DISPATCH(c, residual_max_key<T>(c->stream, src, divV, *p, c->key_dev));
+            if (e != hipSuccess) return fail(NS3D_ERR_HIP, "residual launch: %s", hipGetErrorString(e));
+            double mx;
+            if ((rc = fetch_key(c, &mx))) return rc;
+            const double err = mx * err_scale;
+            if (err_hist && checks < max_checks) err_hist[checks] = err;
+            ++checks;
+            if (eps >= 0 && (err < eps || !std::isfinite(err))) { done = iter; break; }
+        }
+    }
+    if (src != Pr)
+        HIPCHK(c, hipMemcpyAsync(Pr, src, plane * p->nz * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+    if (iters_done) *iters_done = done;
+    if (n_checks) *n_checks = checks;
+    return NS3D_OK;
+}
+
+#define NS3D_DEFINE(T, S)                                                                                    \
+    extern "C" int ns3d_update_tau_##S(ns3d_ctx *c, T *txx, T *tyy, T *tzz, T *txy, T *txz, T *tyz,          \
+                                       const T *Vx, const T *Vy, const T *Vz, double mu, double dx,          \
+                                       double dy, double dz, int nx, int ny, int nz)                         \
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(txx, tyy, tzz, txy, txz, tyz, Vx, Vy, Vz); CHECK_GRID(nx, ny, nz, 2);       \
+        return finish(c, DISPATCH(c, update_tau<T>(c->stream, txx, tyy, tzz, txy, txz, tyz, Vx, Vy, Vz, mu,  \
+                                                   dx, dy, dz, nx, ny, nz)), "update_tau");                  \
+    }                                                                                                        \
+    extern "C" int ns3d_predict_V_##S(ns3d_ctx *c, T *Vx, T *Vy, T *Vz, const T *txx, const T *tyy,          \
+                                      const T *tzz, const T *txy, const T *txz, const T *tyz, double rho,    \
+                                      double g, double dt, double dx, double dy, double dz, int nx, int ny,  \
+                                      int nz)                                                                \
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(Vx, Vy, Vz, txx, tyy, tzz, txy, txz, tyz); CHECK_GRID(nx, ny, nz, 2);       \
+        return finish(c, DISPATCH(c, predict_V<T>(c->stream, Vx, Vy, Vz, txx, tyy, tzz, txy, txz, tyz, rho,  \
+                                                  g, dt, dx, dy, dz, nx, ny, nz)), "predict_V");             \
+    }                                                                                                        \
+    extern "C" int ns3d_set_cylinder_##S(ns3d_ctx *c, T *C, T *Vx, T *Vy, T *Vz, double a2, double b2,       \
+                                         double ox, double oy, double sinb, double cosb, double xco_g,       \
+                                         double yco_g, double zco_g, double lx, double ly, double lz,        \
+                                         double dx, double dy, double dz, int nx, int ny, int nz)            \
+    {                                                                                                        \
+        (void)zco_g; (void)lz; (void)dz;                                                                     \
+        CHECK_CTX(c); CHECK_PTRS(C, Vx, Vy, Vz); CHECK_GRID(nx, ny, nz, 1);                                  \
+        return finish(c, DISPATCH(c, set_cylinder<T>(c->stream, C, Vx, Vy, Vz, a2, b2, ox, oy, sinb, cosb,   \
+                                                     0, xco_g, yco_g, lx, ly, dx, dy, nx, ny, nz)),          \
+                      "set_cylinder");                                                                       \
+    }                                                                                                        \
+    extern "C" int ns3d_set_cylinder_local_##S(ns3d_ctx *c, T *C, T *Vx, T *Vy, T *Vz, double a2, double b2, \
+                                               double ox, double oy, double sinb, double cosb, double lx,    \
+                                               double ly, double lz, double dx, double dy, double dz,        \
+                                               int nx, int ny, int nz)                                       \
+    {                                                                                                        \
+        (void)lz; (void)dz;                                                                                  \
+        CHECK_CTX(c); CHECK_PTRS(C, Vx, Vy, Vz); CHECK_GRID(nx, ny, nz, 1);                                  \
+        return finish(c, DISPATCH(c, set_cylinder<T>(c->stream, C, Vx, Vy, Vz, a2, b2, ox, oy, sinb, cosb,   \
+                                                     1, 0.0, 0.0, lx, ly, dx, dy, nx, ny, nz)),              \
+                      "set_cylinder_local");                                                                 \
+    }                                                                                                        \
+    extern "C" int ns3d_update_divV_##S(ns3d_ctx *c, T *divV, const T *Vx, const T *Vy, const T *Vz,         \
+                                        double dx, double dy, double dz, int nx, int ny, int nz)             \
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(divV, Vx, Vy, Vz); CHECK_GRID(nx, ny, nz, 1);                               \
+        return finish(c, DISPATCH(c, update_divV<T>(c->stream, divV, Vx, Vy, Vz, dx, dy, dz, nx, ny, nz)),   \
+                      "update_divV");                                                                        \
+    }                                                                                                        \
+    extern "C" int ns3d_update_dPrdtau_##S(ns3d_ctx *c, const T *Pr, T *dPrdtau, const T *divV, double rho,  \
+                                           double dt, double dtau, double damp, double dx, double dy,        \
+                                           double dz, int nx, int ny, int nz)                                \
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(Pr, dPrdtau, divV); CHECK_GRID(nx, ny, nz, 3);                              \
+        return finish(c, DISPATCH(c, update_dPrdtau<T>(c->stream, Pr, dPrdtau, divV, rho, dt, dtau, damp,    \
+                                                       dx, dy, dz, nx, ny, nz)), "update_dPrdtau");          \
+    }                                                                                                        \
+    extern "C" int ns3d_update_Pr_##S(ns3d_ctx *c, T *Pr, const T *dPrdtau, double dtau, int nx, int ny,     \
+                                      int nz)                                                                \
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(Pr, dPrdtau); CHECK_GRID(nx, ny, nz, 3);                                    \
+        return finish(c, DISPATCH(c, update_Pr<T>(c->stream, Pr, dPrdtau, dtau, nx, ny, nz)), "update_Pr");  \
+    }                                                                                                        \
+    extern "C" int ns3d_compute_res_##S(ns3d_ctx *c, T *Rp, const T *Pr, const T *divV, double rho,          \
+                                        double dt, double dx, double dy, double dz, int nx, int ny, int nz)  \
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(Rp, Pr, divV); CHECK_GRID(nx, ny, nz, 3);                                   \
+        return finish(c, DISPATCH(c, compute_res<T>(c->stream, Rp, Pr, divV, rho, dt, dx, dy, dz, nx, ny,    \
+                                                    nz)), "compute_res");                                    \
+    }                                                                                                        \
+    extern "C" int ns3d_max_abs_##S(ns3d_ctx *c, const T *A, long n, double *out_host)                       \
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(A, out_host);                                                               \
+        if (n < 0) return fail(NS3D_ERR_ARG, "ns3d_max_abs: negative length");                               \
+        hipError_t e = DISPATCH(c, max_abs_key<T>(c->stream, A, n, c->key_dev));                             \
+        if (e != hipSuccess) return fail(NS3D_ERR_HIP, "max_abs launch: %s", hipGetErrorString(e));          \
+        return fetch_key(c, out_host);                                                                       \
+    }                                                                                                        \
+    extern "C" int ns3d_correct_V_##S(ns3d_ctx *c, T *Vx, T *Vy, T *Vz, const T *Pr, double dt, double rho,  \
+                                      double dx, double dy, double dz, int nx, int ny, int nz)               \
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(Vx, Vy, Vz, Pr); CHECK_GRID(nx, ny, nz, 2);                                 \
+        return finish(c, DISPATCH(c, correct_V<T>(c->stream, Vx, Vy, Vz, Pr, dt, rho, dx, dy, dz, nx, ny,    \
+                                                  nz)), "correct_V");                                        \
+    }                                                                                                        \
+    static int bc_##S(ns3d_ctx *c, int which, T *A, int sx, int sy, int sz, double a, double b, int nz_arg,  \
+                      const char *name)                                                                      \
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(A);                                                                         \
+        if (sx < 2 || sy < 2 || sz < 2) return fail(NS3D_ERR_ARG, "%s: extents %dx%dx%d too small", name,    \
+                                                    sx, sy, sz);                                             \
+        return finish(c, DISPATCH(c, bc_plane<T>(c->stream, which, A, sx, sy, sz, a, b, 0.0, nz_arg)), name);\
+    }                                                                                                        \
+    extern "C" int ns3d_bc_x_##S(ns3d_ctx *c, T *A, int sx, int sy, int sz) { return bc_##S(c, 0, A, sx, sy, sz, 0, 0, 0, "bc_x"); } \
+    extern "C" int ns3d_bc_y_##S(ns3d_ctx *c, T *A, int sx, int sy, int sz) { return bc_##S(c, 1, A, sx, sy, sz, 0, 0, 0, "bc_y"); } \
+    extern "C" int ns3d_bc_z_##S(ns3d_ctx *c, T *A, int sx, int sy, int sz) { return bc_##S(c, 2, A, sx, sy, sz, 0, 0, 0, "bc_z"); } \
+    extern "C" int ns3d_bc_zV_##S(ns3d_ctx *c, T *A, int sx, int sy, int sz) { return bc_##S(c, 3, A, sx, sy, sz, 0, 0, 0, "bc_zV"); } \
+    extern "C" int ns3d_bc_xhydstatic_##S(ns3d_ctx *c, T *A, double dz, int nz, double g, double rho,        \
+                                          int sx, int sy, int sz)                                            \
+    {                                                                                                        \
+        return bc_##S(c, 4, A, sx, sy, sz, (double)((T)rho * (T)g), dz, nz, "bc_xhydstatic");                \
+    }                                                                                                        \
+    extern "C" int ns3d_bc_x_Vx_##S(ns3d_ctx *c, T *A, double V, int sx, int sy, int sz) { return bc_##S(c, 5, A, sx, sy, sz, V, 0, 0, "bc_x_Vx"); } \
+    extern "C" int ns3d_bc_x_Pr_##S(ns3d_ctx *c, T *A, double v, int sx, int sy, int sz) { return bc_##S(c, 6, A, sx, sy, sz, v, 0, 0, "bc_x_Pr"); } \
+    extern "C" int ns3d_copy_##S(ns3d_ctx *c, T *dst, const T *src, long n)                                  \
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(dst, src);                                                                  \
+        if (n < 0) return fail(NS3D_ERR_ARG, "ns3d_copy: negative length");                                  \
+        return finish(c, hipMemcpyAsync(dst, src, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, c->stream),\
+                      "copy");                                                                               \
+    }                                                                                                        \
+    extern "C" int ns3d_advect_##S(ns3d_ctx *c, T *Vx, const T *Vx_o, T *Vy, const T *Vy_o, T *Vz,           \
+                                   const T *Vz_o, T *C, const T *C_o, double dt, double dx, double dy,       \
+                                   double dz, int nx, int ny, int nz, int faithful)                          \
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, C, C_o); CHECK_GRID(nx, ny, nz, 1);           \
+        return finish(c, DISPATCH(c, advect<T>(c->stream, Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, C, C_o, dt, dx, dy,  \
+                                               dz, nx, ny, nz, faithful)), "advect");                        \
+    }                                                                                                        \
+    extern "C" int ns3d_set_bc_Pr_##S(ns3d_ctx *c, T *Pr, int bc_kind, int owns_outlet, double outlet_val,   \
+                                      double dz, int nz_arg, double g, double rho, int nx, int ny, int nz)   \
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(Pr); CHECK_GRID(nx, ny, nz, 2);                                             \
+        hipError_t e = hipSuccess;                                                                           \
+        hipStream_t s = c->stream;                                                                           \
+        if (bc_kind == NS3D_BC_MULTI) { /* multi.jl:176-181 */                                               \
+            e = DISPATCH(c, bc_plane<T>(s, 0, Pr, nx, ny, nz, 0, 0, 0, 0));                                  \
+            if (e == hipSuccess) e = DISPATCH(c, bc_plane<T>(s, 1, Pr, nx, ny, nz, 0, 0, 0, 0));             \
+            if (e == hipSuccess) e = DISPATCH(c, bc_plane<T>(s, 2, Pr, nx, ny, nz, 0, 0, 0, 0));             \
+            if (e == hipSuccess && owns_outlet) e = DISPATCH(c, bc_plane<T>(s, 6, Pr, nx, ny, nz, outlet_val, 0, 0, 0)); \
+        } else if (bc_kind == NS3D_BC_GPU) { /* gpu.jl:282-284 */                                            \
+            e = DISPATCH(c, bc_plane<T>(s, 1, Pr, nx, ny, nz, 0, 0, 0, 0));                                  \
+            if (e == hipSuccess) e = DISPATCH(c, bc_plane<T>(s, 2, Pr, nx, ny, nz, 0, 0, 0, 0));             \
+            if (e == hipSuccess) e = DISPATCH(c, bc_plane<T>(s, 4, Pr, nx, ny, nz, (double)((T)rho * (T)g), dz, 0, nz_arg)); \
+        } else return fail(NS3D_ERR_ARG, "ns3d_set_bc_Pr: bad bc_kind %d", bc_kind);                         \
+        return finish(c, e, "set_bc_Pr");                                                                    \
+    }                                                                                                        \
+    extern "C" int ns3d_set_bc_Vel_##S(ns3d_ctx *c, T *Vx, T *Vy, T *Vz, int bc_kind, int owns_inlet,        \
+                                       double vin, int nx, int ny, int nz)                                   \
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(Vx, Vy, Vz); CHECK_GRID(nx, ny, nz, 2);                                     \
+        hipStream_t s = c->stream;                                                                           \
+        hipError_t e = hipSuccess;                                                                           \
+        struct { int which; T *A; int sx, sy, sz; } seq[9];                                                  \
+        int n = 0;                                                                                           \
+        if (bc_kind == NS3D_BC_MULTI) { /* multi.jl:157-163 */                                               \
+            seq[n++] = {0, Vx, nx + 1, ny, nz}; seq[n++] = {1, Vx, nx + 1, ny, nz}; seq[n++] = {2, Vx, nx + 1, ny, nz}; \
+            seq[n++] = {0, Vy, nx, ny + 1, nz}; seq[n++] = {2, Vy, nx, ny + 1, nz};                          \
+            seq[n++] = {0, Vz, nx, ny, nz + 1}; seq[n++] = {1, Vz, nx, ny, nz + 1};                          \
+        } else if (bc_kind == NS3D_BC_GPU) { /* gpu.jl:265-276 */                                            \
+            seq[n++] = {0, Vx, nx + 1, ny, nz}; seq[n++] = {1, Vx, nx + 1, ny, nz}; seq[n++] = {3, Vx, nx + 1, ny, nz}; \
+            seq[n++] = {0, Vy, nx, ny + 1, nz}; seq[n++] = {1, Vy, nx, ny + 1, nz}; seq[n++] = {3, Vy, nx, ny + 1, nz}; \
+            seq[n++] = {0, Vz, nx, ny, nz + 1}; seq[n++] = {1, Vz, nx, ny, nz + 1}; seq[n++] = {3, Vz, nx, ny, nz + 1}; \
+        } else return fail(NS3D_ERR_ARG, "ns3d_set_bc_Vel: bad bc_kind %d", bc_kind);                        \
+        for (int q = 0; q < n && e == hipSuccess; ++q)                                                       \
+            e = DISPATCH(c, bc_plane<T>(s, seq[q].which, seq[q].A, seq[q].sx, seq[q].sy, seq[q].sz, 0, 0, 0, 0)); \
+        if (e == hipSuccess && bc_kind == NS3D_BC_MULTI && owns_inlet) /* multi.jl:164-166 */                \
+            e = DISPATCH(c, bc_plane<T>(s, 5, Vx, nx + 1, ny, nz, vin, 0, 0, 0));                            \
+        return finish(c, e, "set_bc_Vel");                                                                   \
+    }                                                                                                        \
+    extern "C" int ns3d_pt_iterate_##S(ns3d_ctx *c, T *Pr, T *dPrdtau, const T *divV,                        \
+                                       const ns3d_pt_params *p, int n_iters)                                 \
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(Pr, dPrdtau, divV);                                                         \
+        int rc = check_pt_params(p, "ns3d_pt_iterate");                                                      \
+        if (rc) return rc;                                                                                   \
+        if ((rc = pt_iterate_impl<T>(c, Pr, dPrdtau, divV, p, n_iters))) return rc;                          \
+        return finish(c, hipSuccess, "pt_iterate");                                                          \
+    }                                                                                                        \
+    extern "C" int ns3d_pt_sweep_##S(ns3d_ctx *c, const T *Pr_in, T *Pr_out, T *dPrdtau, const T *divV,      \
+                                     const ns3d_pt_params *p, int k0, int k1)                                \
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(Pr_in, Pr_out, dPrdtau, divV);                                              \
+        int rc = check_pt_params(p, "ns3d_pt_sweep");                                                        \
+        if (rc) return rc;                                                                                   \
+        if (Pr_in == Pr_out) return fail(NS3D_ERR_ARG, "ns3d_pt_sweep: Pr_in and Pr_out must differ");       \
+        if (k0 < 1 || k1 > p->nz - 1 || k0 > k1)                                                             \
+            return fail(NS3D_ERR_ARG, "ns3d_pt_sweep: plane range [%d,%d) outside [1,%d)", k0, k1, p->nz - 1);\
+        return finish(c, DISPATCH(c, pt_sweep<T>(c->stream, c->pt_variant, Pr_in, Pr_out, dPrdtau, divV, *p, \
+                                                 k0, k1)), "pt_sweep");                                      \
+    }                                                                                                        \
+    extern "C" int ns3d_residual_max_##S(ns3d_ctx *c, const T *Pr, const T *divV, const ns3d_pt_params *p,   \
+                                         double *out_host)                                                   \
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(Pr, divV, out_host);                                                        \
+        int rc = check_pt_params(p, "ns3d_residual_max");                                                    \
+        if (rc) return rc;                                                                                   \
+        hipError_t e = DISPATCH(c, residual_max_key<T>(c->stream, Pr, divV, *p, c->key_dev));                \
+        if (e != hipSuccess) return fail(NS3D_ERR_HIP, "residual launch: %s", hipGetErrorString(e));         \
+        return fetch_key(c, out_host);                                                                       \
+    }                                                                                                        \
+    extern "C" int ns3d_pt_solve_##S(ns3d_ctx *c, T *Pr, T *dPrdtau, const T *divV, const ns3d_pt_params *p, \
+                                     double eps, int niter, int nchk, double err_scale, int *iters_done,     \
+                                     double *err_hist, int max_checks, int *n_checks)                        \
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(Pr, dPrdtau, divV);                                                         \
+        int rc = check_pt_params(p, "ns3d_pt_solve");                                                        \
+        if (rc) return rc;                                                                                   \
+        if (p->z_lo_is_halo || p->z_hi_is_halo)                                                              \
+            return fail(NS3D_ERR_ARG, "ns3d_pt_solve: single-rank loop; drive z-slab ranks with ns3d_pt_sweep + halo exchange"); \
+        if (niter < 0 || nchk < 0) return fail(NS3D_ERR_ARG, "ns3d_pt_solve: negative niter/nchk");          \
+        if ((rc = pt_solve_impl<T>(c, Pr, dPrdtau, divV, p, eps, niter, nchk, err_scale, iters_done,         \
+                                   err_hist, max_checks, n_checks))) return rc;                              \
+        return finish(c, hipSuccess, "pt_solve");                                                            \
+    }
+
+NS3D_DEFINE(double, f64)
+NS3D_DEFINE(float, f32)

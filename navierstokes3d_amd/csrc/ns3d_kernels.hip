@@ -1,0 +1,848 @@
+// ns3d_kernels.hip — hand-written HIP kernels (gfx950 / CDNA4, wave64) for the NavierStokes3D hot path.
+//
+// Compiled twice by navierstokes3d_amd/build.py:
+//   -DNS3D_MODE_STRICT -ffp-contract=off   → namespace ns3d_strict : the reference's operation order, IEEE
+//                                            divisions, no FMA  (bit-identical to oracle/ns3d_oracle.c)
+//   -DNS3D_MODE_FAST   -ffp-contract=fast  → namespace ns3d_fast   : reciprocal constants + FMA
+//
+// Reference kernel bodies restated here: scripts/NavierStokes3D_multi_gpu.jl:15-281 ("multi.jl"),
+// scripts/NavierStokes3D_gpu.jl:175-368 ("gpu.jl"); macro meanings per SURVEY.md Appendix A.
+// Layout: packed column-major, x fastest — a wave64 spans 64 consecutive x (512 B of fp64 per row).
+// All of these are HBM-bound 7-point-class stencils: no MFMA anywhere.
+#include "ns3d_launch.h"
+
+#if defined(NS3D_MODE_FAST)
+#define NS3D_NS ns3d_fast
+#define NS3D_FASTMATH 1
+#elif defined(NS3D_MODE_STRICT)
+#define NS3D_NS ns3d_strict
+#define NS3D_FASTMATH 0
+#else
+#error "compile with -DNS3D_MODE_STRICT or -DNS3D_MODE_FAST"
+#endif
+
+namespace NS3D_NS {
+
+typedef long long idx_t;
+#define IX3(i, j, k, sx, sy) ((idx_t)(i) + (idx_t)(sx) * ((idx_t)(j) + (idx_t)(sy) * (idx_t)(k)))
+
+// Grid spacings.  STRICT divides (x/dx, x/dx/dx) exactly like the Julia expressions; FAST multiplies by
+// reciprocals computed once on the host in double precision.
+template <class T>
+struct Geo {
+    T dx, dy, dz;
+    T rdx, rdy, rdz;    // 1/dx …
+    T rdx2, rdy2, rdz2; // 1/dx² …
+};
+template <class T>
+static Geo<T> make_geo(double dx, double dy, double dz)
+{
+    Geo<T> g;
+    g.dx = (T)dx; g.dy = (T)dy; g.dz = (T)dz;
+    g.rdx = (T)(1.0 / dx); g.rdy = (T)(1.0 / dy); g.rdz = (T)(1.0 / dz);
+    g.rdx2 = (T)(1.0 / (dx * dx)); g.rdy2 = (T)(1.0 / (dy * dy)); g.rdz2 = (T)(1.0 / (dz * dz));
+    return g;
+}
+#if NS3D_FASTMATH
+#define DIV_X(v) ((v)*g.rdx)
+#define DIV_Y(v) ((v)*g.rdy)
+#define DIV_Z(v) ((v)*g.rdz)
+#define DIV_XX(v) ((v)*g.rdx2)
+#define DIV_YY(v) ((v)*g.rdy2)
+#define DIV_ZZ(v) ((v)*g.rdz2)
+#define DIV_3(v) ((v) * (T)(1.0 / 3.0))
+#else
+#define DIV_X(v) ((v) / g.dx)
+#define DIV_Y(v) ((v) / g.dy)
+#define DIV_Z(v) ((v) / g.dz)
+#define DIV_XX(v) ((v) / g.dx / g.dx)
+#define DIV_YY(v) ((v) / g.dy / g.dy)
+#define DIV_ZZ(v) ((v) / g.dz / g.dz)
+#define DIV_3(v) ((v) / (T)3.0)
+#endif
+
+static inline dim3 grid3(int X, int Y, int Z, dim3 b)
+{
+    return dim3((unsigned)((X + (int)b.x - 1) / (int)b.x), (unsigned)((Y + (int)b.y - 1) / (int)b.y),
+                (unsigned)((Z + (int)b.z - 1) / (int)b.z));
+}
+#define BLK3 dim3(64, 4, 1)
+#define TID3                                                                                                \
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;                                                    \
+    const int j = blockIdx.y * blockDim.y + threadIdx.y;                                                    \
+    const int k = blockIdx.z * blockDim.z + threadIdx.z;
+
+// ---------------------------------------------------------------------------------------------------------
+// update_τ!   multi.jl:36-44 / gpu.jl:177-185.   One thread per cell (i<nx, j<ny, k<nz); the shear
+// statements are guarded by the (nx-1,ny-1,nz-1) extents of τxy,τxz,τyz.
+// ---------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_update_tau(T *__restrict__ txx, T *__restrict__ tyy, T *__restrict__ tzz,
+                                                    T *__restrict__ txy, T *__restrict__ txz, T *__restrict__ tyz,
+                                                    const T *__restrict__ Vx, const T *__restrict__ Vy,
+                                                    const T *__restrict__ Vz, T mu, Geo<T> g, int nx, int ny, int nz)
+{
+    TID3
+    if (i >= nx || j >= ny || k >= nz) return;
+    const T two_mu = (T)2 * mu;
+    const T dVx = Vx[IX3(i + 1, j, k, nx + 1, ny)] - Vx[IX3(i, j, k, nx + 1, ny)];
+    const T dVy = Vy[IX3(i, j + 1, k, nx, ny + 1)] - Vy[IX3(i, j, k, nx, ny + 1)];
+    const T dVz = Vz[IX3(i, j, k + 1, nx, ny)] - Vz[IX3(i, j, k, nx, ny)];
+    const T div = (DIV_X(dVx) + DIV_Y(dVy)) + DIV_Z(dVz); // @∇V()  multi.jl:15
+    const idx_t c = IX3(i, j, k, nx, ny);
+    txx[c] = two_mu * (DIV_X(dVx) - DIV_3(div));
+    tyy[c] = two_mu * (DIV_Y(dVy) - DIV_3(div));
+    tzz[c] = two_mu * (DIV_Z(dVz) - DIV_3(div));
+    if (i < nx - 1 && j < ny - 1 && k < nz - 1) {
+        const idx_t s = IX3(i, j, k, nx - 1, ny - 1);
+        const T vx111 = Vx[IX3(i + 1, j + 1, k + 1, nx + 1, ny)];
+        const T vy111 = Vy[IX3(i + 1, j + 1, k + 1, nx, ny + 1)];
+        const T vz111 = Vz[IX3(i + 1, j + 1, k + 1, nx, ny)];
+        txy[s] = mu * (DIV_Y(vx111 - Vx[IX3(i + 1, j, k + 1, nx + 1, ny)]) +
+                       DIV_X(vy111 - Vy[IX3(i, j + 1, k + 1, nx, ny + 1)]));
+        txz[s] = mu * (DIV_Z(vx111 - Vx[IX3(i + 1, j + 1, k, nx + 1, ny)]) +
+                       DIV_X(vz111 - Vz[IX3(i, j + 1, k + 1, nx, ny)]));
+        tyz[s] = mu * (DIV_Z(vy111 - Vy[IX3(i + 1, j + 1, k, nx, ny + 1)]) +
+                       DIV_Y(vz111 - Vz[IX3(i + 1, j, k + 1, nx, ny)]));
+    }
+}
+template <class T>
+hipError_t update_tau(hipStream_t s, T *txx, T *tyy, T *tzz, T *txy, T *txz, T *tyz, const T *Vx, const T *Vy,
+                      const T *Vz, double mu, double dx, double dy, double dz, int nx, int ny, int nz)
+{
+    hipLaunchKernelGGL(k_update_tau<T>, grid3(nx, ny, nz, BLK3), BLK3, 0, s, txx, tyy, tzz, txy, txz, tyz, Vx, Vy,
+                       Vz, (T)mu, make_geo<T>(dx, dy, dz), nx, ny, nz);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// predict_V!  multi.jl:50-55 / gpu.jl:187-192.  Thread (i,j,k) updates Vx/Vy/Vz[i+1,j+1,k+1] where inner.
+// ---------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_predict_V(T *__restrict__ Vx, T *__restrict__ Vy, T *__restrict__ Vz,
+                                                   const T *__restrict__ txx, const T *__restrict__ tyy,
+                                                   const T *__restrict__ tzz, const T *__restrict__ txy,
+                                                   const T *__restrict__ txz, const T *__restrict__ tyz, T dt_rho,
+                                                   T rho_g, Geo<T> g, int nx, int ny, int nz)
+{
+    TID3
+    if (i >= nx - 1 || j >= ny - 1 || k >= nz - 1) return;
+    const int sx = nx - 1, sy = ny - 1;
+    if (j < ny - 2 && k < nz - 2) {
+        const idx_t v = IX3(i + 1, j + 1, k + 1, nx + 1, ny);
+        const T a = DIV_X(txx[IX3(i + 1, j + 1, k + 1, nx, ny)] - txx[IX3(i, j + 1, k + 1, nx, ny)]);
+        const T b = DIV_Y(txy[IX3(i, j + 1, k, sx, sy)] - txy[IX3(i, j, k, sx, sy)]);
+        const T c = DIV_Z(txz[IX3(i, j, k + 1, sx, sy)] - txz[IX3(i, j, k, sx, sy)]);
+        Vx[v] = Vx[v] + dt_rho * ((a + b) + c);
+    }
+    if (i < nx - 2 && k < nz - 2) {
+        const idx_t v = IX3(i + 1, j + 1, k + 1, nx, ny + 1);
+        const T a = DIV_Y(tyy[IX3(i + 1, j + 1, k + 1, nx, ny)] - tyy[IX3(i + 1, j, k + 1, nx, ny)]);
+        const T b = DIV_X(txy[IX3(i + 1, j, k, sx, sy)] - txy[IX3(i, j, k, sx, sy)]);
+        const T c = DIV_Z(tyz[IX3(i, j, k + 1, sx, sy)] - tyz[IX3(i, j, k, sx, sy)]);
+        Vy[v] = Vy[v] + dt_rho * ((a + b) + c);
+    }
+    if (i < nx - 2 && j < ny - 2) {
+        const idx_t v = IX3(i + 1, j + 1, k + 1, nx, ny);
+        const T a = DIV_Z(tzz[IX3(i + 1, j + 1, k + 1, nx, ny)] - tzz[IX3(i + 1, j + 1, k, nx, ny)]);
+        const T b = DIV_X(txz[IX3(i + 1, j, k, sx, sy)] - txz[IX3(i, j, k, sx, sy)]);
+        const T c = DIV_Y(tyz[IX3(i, j + 1, k, sx, sy)] - tyz[IX3(i, j, k, sx, sy)]);
+        Vz[v] = Vz[v] + dt_rho * (((a + b) + c) - rho_g);
+    }
+}
+template <class T>
+hipError_t predict_V(hipStream_t s, T *Vx, T *Vy, T *Vz, const T *txx, const T *tyy, const T *tzz, const T *txy,
+                     const T *txz, const T *tyz, double rho, double gg, double dt, double dx, double dy, double dz,
+                     int nx, int ny, int nz)
+{
+    const T dt_rho = (T)dt / (T)rho, rho_g = (T)rho * (T)gg;
+    hipLaunchKernelGGL(k_predict_V<T>, grid3(nx - 1, ny - 1, nz - 1, BLK3), BLK3, 0, s, Vx, Vy, Vz, txx, tyy, tzz,
+                       txy, txz, tyz, dt_rho, rho_g, make_geo<T>(dx, dy, dz), nx, ny, nz);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// update_∇V!  multi.jl:61-64 / gpu.jl:194-197
+// ---------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_update_divV(T *__restrict__ divV, const T *__restrict__ Vx,
+                                                     const T *__restrict__ Vy, const T *__restrict__ Vz, Geo<T> g,
+                                                     int nx, int ny, int nz)
+{
+    TID3
+    if (i >= nx || j >= ny || k >= nz) return;
+    const T dVx = Vx[IX3(i + 1, j, k, nx + 1, ny)] - Vx[IX3(i, j, k, nx + 1, ny)];
+    const T dVy = Vy[IX3(i, j + 1, k, nx, ny + 1)] - Vy[IX3(i, j, k, nx, ny + 1)];
+    const T dVz = Vz[IX3(i, j, k + 1, nx, ny)] - Vz[IX3(i, j, k, nx, ny)];
+    divV[IX3(i, j, k, nx, ny)] = (DIV_X(dVx) + DIV_Y(dVy)) + DIV_Z(dVz);
+}
+template <class T>
+hipError_t update_divV(hipStream_t s, T *divV, const T *Vx, const T *Vy, const T *Vz, double dx, double dy,
+                       double dz, int nx, int ny, int nz)
+{
+    hipLaunchKernelGGL(k_update_divV<T>, grid3(nx, ny, nz, BLK3), BLK3, 0, s, divV, Vx, Vy, Vz,
+                       make_geo<T>(dx, dy, dz), nx, ny, nz);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The Poisson right-hand side shared by update_dPrdτ! and compute_res!  (multi.jl:71,89):
+//   @d2_xi(Pr)/dx/dx + @d2_yi(Pr)/dy/dy + @d2_zi(Pr)/dz/dz − ρ/dt*@inn(∇V)
+// ---------------------------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ T poisson_rhs(T c, T w, T e, T s, T n, T b, T t, T dv, T rho_dt, const Geo<T> &g)
+{
+    const T d2x = (e - c) - (c - w);
+    const T d2y = (n - c) - (c - s);
+    const T d2z = (t - c) - (c - b);
+    const T lap = (DIV_XX(d2x) + DIV_YY(d2y)) + DIV_ZZ(d2z);
+    return lap - rho_dt * dv;
+}
+
+// Drop-in, signature-preserving (unfused) PT kernels: one thread per interior cell.
+template <class T, int MODE> // MODE 0: update_dPrdτ!   1: compute_res!
+__global__ __launch_bounds__(256) void k_pt_unfused(const T *__restrict__ Pr, T *__restrict__ out,
+                                                    const T *__restrict__ divV, T rho_dt, T dtau, T one_m_damp,
+                                                    Geo<T> g, int nx, int ny, int nz)
+{
+    TID3
+    if (i >= nx - 2 || j >= ny - 2 || k >= nz - 2) return;
+    const idx_t p = IX3(i + 1, j + 1, k + 1, nx, ny);
+    const idx_t sy = nx, sz = (idx_t)nx * ny;
+    const T r = poisson_rhs<T>(Pr[p], Pr[p - 1], Pr[p + 1], Pr[p - sy], Pr[p + sy], Pr[p - sz], Pr[p + sz], divV[p],
+                               rho_dt, g);
+    const idx_t d = IX3(i, j, k, nx - 2, ny - 2);
+    if (MODE == 0) out[d] = out[d] * one_m_damp + dtau * r;
+    else out[d] = r;
+}
+template <class T>
+hipError_t update_dPrdtau(hipStream_t s, const T *Pr, T *dPrdtau, const T *divV, double rho, double dt, double dtau,
+                          double damp, double dx, double dy, double dz, int nx, int ny, int nz)
+{
+    hipLaunchKernelGGL((k_pt_unfused<T, 0>), grid3(nx - 2, ny - 2, nz - 2, BLK3), BLK3, 0, s, Pr, dPrdtau, divV,
+                       (T)rho / (T)dt, (T)dtau, (T)1.0 - (T)damp, make_geo<T>(dx, dy, dz), nx, ny, nz);
+    return hipGetLastError();
+}
+template <class T>
+hipError_t compute_res(hipStream_t s, T *Rp, const T *Pr, const T *divV, double rho, double dt, double dx, double dy,
+                       double dz, int nx, int ny, int nz)
+{
+    hipLaunchKernelGGL((k_pt_unfused<T, 1>), grid3(nx - 2, ny - 2, nz - 2, BLK3), BLK3, 0, s, Pr, Rp, divV,
+                       (T)rho / (T)dt, (T)0, (T)0, make_geo<T>(dx, dy, dz), nx, ny, nz);
+    return hipGetLastError();
+}
+
+// update_Pr!  multi.jl:79-82 / gpu.jl:204-207
+template <class T>
+__global__ __launch_bounds__(256) void k_update_Pr(T *__restrict__ Pr, const T *__restrict__ dPrdtau, T dtau, int nx,
+                                                   int ny, int nz)
+{
+    TID3
+    if (i >= nx - 2 || j >= ny - 2 || k >= nz - 2) return;
+    const idx_t p = IX3(i + 1, j + 1, k + 1, nx, ny);
+    Pr[p] = Pr[p] + dtau * dPrdtau[IX3(i, j, k, nx - 2, ny - 2)];
+}
+template <class T>
+hipError_t update_Pr(hipStream_t s, T *Pr, const T *dPrdtau, double dtau, int nx, int ny, int nz)
+{
+    hipLaunchKernelGGL(k_update_Pr<T>, grid3(nx - 2, ny - 2, nz - 2, BLK3), BLK3, 0, s, Pr, dPrdtau, (T)dtau, nx, ny,
+                       nz);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// NaN-propagating max|A| (= Julia maximum(abs.(A)), multi.jl:466): IEEE bit patterns of non-negative doubles
+// are monotone as unsigned integers and the canonical NaN 0x7FF8… sorts above +Inf, so the reduction is an
+// unsigned max: wave64 butterfly (__shfl_xor) → one LDS slot per wave → one atomicMax per block.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long abs_key(double a)
+{
+    return (a != a) ? 0x7FF8000000000000ull : (unsigned long long)__double_as_longlong(fabs(a));
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long u = __shfl_xor(v, o, 64);
+        v = u > v ? u : v;
+    }
+    return v;
+}
+__device__ __forceinline__ void block_max_to_global(unsigned long long key, unsigned long long *out)
+{
+    __shared__ unsigned long long wmax[16];
+    const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    const int nw = (blockDim.x * blockDim.y * blockDim.z + 63) >> 6;
+    key = wave_max_u64(key);
+    if ((tid & 63) == 0) wmax[tid >> 6] = key;
+    __syncthreads();
+    if (tid < 64) {
+        unsigned long long v = tid < nw ? wmax[tid] : 0ull;
+        v = wave_max_u64(v);
+        if (tid == 0 && v != 0ull) atomicMax(out, v);
+    }
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_max_abs(const T *__restrict__ A, long n, unsigned long long *out)
+{
+    unsigned long long key = 0ull;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long)gridDim.x * blockDim.x) {
+        unsigned long long u = abs_key((double)A[q]);
+        key = u > key ? u : key;
+    }
+    block_max_to_global(key, out);
+}
+template <class T>
+hipError_t max_abs_key(hipStream_t s, const T *A, long n, unsigned long long *key_dev)
+{
+    hipError_t e = hipMemsetAsync(key_dev, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    if (n <= 0) return hipSuccess;
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_max_abs<T>, dim3((unsigned)blocks), dim3(256), 0, s, A, n, key_dev);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// correct_V!  multi.jl:97-102 / gpu.jl:214-219
+// ---------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_correct_V(T *__restrict__ Vx, T *__restrict__ Vy, T *__restrict__ Vz,
+                                                   const T *__restrict__ Pr, T dt_rho, Geo<T> g, int nx, int ny,
+                                                   int nz)
+{
+    TID3
+    if (i >= nx - 1 || j >= ny - 1 || k >= nz - 1) return;
+    const T c = Pr[IX3(i + 1, j + 1, k + 1, nx, ny)];
+    if (j < ny - 2 && k < nz - 2) {
+        const idx_t v = IX3(i + 1, j + 1, k + 1, nx + 1, ny);
+        Vx[v] = Vx[v] - DIV_X(dt_rho * (c - Pr[IX3(i, j + 1, k + 1, nx, ny)]));
+    }
+    if (i < nx - 2 && k < nz - 2) {
+        const idx_t v = IX3(i + 1, j + 1, k + 1, nx, ny + 1);
+        Vy[v] = Vy[v] - DIV_Y(dt_rho * (c - Pr[IX3(i + 1, j, k + 1, nx, ny)]));
+    }
+    if (i < nx - 2 && j < ny - 2) {
+        const idx_t v = IX3(i + 1, j + 1, k + 1, nx, ny);
+        Vz[v] = Vz[v] - DIV_Z(dt_rho * (c - Pr[IX3(i + 1, j + 1, k, nx, ny)]));
+    }
+}
+template <class T>
+hipError_t correct_V(hipStream_t s, T *Vx, T *Vy, T *Vz, const T *Pr, double dt, double rho, double dx, double dy,
+                     double dz, int nx, int ny, int nz)
+{
+    hipLaunchKernelGGL(k_correct_V<T>, grid3(nx - 1, ny - 1, nz - 1, BLK3), BLK3, 0, s, Vx, Vy, Vz, Pr,
+                       (T)dt / (T)rho, make_geo<T>(dx, dy, dz), nx, ny, nz);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Boundary-plane kernels on an array of extents (sx,sy,sz): bc_x!/bc_y!/bc_z! (multi.jl:108-132),
+// bc_zV! (gpu.jl:239-243), bc_xhydstatic! (gpu.jl:257-261), bc_x_Vx! (multi.jl:138-141),
+// bc_x_Pr! (multi.jl:147-150).  One thread per point of the 2-D index range the reference launches.
+// ---------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_bc_plane(int which, T *__restrict__ A, int sx, int sy, int sz, T a, T b, T c,
+                                                  int nz_arg)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = blockIdx.y * blockDim.y + threadIdx.y;
+    switch (which) {
+    case 0: // bc_x!  (iy,iz)
+        if (u < sy && v < sz) {
+            A[IX3(0, u, v, sx, sy)] = A[IX3(1, u, v, sx, sy)];
+            A[IX3(sx - 1, u, v, sx, sy)] = A[IX3(sx - 2, u, v, sx, sy)];
+        }
+        break;
+    case 1: // bc_y!  (ix,iz)
+        if (u < sx && v < sz) {
+            A[IX3(u, 0, v, sx, sy)] = A[IX3(u, 1, v, sx, sy)];
+            A[IX3(u, sy - 1, v, sx, sy)] = A[IX3(u, sy - 2, v, sx, sy)];
+        }
+        break;
+    case 2: // bc_z!  (ix,iy)
+        if (u < sx && v < sy) {
+            A[IX3(u, v, 0, sx, sy)] = A[IX3(u, v, 1, sx, sy)];
+            A[IX3(u, v, sz - 1, sx, sy)] = A[IX3(u, v, sz - 2, sx, sy)];
+        }
+        break;
+    case 3: // bc_zV!
+        if (u < sx && v < sy) {
+            A[IX3(u, v, 0, sx, sy)] = (T)0.0;
+            A[IX3(u, v, sz - 1, sx, sy)] = A[IX3(u, v, sz - 2, sx, sy)];
+        }
+        break;
+    case 4: // bc_xhydstatic!(A,dz,nz,g,ρ): a = ρ*g, b = dz ; iz = v+1
+        if (u < sy && v < sz) {
+            const T h = (a * ((T)(nz_arg - (v + 1)) + (T)0.5)) * b;
+            A[IX3(0, u, v, sx, sy)] = h + (T)100;
+            A[IX3(sx - 1, u, v, sx, sy)] = h;
+        }
+        break;
+    case 5: // bc_x_Vx!(A,V): a = V
+        if (u < sy && v < sz) A[IX3(0, u, v, sx, sy)] = a;
+        break;
+    case 6: // bc_x_Pr!(A,val): a = val
+        if (u < sy && v < sz) A[IX3(sx - 1, u, v, sx, sy)] = a;
+        break;
+    }
+    (void)c;
+}
+template <class T>
+hipError_t bc_plane(hipStream_t s, int which, T *A, int sx, int sy, int sz, double a, double b, double c, int nz_arg)
+{
+    int U, V;
+    switch (which) {
+    case 0: case 4: case 5: case 6: U = sy; V = sz; break;
+    case 1: U = sx; V = sz; break;
+    default: U = sx; V = sy; break;
+    }
+    const dim3 blk(64, 4, 1);
+    hipLaunchKernelGGL(k_bc_plane<T>, grid3(U, V, 1, blk), blk, 0, s, which, A, sx, sy, sz, (T)a, (T)b, (T)c, nz_arg);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// set_cylinder!  multi.jl:249-281 (global-coordinate form) / gpu.jl:336-368 (local form, yc = yv + dx/2 sic)
+// Thread range (nx+1,ny+1,nz+1) = element-wise max of the argument sizes.
+// ---------------------------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ bool in_ellipse(T xq, T yq, T ox, T oy, T sinb, T cosb, T a2, T b2, T thr)
+{
+    const T xr = (xq - ox) * cosb - (yq - oy) * sinb;
+    const T yr = (xq - ox) * sinb + (yq - oy) * cosb;
+    return (xr * xr / a2 + yr * yr / b2) < thr;
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_set_cylinder(T *__restrict__ C, T *__restrict__ Vx, T *__restrict__ Vy,
+                                                      T *__restrict__ Vz, T a2, T b2, T ox, T oy, T sinb, T cosb,
+                                                      int local_form, T xco, T yco, T lx, T ly, T dx, T dy, int nx,
+                                                      int ny, int nz)
+{
+    TID3
+    if (i > nx || j > ny || k > nz) return;
+    T xc, yc, xv, yv;
+    if (!local_form) {
+        xc = xco + (T)i * dx; yc = yco + (T)j * dy;
+        xv = xc - dx / (T)2;  yv = yc - dy / (T)2;
+    } else {
+        xv = (T)i * dx - lx / (T)2; yv = (T)j * dy - ly / (T)2;
+        xc = xv + dx / (T)2;        yc = yv + dx / (T)2;
+    }
+    if (i < nx && j < ny && k < nz && in_ellipse<T>(xc, yc, ox, oy, sinb, cosb, a2, b2, (T)1.05))
+        C[IX3(i, j, k, nx, ny)] = (T)1.0;
+    if (j < ny && k < nz && in_ellipse<T>(xv, yc, ox, oy, sinb, cosb, a2, b2, (T)1.0))
+        Vx[IX3(i, j, k, nx + 1, ny)] = (T)0.0;
+    if (i < nx && k < nz && in_ellipse<T>(xc, yv, ox, oy, sinb, cosb, a2, b2, (T)1.0))
+        Vy[IX3(i, j, k, nx, ny + 1)] = (T)0.0;
+    if (i < nx && j < ny && in_ellipse<T>(xc, yc, ox, oy, sinb, cosb, a2, b2, (T)1.0))
+        Vz[IX3(i, j, k, nx, ny)] = (T)0.0;
+}
+template <class T>
+hipError_t set_cylinder(hipStream_t s, T *C, T *Vx, T *Vy, T *Vz, double a2, double b2, double ox, double oy,
+                        double sinb, double cosb, int local_form, double xco, double yco, double lx, double ly,
+                        double dx, double dy, int nx, int ny, int nz)
+{
+    hipLaunchKernelGGL(k_set_cylinder<T>, grid3(nx + 1, ny + 1, nz + 1, BLK3), BLK3, 0, s, C, Vx, Vy, Vz, (T)a2, (T)b2,
+                       (T)ox, (T)oy, (T)sinb, (T)cosb, local_form, (T)xco, (T)yco, (T)lx, (T)ly, (T)dx, (T)dy, nx, ny,
+                       nz);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// advect! / backtrack! / lerp   multi.jl:190-243 / gpu.jl:288-334.  One thread per (ix,iy,iz) of the
+// (nx+1,ny+1,nz+1) range like the reference; data-dependent 8-point gathers served by L2 / Infinity Cache.
+// ix,iy,iz below are the reference's 1-based indices.
+// ---------------------------------------------------------------------------------------------------------
+template <class T> __device__ __forceinline__ T lerp_(T a, T b, T t) { return b * t + a * ((T)1 - t); }
+__device__ __forceinline__ int clampi(long long v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : (int)v); }
+__device__ __forceinline__ double fmod1(double a) { return fmod(a, 1.0); }
+__device__ __forceinline__ float fmod1(float a) { return fmodf(a, 1.0f); }
+__device__ __forceinline__ double floor_(double a) { return floor(a); }
+__device__ __forceinline__ float floor_(float a) { return floorf(a); }
+
+template <class T>
+__device__ __forceinline__ void backtrack(T *__restrict__ A, const T *__restrict__ A_o, T vxc, T vyc, T vzc, T dt,
+                                          const Geo<T> &g, int ix, int iy, int iz, int sx, int sy, int sz)
+{
+#if NS3D_FASTMATH
+    const T ddx = dt * vxc * g.rdx, ddy = dt * vyc * g.rdy, ddz = dt * vzc * g.rdz;
+#else
+    const T ddx = dt * vxc / g.dx, ddy = dt * vyc / g.dy, ddz = dt * vzc / g.dz;
+#endif
+    const int ix1 = clampi((long long)floor_((T)ix - ddx), 1, sx);
+    const int iy1 = clampi((long long)floor_((T)iy - ddy), 1, sy);
+    const int iz1 = clampi((long long)floor_((T)iz - ddz), 1, sz);
+    const int ix2 = clampi(ix1 + 1, 1, sx), iy2 = clampi(iy1 + 1, 1, sy), iz2 = clampi(iz1 + 1, 1, sz);
+    const T wx = (ddx > (T)0 ? (T)1 : (T)0) - fmod1(ddx);
+    const T wy = (ddy > (T)0 ? (T)1 : (T)0) - fmod1(ddy);
+    const T wz = (ddz > (T)0 ? (T)1 : (T)0) - fmod1(ddz);
+#define AO(i_, j_, k_) A_o[IX3((i_)-1, (j_)-1, (k_)-1, sx, sy)]
+    const T fy1z1 = lerp_<T>(AO(ix1, iy1, iz1), AO(ix2, iy1, iz1), wx);
+    const T fy1z2 = lerp_<T>(AO(ix1, iy1, iz2), AO(ix2, iy1, iz2), wx);
+    const T fy2z1 = lerp_<T>(AO(ix1, iy2, iz1), AO(ix2, iy2, iz1), wx);
+    const T fy2z2 = lerp_<T>(AO(ix1, iy2, iz2), AO(ix2, iy2, iz2), wx);
+#undef AO
+    const T fz1 = lerp_<T>(fy1z1, fy2z1, wy);
+    const T fz2 = lerp_<T>(fy1z2, fy2z2, wy);
+    A[IX3(ix - 1, iy - 1, iz - 1, sx, sy)] = lerp_<T>(fz1, fz2, wz);
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_advect(T *__restrict__ Vx, const T *__restrict__ Vx_o, T *__restrict__ Vy,
+                                                const T *__restrict__ Vy_o, T *__restrict__ Vz,
+                                                const T *__restrict__ Vz_o, T *__restrict__ C,
+                                                const T *__restrict__ C_o, T dt, Geo<T> g, int nx, int ny, int nz,
+                                                int faithful)
+{
+    const int ix = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int iy = blockIdx.y * blockDim.y + threadIdx.y + 1;
+    const int iz = blockIdx.z * blockDim.z + threadIdx.z + 1;
+    if (ix > nx + 1 || iy > ny + 1 || iz > nz + 1) return;
+#define VXO(i_, j_, k_) Vx_o[IX3((i_)-1, (j_)-1, (k_)-1, nx + 1, ny)]
+#define VYO(i_, j_, k_) Vy_o[IX3((i_)-1, (j_)-1, (k_)-1, nx, ny + 1)]
+#define VZO(i_, j_, k_) Vz_o[IX3((i_)-1, (j_)-1, (k_)-1, nx, ny)]
+    T vxc, vyc, vzc;
+    if (ix > 1 && ix < nx + 1 && iy <= ny && iz <= nz) { // multi.jl:218-223
+        vxc = VXO(ix, iy, iz);
+        vyc = (T)0.25 * (((VYO(ix - 1, iy, iz) + VYO(ix - 1, iy + 1, iz)) + VYO(ix, iy, iz)) + VYO(ix, iy + 1, iz));
+        vzc = (T)0.25 * (((VZO(ix - 1, iy, iz) + VZO(ix - 1, iy, iz + 1)) + VZO(ix, iy, iz)) + VZO(ix, iy, iz + 1));
+        backtrack<T>(Vx, Vx_o, vxc, vyc, vzc, dt, g, ix, iy, iz, nx + 1, ny, nz);
+    }
+    if (iy > 1 && iy < ny + 1 && ix <= nx && iz <= nz) { // multi.jl:224-229
+        vxc = (T)0.25 * (((VXO(ix, iy - 1, iz) + VXO(ix + 1, iy - 1, iz)) + VXO(ix, iy, iz)) + VXO(ix + 1, iy, iz));
+        vyc = VYO(ix, iy, iz);
+        vzc = (T)0.25 * (((VZO(ix, iy - 1, iz) + VZO(ix, iy - 1, iz + 1)) + VZO(ix, iy, iz)) + VZO(ix, iy, iz + 1));
+        backtrack<T>(Vy, Vy_o, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny + 1, nz);
+    }
+    if (iz > 1 && iz < nz + 1 && ix <= nx && iy <= ny) { // multi.jl:230-235
+        vxc = (T)0.25 * (((VXO(ix, iy, iz - 1) + VXO(ix + 1, iy, iz - 1)) + VXO(ix, iy, iz)) + VXO(ix + 1, iy, iz));
+        vyc = (T)0.25 * (((VYO(ix, iy, iz - 1) + VYO(ix, iy + 1, iz - 1)) + VYO(ix, iy, iz)) + VYO(ix, iy + 1, iz));
+        vzc = VZO(ix, iy, iz);
+        // multi.jl:234 / gpu.jl:325 call backtrack!(Vy,Vy_o,…) here (sic): the SAME lane issued the branch-2
+        // store to Vy[ix,iy,iz] above, so the two stores are ordered and this one wins, as in the reference.
+        if (faithful) backtrack<T>(Vy, Vy_o, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny + 1, nz);
+        else backtrack<T>(Vz, Vz_o, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny, nz + 1);
+    }
+    if (ix <= nx && iy <= ny && iz <= nz) { // multi.jl:236-241
+        vxc = (T)0.5 * (VXO(ix, iy, iz) + VXO(ix + 1, iy, iz));
+        vyc = (T)0.5 * (VYO(ix, iy, iz) + VYO(ix, iy + 1, iz));
+        vzc = (T)0.5 * (VZO(ix, iy, iz) + VZO(ix, iy, iz + 1));
+        backtrack<T>(C, C_o, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny, nz);
+    }
+#undef VXO
+#undef VYO
+#undef VZO
+}
+template <class T>
+hipError_t advect(hipStream_t s, T *Vx, const T *Vx_o, T *Vy, const T *Vy_o, T *Vz, const T *Vz_o, T *C,
+                  const T *C_o, double dt, double dx, double dy, double dz, int nx, int ny, int nz, int faithful)
+{
+    hipLaunchKernelGGL(k_advect<T>, grid3(nx + 1, ny + 1, nz + 1, BLK3), BLK3, 0, s, Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, C,
+                       C_o, (T)dt, make_geo<T>(dx, dy, dz), nx, ny, nz, faithful);
+    return hipGetLastError();
+}
+
+// =========================================================================================================
+// The fused pseudo-transient sweep  —  THE hot kernel (≥98 % of all bytes moved).
+//
+// One launch = one PT iteration  { update_dPrdτ! ; update_Pr! ; set_bc_Pr! }  (multi.jl:459-463):
+//     d⁺[c]  = d[c]·(1−damp) + dτ·(∇²P[c] − ρ/dt·∇V[c])                 interior cells c
+//     P⁺[c]  = P[c] + dτ·d⁺[c]
+//     P⁺[face/edge/corner] = boundary rule applied to P⁺ in the reference's order
+// reading P (7-point), ∇V, d and writing d⁺, P⁺ into a SECOND pressure buffer (ping-pong; Jacobi sweeps read
+// only the previous iterate).  Algorithmic traffic: 5 × 8 B = 40 B per cell per iteration (fp64).
+//
+// Boundary folding.  multi.jl applies bc_x!, bc_y!, bc_z! in that order on the whole planes, so afterwards
+// every face/edge/corner cell equals the nearest interior cell (index clamped to [2,n−1] in each direction),
+// then bc_x_Pr! overwrites the whole outlet plane.  gpu.jl applies bc_y!, bc_z!, then sets BOTH x planes to
+// the hydrostatic profile for every (iy,iz).  Hence the thread that produces interior cell (i,j,k) also stores
+// the boundary cells that clamp onto it; x planes get the copy / outlet value / hydrostatic value.
+// z planes that are inter-slab halos are left to the halo exchange.
+//
+// Thread mapping (variant Z: z-marching register pipeline).  x is the unit-stride dimension: one wave64 owns 64
+// consecutive x of RY consecutive rows and marches KZ planes in z holding P[k−1],P[k],P[k+1] of its RY rows in
+// registers, so every P value is loaded once per block (plus y/x halos that hit in L2).  x±1 neighbours move
+// between lanes (DPP wave shifts), the two edge lanes take one extra predicated load; y±1 neighbours are
+// register rows, the first/last row take one halo-row load.  All loads for plane k+1 are issued before plane k
+// is computed (software pipelining; the compiler's s_waitcnt lands at first use, one iteration later).
+// =========================================================================================================
+template <class T>
+struct SweepArgs {
+    const T *__restrict__ Pin;
+    T *__restrict__ Pout;
+    T *__restrict__ D;
+    const T *__restrict__ RHS; // ∇V
+    Geo<T> g;
+    T rho_dt, dtau, one_m_damp;
+    T outlet_val, rho_g;
+    int nx, ny, nz;
+    int bc_kind, owns_outlet, zlo_halo, zhi_halo;
+    int k0, k1; // interior planes [k0,k1) handled by this launch
+    int kz;     // planes per block
+};
+
+// value stored on the x planes for target plane kk (0-based)
+template <class T>
+__device__ __forceinline__ T xface_val(const SweepArgs<T> &a, bool hi, T copy, int kk)
+{
+    if (a.bc_kind == NS3D_BC_GPU) { // gpu.jl:258-259, iz = kk+1
+        const T h = (a.rho_g * ((T)(a.nz - (kk + 1)) + (T)0.5)) * a.g.dz;
+        return hi ? h : h + (T)100;
+    }
+    return (hi && a.owns_outlet) ? a.outlet_val : copy; // multi.jl:109-110,148
+}
+
+// store P⁺(i,j,k)=v and every boundary cell that maps onto it
+template <class T>
+__device__ __forceinline__ void store_with_bc(const SweepArgs<T> &a, int i, int j, int k, T v)
+{
+    const int nx = a.nx, ny = a.ny, nz = a.nz;
+    const bool xlo = (i == 1), xhi = (i == nx - 2);
+    const bool ylo = (j == 1), yhi = (j == ny - 2);
+    const bool zlo = (k == 1) && !a.zlo_halo, zhi = (k == nz - 2) && !a.zhi_halo;
+    T *__restrict__ P = a.Pout;
+    P[IX3(i, j, k, nx, ny)] = v;
+    if (!(xlo | xhi | ylo | yhi | zlo | zhi)) return;
+#pragma unroll
+    for (int zz = 0; zz < 3; ++zz) {
+        if ((zz == 1 && !zlo) || (zz == 2 && !zhi)) continue;
+        const int kk = zz == 0 ? k : (zz == 1 ? 0 : nz - 1);
+#pragma unroll
+        for (int yy = 0; yy < 3; ++yy) {
+            if ((yy == 1 && !ylo) || (yy == 2 && !yhi)) continue;
+            const int jj = yy == 0 ? j : (yy == 1 ? 0 : ny - 1);
+            if (zz | yy) P[IX3(i, jj, kk, nx, ny)] = v;
+            if (xlo) P[IX3(0, jj, kk, nx, ny)] = xface_val<T>(a, false, v, kk);
+            if (xhi) P[IX3(nx - 1, jj, kk, nx, ny)] = xface_val<T>(a, true, v, kk);
+        }
+    }
+}
+
+// ---- variant N: one thread per interior cell, neighbours straight from global/L2 (simple baseline) ------
+template <class T>
+__global__ __launch_bounds__(256) void k_pt_sweep_naive(SweepArgs<T> a)
+{
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = a.k0 + blockIdx.z * blockDim.z + threadIdx.z;
+    if (i > a.nx - 2 || j > a.ny - 2 || k >= a.k1) return;
+    const Geo<T> &g = a.g;
+    const idx_t p = IX3(i, j, k, a.nx, a.ny);
+    const idx_t sy = a.nx, sz = (idx_t)a.nx * a.ny;
+    const T *__restrict__ P = a.Pin;
+    const T c = P[p];
+    const T r = poisson_rhs<T>(c, P[p - 1], P[p + 1], P[p - sy], P[p + sy], P[p - sz], P[p + sz], a.RHS[p], a.rho_dt, g);
+    const idx_t d = IX3(i - 1, j - 1, k - 1, a.nx - 2, a.ny - 2);
+    const T dn = a.D[d] * a.one_m_damp + a.dtau * r;
+    a.D[d] = dn;
+    store_with_bc<T>(a, i, j, k, c + a.dtau * dn);
+}
+
+// ---- lane shifts: value of lane−1 / lane+1 within the wave64 ---------------------------------------------
+template <class T> __device__ __forceinline__ T lane_prev(T v) { return __shfl_up(v, 1, 64); }
+template <class T> __device__ __forceinline__ T lane_next(T v) { return __shfl_down(v, 1, 64); }
+
+// ---- variant Z: z-marching register pipeline -------------------------------------------------------------
+template <class T, int RY, int BY>
+__global__ __launch_bounds__(64 * BY) void k_pt_sweep_zmarch(SweepArgs<T> a)
+{
+    const int nx = a.nx, ny = a.ny;
+    const Geo<T> &g = a.g;
+    const int lane = threadIdx.x;
+    const int i = 1 + blockIdx.x * 64 + lane;                     // P index of this lane's column
+    const int j0 = 1 + (blockIdx.y * BY + threadIdx.y) * RY;      // first row of this thread
+    const int kb = a.k0 + blockIdx.z * a.kz;
+    const int ke = min(kb + a.kz, a.k1);
+    if (j0 > ny - 2 || kb >= ke) return;                          // wave-uniform
+    const bool lane_act = (i <= nx - 2);
+    const int ic = min(i, nx - 1);                                // clamped load column (face column is a valid neighbour)
+    const bool edge = (lane == 0) | (lane == 63);
+    const int ih = lane == 0 ? i - 1 : min(i + 1, nx - 1);        // x-halo column fetched by the two edge lanes
+    const idx_t sy = nx, sz = (idx_t)nx * ny;
+    const idx_t dsy = nx - 2, dsz = (idx_t)(nx - 2) * (ny - 2);
+    const T *__restrict__ P = a.Pin;
+    const T *__restrict__ RHS = a.RHS;
+    T *__restrict__ D = a.D;
+
+    int jr[RY];       // clamped row index for P/∇V loads
+    bool ract[RY];    // row is an interior row
+    idx_t drow[RY];   // row offset into dPrdτ (clamped)
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        const int j = j0 + r;
+        ract[r] = (j <= ny - 2);
+        jr[r] = min(j, ny - 1);
+        drow[r] = (idx_t)(min(j, ny - 2) - 1) * dsy + (min(i, nx - 2) - 1);
+    }
+    const int jlo = j0 - 1, jhi = min(j0 + RY, ny - 1);
+
+    T pm[RY], pc[RY], pp[RY]; // planes k-1, k, k+1
+    T hx[RY];                 // x-halo of plane k (edge lanes only)
+    T dv[RY], rv[RY];         // dPrdτ and ∇V of plane k
+    T ylo, yhi;               // y-halo rows of plane k
+    // prologue: planes kb-1 and kb, and everything plane kb needs
+    {
+        const idx_t zc = (idx_t)kb * sz, zm = zc - sz;
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            pm[r] = P[zm + (idx_t)jr[r] * sy + ic];
+            pc[r] = P[zc + (idx_t)jr[r] * sy + ic];
+            hx[r] = edge ? P[zc + (idx_t)jr[r] * sy + ih] : (T)0;
+            dv[r] = D[(idx_t)(kb - 1) * dsz + drow[r]];
+            rv[r] = RHS[zc + (idx_t)min(jr[r], ny - 2) * sy + min(i, nx - 2)];
+        }
+        ylo = P[zc + (idx_t)jlo * sy + ic];
+        yhi = P[zc + (idx_t)jhi * sy + ic];
+    }
+    for (int k = kb; k < ke; ++k) {
+        // ---- issue the loads of plane k+1 (consumed in the next iteration) ----
+        const idx_t zn = (idx_t)(k + 1) * sz;
+        const bool more = (k + 1 < ke);
+        T hxn[RY], dvn[RY], rvn[RY], ylon = (T)0, yhin = (T)0;
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            pp[r] = P[zn + (idx_t)jr[r] * sy + ic];
+            hxn[r] = (T)0; dvn[r] = (T)0; rvn[r] = (T)0;
+            if (more) {
+                hxn[r] = edge ? P[zn + (idx_t)jr[r] * sy + ih] : (T)0;
+                dvn[r] = D[(idx_t)k * dsz + drow[r]];
+                rvn[r] = RHS[zn + (idx_t)min(jr[r], ny - 2) * sy + min(i, nx - 2)];
+            }
+        }
+        if (more) {
+            ylon = P[zn + (idx_t)jlo * sy + ic];
+            yhin = P[zn + (idx_t)jhi * sy + ic];
+        }
+        // ---- compute plane k ----
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            const T c = pc[r];
+            T w = lane_prev<T>(c), e = lane_next<T>(c);
+            w = lane == 0 ? hx[r] : w;
+            e = lane == 63 ? hx[r] : e;
+            const T s = r == 0 ? ylo : pc[r - 1 < 0 ? 0 : r - 1];
+            const T n = r == RY - 1 ? yhi : pc[r + 1 > RY - 1 ? RY - 1 : r + 1];
+            const T res = poisson_rhs<T>(c, w, e, s, n, pm[r], pp[r], rv[r], a.rho_dt, g);
+            const T dn = dv[r] * a.one_m_damp + a.dtau * res;
+            if (lane_act && ract[r]) {
+                D[(idx_t)(k - 1) * dsz + drow[r]] = dn;
+                store_with_bc<T>(a, i, j0 + r, k, c + a.dtau * dn);
+            }
+        }
+        // ---- rotate the pipeline ----
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            pm[r] = pc[r]; pc[r] = pp[r];
+            hx[r] = hxn[r]; dv[r] = dvn[r]; rv[r] = rvn[r];
+        }
+        ylo = ylon; yhi = yhin;
+    }
+}
+
+template <class T, int RY, int BY>
+static hipError_t launch_zmarch(hipStream_t s, SweepArgs<T> &a, int kz)
+{
+    a.kz = kz;
+    const int nxi = a.nx - 2, nyi = a.ny - 2, nk = a.k1 - a.k0;
+    dim3 blk(64, BY, 1);
+    dim3 grd((unsigned)((nxi + 63) / 64), (unsigned)((nyi + RY * BY - 1) / (RY * BY)), (unsigned)((nk + kz - 1) / kz));
+    hipLaunchKernelGGL((k_pt_sweep_zmarch<T, RY, BY>), grd, blk, 0, s, a);
+    return hipGetLastError();
+}
+
+template <class T>
+hipError_t pt_sweep(hipStream_t s, int variant, const T *Pin, T *Pout, T *D, const T *RHS, const ns3d_pt_params &p,
+                    int k0, int k1)
+{
+    SweepArgs<T> a;
+    a.Pin = Pin; a.Pout = Pout; a.D = D; a.RHS = RHS;
+    a.g = make_geo<T>(p.dx, p.dy, p.dz);
+    a.rho_dt = (T)p.rho / (T)p.dt; a.dtau = (T)p.dtau; a.one_m_damp = (T)1.0 - (T)p.damp;
+    a.outlet_val = (T)p.outlet_val; a.rho_g = (T)p.rho * (T)p.g;
+    a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
+    a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = p.z_lo_is_halo; a.zhi_halo = p.z_hi_is_halo;
+    a.k0 = k0; a.k1 = k1; a.kz = 1;
+    if (k1 <= k0) return hipSuccess;
+    // variant = family*100 + kz  (kz = planes marched per block; 0 → default)
+    const int fam = variant / 100;
+    int kz = variant % 100;
+    if (kz <= 0) kz = 32;
+    switch (fam) {
+    case 1: {
+        dim3 blk(64, 4, 1);
+        hipLaunchKernelGGL(k_pt_sweep_naive<T>, grid3(a.nx - 2, a.ny - 2, k1 - k0, blk), blk, 0, s, a);
+        return hipGetLastError();
+    }
+    case 2: return launch_zmarch<T, 2, 4>(s, a, kz);
+    case 3: return launch_zmarch<T, 4, 2>(s, a, kz);
+    case 4: return launch_zmarch<T, 8, 2>(s, a, kz);
+    case 5: return launch_zmarch<T, 1, 4>(s, a, kz);
+    case 6: return launch_zmarch<T, 2, 8>(s, a, kz);
+    default: return launch_zmarch<T, 4, 4>(s, a, kz);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// compute_res! fused with maximum(abs.(Rp))  (multi.jl:465-466): no Rp round trip, 16 B/cell.
+// ---------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_residual_max(const T *__restrict__ P, const T *__restrict__ RHS, T rho_dt,
+                                                      Geo<T> g, int nx, int ny, int nz, unsigned long long *out)
+{
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = 1 + blockIdx.z * blockDim.z + threadIdx.z;
+    unsigned long long key = 0ull;
+    if (i <= nx - 2 && j <= ny - 2 && k <= nz - 2) {
+        const idx_t p = IX3(i, j, k, nx, ny);
+        const idx_t sy = nx, sz = (idx_t)nx * ny;
+        const T r = poisson_rhs<T>(P[p], P[p - 1], P[p + 1], P[p - sy], P[p + sy], P[p - sz], P[p + sz], RHS[p], rho_dt, g);
+        key = abs_key((double)r);
+    }
+    block_max_to_global(key, out);
+}
+template <class T>
+hipError_t residual_max_key(hipStream_t s, const T *Pr, const T *divV, const ns3d_pt_params &p,
+                            unsigned long long *key_dev)
+{
+    hipError_t e = hipMemsetAsync(key_dev, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_residual_max<T>, grid3(p.nx - 2, p.ny - 2, p.nz - 2, BLK3), BLK3, 0, s, Pr, divV,
+                       (T)p.rho / (T)p.dt, make_geo<T>(p.dx, p.dy, p.dz), p.nx, p.ny, p.nz, key_dev);
+    return hipGetLastError();
+}
+
+// ---- explicit instantiations -----------------------------------------------------------------------------
+#define INST(T)                                                                                              \
+    template hipError_t update_tau<T>(hipStream_t, T *, T *, T *, T *, T *, T *, const T *, const T *,       \
+                                      const T *, double, double, double, double, int, int, int);             \
+    template hipError_t predict_V<T>(hipStream_t, T *, T *, T *, const T *, const T *, const T *, const T *, \
+                                     const T *, const T *, double, double, double, double, double, double,   \
+                                     int, int, int);                                                         \
+    template hipError_t set_cylinder<T>(hipStream_t, T *, T *, T *, T *, double, double, double, double,     \
+                                        double, double, int, double, double, double, double, double, double, \
+                                        int, int, int);                                                      \
+    template hipError_t update_divV<T>(hipStream_t, T *, const T *, const T *, const T *, double, double,    \
+                                       double, int, int, int);                                               \
+    template hipError_t update_dPrdtau<T>(hipStream_t, const T *, T *, const T *, double, double, double,    \
+                                          double, double, double, double, int, int, int);                    \
+    template hipError_t update_Pr<T>(hipStream_t, T *, const T *, double, int, int, int);                    \
+    template hipError_t compute_res<T>(hipStream_t, T *, const T *, const T *, double, double, double,       \
+                                       double, double, int, int, int);                                       \
+    template hipError_t max_abs_key<T>(hipStream_t, const T *, long, unsigned long long *);                  \
+    template hipError_t correct_V<T>(hipStream_t, T *, T *, T *, const T *, double, double, double, double,  \
+                                     double, int, int, int);                                                 \
+    template hipError_t bc_plane<T>(hipStream_t, int, T *, int, int, int, double, double, double, int);      \
+    template hipError_t advect<T>(hipStream_t, T *, const T *, T *, const T *, T *, const T *, T *,          \
+                                  const T *, double, double, double, double, int, int, int, int);            \
+    template hipError_t pt_sweep<T>(hipStream_t, int, const T *, T *, T *, const T *, const ns3d_pt_params &,\
+                                    int, int);                                                               \
+    template hipError_t residual_max_key<T>(hipStream_t, const T *, const T *, const ns3d_pt_params &,       \
+                                            unsigned long long *);
+INST(double)
+INST(float)
+#undef INST
+
+} // namespace NS3D_NS

@@ -1,0 +1,50 @@
+// ns3d_launch.h — host-side launcher declarations shared by ns3d_kernels.hip (compiled twice: once per
+// arithmetic mode) and ns3d_api.cpp.  Internal header; the public boundary is include/ns3d.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/ns3d.h"
+
+#define NS3D_LAUNCHER_DECLS(NS)                                                                              \
+    namespace NS {                                                                                           \
+    template <class T>                                                                                       \
+    hipError_t update_tau(hipStream_t, T *, T *, T *, T *, T *, T *, const T *, const T *, const T *, double,\
+                          double, double, double, int, int, int);                                            \
+    template <class T>                                                                                       \
+    hipError_t predict_V(hipStream_t, T *, T *, T *, const T *, const T *, const T *, const T *, const T *,  \
+                         const T *, double, double, double, double, double, double, int, int, int);          \
+    template <class T>                                                                                       \
+    hipError_t set_cylinder(hipStream_t, T *, T *, T *, T *, double, double, double, double, double, double, \
+                            int local_form, double, double, double, double, double, double, int, int, int);  \
+    template <class T>                                                                                       \
+    hipError_t update_divV(hipStream_t, T *, const T *, const T *, const T *, double, double, double, int,   \
+                           int, int);                                                                        \
+    template <class T>                                                                                       \
+    hipError_t update_dPrdtau(hipStream_t, const T *, T *, const T *, double, double, double, double, double,\
+                              double, double, int, int, int);                                                \
+    template <class T>                                                                                       \
+    hipError_t update_Pr(hipStream_t, T *, const T *, double, int, int, int);                                \
+    template <class T>                                                                                       \
+    hipError_t compute_res(hipStream_t, T *, const T *, const T *, double, double, double, double, double,   \
+                           int, int, int);                                                                   \
+    template <class T>                                                                                       \
+    hipError_t max_abs_key(hipStream_t, const T *, long, unsigned long long *key_dev);                       \
+    template <class T>                                                                                       \
+    hipError_t correct_V(hipStream_t, T *, T *, T *, const T *, double, double, double, double, double, int, \
+                         int, int);                                                                          \
+    /* which: 0 bc_x 1 bc_y 2 bc_z 3 bc_zV 4 bc_xhydstatic 5 bc_x_Vx 6 bc_x_Pr */                            \
+    template <class T>                                                                                       \
+    hipError_t bc_plane(hipStream_t, int which, T *, int, int, int, double a, double b, double c, int nz_arg);\
+    template <class T>                                                                                       \
+    hipError_t advect(hipStream_t, T *, const T *, T *, const T *, T *, const T *, T *, const T *, double,   \
+                      double, double, double, int, int, int, int);                                           \
+    template <class T>                                                                                       \
+    hipError_t pt_sweep(hipStream_t, int variant, const T *, T *, T *, const T *, const ns3d_pt_params &,    \
+                        int k0, int k1);                                                                     \
+    template <class T>                                                                                       \
+    hipError_t residual_max_key(hipStream_t, const T *, const T *, const ns3d_pt_params &,                   \
+                                unsigned long long *key_dev);                                                \
+    }
+
+NS3D_LAUNCHER_DECLS(ns3d_strict)
+NS3D_LAUNCHER_DECLS(ns3d_fast)

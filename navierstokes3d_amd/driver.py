@@ -1,0 +1,266 @@
+"""Host-side mirror of the reference's two drivers, running on libns3d.so (HIP, gfx950).
+
+    run_navierstokes3D(; do_vis, do_save, do_print, nx, nt)  ↔ scripts/NavierStokes3D_multi_gpu.jl:287-536
+    runme(; do_vis, do_save)                                  ↔ scripts/NavierStokes3D_gpu.jl:12-173
+
+Same keyword names, same return contract (C_v,Pr_v,Vx_v,Vy_v,Vz_v: halo-stripped global host arrays on rank 0,
+multi.jl:528-535).  Extra keyword-only options select the arithmetic mode, the fused PT path and the z-slab
+process grid.  Plotting (do_vis) is out of scope and raises if requested.
+
+The time loops below follow the reference line by line (cited); with `fused=True` the inner pseudo-transient
+loop {update_dPrdτ!; update_Pr!; set_bc_Pr!}×n is replaced by ns3d_pt_solve / overlapped ns3d_pt_sweep calls
+that produce the same iterates (the redundant halo updates multi.jl:460,462 are dropped).
+"""
+import math
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import kernels as K
+from . import lib as L
+from .halo import ZSlabGrid
+from .params import gpu_params, multi_params
+
+
+def _alloc(nx, ny, nz, dtype, device):
+    """multi.jl:343-360 / gpu.jl:65-82"""
+    z = lambda *s: K.zeros(s, dtype, device)
+    f = SimpleNamespace()
+    f.Pr = z(nx, ny, nz); f.dPrdtau = z(nx - 2, ny - 2, nz - 2)
+    f.C = z(nx, ny, nz); f.C_o = z(nx, ny, nz)
+    f.txx = z(nx, ny, nz); f.tyy = z(nx, ny, nz); f.tzz = z(nx, ny, nz)
+    f.txy = z(nx - 1, ny - 1, nz - 1); f.txz = z(nx - 1, ny - 1, nz - 1); f.tyz = z(nx - 1, ny - 1, nz - 1)
+    f.Vx = z(nx + 1, ny, nz); f.Vy = z(nx, ny + 1, nz); f.Vz = z(nx, ny, nz + 1)
+    f.Vx_o = z(nx + 1, ny, nz); f.Vy_o = z(nx, ny + 1, nz); f.Vz_o = z(nx, ny, nz + 1)
+    f.divV = z(nx, ny, nz); f.Rp = z(nx - 2, ny - 2, nz - 2)
+    return f
+
+
+def save_array(Aname, A):
+    """save_array(Aname, A) (multi.jl:27-30): raw little-endian column-major dump to Aname.bin."""
+    with open(Aname + ".bin", "wb") as fh:
+        fh.write(np.asfortranarray(A).tobytes(order="F"))
+
+
+def _inner(t):
+    """Array(A)[2:end-1,2:end-1,2:end-1] (multi.jl:399)"""
+    return K.to_numpy(t)[1:-1, 1:-1, 1:-1]
+
+
+def _gather_all(grid, f):
+    """multi.jl:399-403 / :528-532"""
+    return tuple(grid.gather(_inner(getattr(f, n))) for n in ("C", "Pr", "Vx", "Vy", "Vz"))
+
+
+def _save_frame(grid, fields_v, iframe):
+    """multi.jl:404-413 / :515-522 — rank 0 writes Float32 raw dumps of the gathered arrays."""
+    if grid.me != 0:
+        return
+    os.makedirs("./out_save", exist_ok=True)
+    for name, A in zip(("C", "Pr", "Vx", "Vy", "Vz"), fields_v):
+        save_array("out_save/out_%s_v_%04d" % (name, iframe), A.astype(np.float32))
+
+
+def pt_loop_reference(ctx, grid, f, p, niter, do_print=False):
+    """The inner loop exactly as written in multi.jl:458-471 (including its redundant halo updates)."""
+    errs, done = [], niter
+    for it in range(1, niter + 1):
+        K.update_dPrdtau(f.Pr, f.dPrdtau, f.divV, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, ctx=ctx)   # :459
+        grid.update_halo(f.divV)                                                                          # :460
+        K.update_Pr(f.Pr, f.dPrdtau, p.dtau, ctx=ctx)                                                     # :461
+        grid.update_halo(f.Pr)                                                                            # :462
+        K.set_bc_Pr_multi(f.Pr, p.owns_outlet, 0.0, ctx=ctx)                                              # :463 → :176-181
+        grid.update_halo(f.Pr)                                                                            # :182
+        if it % p.nchk == 0:                                                                              # :464
+            K.compute_res(f.Rp, f.Pr, f.divV, p.rho, p.dt, p.dx, p.dy, p.dz, ctx=ctx)                     # :465
+            err = grid.max_g(K.max_abs(f.Rp, ctx=ctx)) * p.ly * p.ly / p.psc                              # :466
+            errs.append(err)
+            if grid.me == 0 and do_print:
+                print("  #iter = %d, err = %1.3e" % (it, err))                                            # :468
+            if err < p.eps or not math.isfinite(err):                                                     # :469
+                done = it
+                break
+    return done, errs
+
+
+def pt_loop_fused_slab(ctx, grid, f, p, pt, niter, do_print=False, scratch=None):
+    """Same iterates as pt_loop_reference on a z-slab rank: per iteration the two seam-adjacent interior planes
+    are swept first, their exchange over xGMI is posted, and the interior sweep runs behind it."""
+    nz = p.nz
+    Pa = f.Pr
+    Pb = scratch if scratch is not None else K.clone(f.Pr)
+    if scratch is not None:
+        K.copy(Pb, Pa, ctx=ctx)   # seeds faces/halo planes
+    errs, done = [], niter
+    for it in range(1, niter + 1):
+        K.pt_sweep(Pa, Pb, f.dPrdtau, f.divV, pt, 1, 2, ctx=ctx)
+        if nz - 2 > 1:
+            K.pt_sweep(Pa, Pb, f.dPrdtau, f.divV, pt, nz - 2, nz - 1, ctx=ctx)
+        work = grid.start_halo(Pb)
+        if nz - 2 > 2:
+            K.pt_sweep(Pa, Pb, f.dPrdtau, f.divV, pt, 2, nz - 2, ctx=ctx)
+        grid.finish_halo(work)
+        Pa, Pb = Pb, Pa
+        if it % p.nchk == 0:
+            err = grid.max_g(K.residual_max(Pa, f.divV, pt, ctx=ctx)) * p.ly * p.ly / p.psc
+            errs.append(err)
+            if grid.me == 0 and do_print:
+                print("  #iter = %d, err = %1.3e" % (it, err))
+            if err < p.eps or not math.isfinite(err):
+                done = it
+                break
+    if Pa is not f.Pr:
+        K.copy(f.Pr, Pa, ctx=ctx)
+    return done, errs
+
+
+def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=10, *, mode="strict", fused=True,
+                       dtype=torch.float64, faithful=True, grid=None, device=None, niter_cap=None,
+                       return_info=False):
+    """run_navierstokes3D (multi.jl:287-536).  nx is the LOCAL streamwise size (ny = nz = ceil(0.6 nx) local);
+    with an initialised torch.distributed process group the domain is decomposed into one z-slab per rank."""
+    if do_vis:
+        raise NotImplementedError("plotting (multi.jl:416-443, 486-513) is out of scope of this build")
+    if device is None:
+        device = torch.cuda.current_device()
+    dev = torch.device("cuda", device)
+    ctx = K.Context(device, mode, async_=True)
+    P, me = 1, 0
+    if grid is None:
+        p0 = multi_params(nx)
+        grid = ZSlabGrid(p0.nx, p0.ny, p0.nz)                                                  # :325
+    P, me = grid.P, grid.me
+    p = multi_params(nx, P, me)
+    nx, ny, nz = p.nx, p.ny, p.nz
+    niter = p.niter if niter_cap is None else min(p.niter, niter_cap)
+    f = _alloc(nx, ny, nz, dtype, dev)                                                        # :343-360
+    # initialization :369-373
+    f.Vy[0, :, :] = p.vin                                                                     # :369 (sic)
+    # :370 Pr = -(z_g-dz/2)*ρ*g (+0+0): identically 0 because g = 1/Fr² = 0 (:316); evaluated for fidelity
+    zg = np.array([(me * (nz - 2) + iz) * p.dz for iz in range(nz)])
+    f.Pr[:, :, :] = torch.from_numpy(-(zg - p.dz / 2) * p.rho * p.g + 0.0).to(dev, dtype)[None, None, :]
+    grid.update_halo(f.Pr)                                                                    # :371
+    cyl = (p.a2, p.b2, p.ox, p.oy, p.sinb, p.cosb, p.xco_g, p.yco_g, p.zco_g, p.lx, p.ly, p.lz, p.dx, p.dy, p.dz)
+    K.set_cylinder(f.C, f.Vx, f.Vy, f.Vz, *cyl, ctx=ctx)                                      # :372
+    grid.update_halo(f.C, f.Vx, f.Vy, f.Vz)                                                   # :373
+    iframe = 0
+    if do_save:                                                                               # :404-413
+        ctx.sync()
+        _save_frame(grid, _gather_all(grid, f), iframe)
+    iframe += 1
+    pt = K.pt_params(f.Pr, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, L.NS3D_BC_MULTI, p.owns_outlet, 0.0,
+                     p.g, grid.z_lo_is_halo(), grid.z_hi_is_halo())
+    scratch = K.clone(f.Pr) if (fused and P > 1) else None
+    info = SimpleNamespace(iters=[], errs=[], params=p)
+    nsave = 10                                                                                # :332
+    for it in range(1, nt + 1):                                                               # :446
+        K.update_tau(f.txx, f.tyy, f.tzz, f.txy, f.txz, f.tyz, f.Vx, f.Vy, f.Vz, p.mu, p.dx, p.dy, p.dz, ctx=ctx)  # :449
+        grid.update_halo(f.txx, f.tyy, f.tzz)                                                 # :450
+        K.predict_V(f.Vx, f.Vy, f.Vz, f.txx, f.tyy, f.tzz, f.txy, f.txz, f.tyz, p.rho, p.g, p.dt, p.dx, p.dy, p.dz,
+                    ctx=ctx)                                                                  # :451
+        K.set_cylinder(f.C, f.Vx, f.Vy, f.Vz, *cyl, ctx=ctx)                                  # :452
+        grid.update_halo(f.C, f.Vx, f.Vy, f.Vz)                                               # :453
+        K.update_divV(f.divV, f.Vx, f.Vy, f.Vz, p.dx, p.dy, p.dz, ctx=ctx)                    # :454
+        grid.update_halo(f.divV)                                                              # :455
+        if me == 0 and do_print:
+            print("#it = %d" % it)                                                            # :456
+        if not fused:                                                                         # :458-471
+            done, errs = pt_loop_reference(ctx, grid, f, p, niter, do_print)
+        elif P == 1:
+            done, errs = K.pt_solve(f.Pr, f.dPrdtau, f.divV, pt, p.eps, niter, p.nchk, p.err_scale, ctx=ctx)
+            if me == 0 and do_print:
+                for q, e in enumerate(errs):
+                    print("  #iter = %d, err = %1.3e" % ((q + 1) * p.nchk, e))
+        else:
+            done, errs = pt_loop_fused_slab(ctx, grid, f, p, pt, niter, do_print, scratch)
+        info.iters.append(done); info.errs.append(errs)
+        K.correct_V(f.Vx, f.Vy, f.Vz, f.Pr, p.dt, p.rho, p.dx, p.dy, p.dz, ctx=ctx)            # :472
+        K.set_cylinder(f.C, f.Vx, f.Vy, f.Vz, *cyl, ctx=ctx)                                  # :473
+        K.set_bc_Vel_multi(f.Vx, f.Vy, f.Vz, p.owns_inlet, p.vin, ctx=ctx)                     # :474 → :157-166
+        grid.update_halo(f.Vx, f.Vy, f.Vz)                                                    # :167
+        K.copy(f.Vx_o, f.Vx, ctx=ctx); K.copy(f.Vy_o, f.Vy, ctx=ctx)                          # :475
+        K.copy(f.Vz_o, f.Vz, ctx=ctx); K.copy(f.C_o, f.C, ctx=ctx)
+        K.advect(f.Vx, f.Vx_o, f.Vy, f.Vy_o, f.Vz, f.Vz_o, f.C, f.C_o, p.dt, p.dx, p.dy, p.dz, faithful, ctx=ctx)  # :476
+        grid.update_halo(f.Vx, f.Vy, f.Vz)                                                    # :477 (not C)
+        if do_save and it % nsave == 0:                                                       # :479-525
+            ctx.sync()
+            _save_frame(grid, _gather_all(grid, f), iframe)
+            iframe += 1
+    ctx.sync()
+    out = _gather_all(grid, f)                                                                # :528-532
+    info.fields = f
+    info.ctx = ctx
+    return out + ((info,) if return_info else ())                                             # :535
+
+
+def gpu_initial_fields(p):
+    """gpu.jl:62-63,85-88: LinRange cell centres, 1/7-power-law Vx profile, hydrostatic Pr (host setup)."""
+    nx, ny, nz = p.nx, p.ny, p.nz
+    t = np.arange(nz, dtype=np.float64) / (nz - 1)                    # Julia LinRange: (1-t)*a + t*b
+    zc = (1 - t) * (-(p.lz - p.dz) / 2) + t * ((p.lz - p.dz) / 2)
+    prof = p.vin * (7.0 / 6.0) * ((zc + p.lz / 2) / p.lz) ** (1.0 / 6.0)
+    Vx = np.empty((nx + 1, ny, nz), order="F"); Vx[:, :, :] = prof[None, None, :]
+    Pr = np.empty((nx, ny, nz), order="F"); Pr[:, :, :] = (-(zc - p.lz / 2) * p.rho * p.g)[None, None, :]
+    return Vx, Pr
+
+
+def runme(do_vis=False, do_save=False, *, nx=255, nt=10000, mode="strict", fused=True, dtype=torch.float64,
+          faithful=True, device=None, niter_cap=None, do_print=False, initial=None):
+    """runme (gpu.jl:12-173): single device, gravity, hydrostatic x-planes.  Returns (fields, info).
+    nx/nt are literals in the reference (gpu.jl:44,51: 255, 10000) and keyword options here."""
+    if do_vis:
+        raise NotImplementedError("plotting (gpu.jl:90-117, 143-167) is out of scope of this build")
+    if do_save:
+        raise NotImplementedError("MAT-file output (gpu.jl:89,168-170) is out of scope of this build")
+    if device is None:
+        device = torch.cuda.current_device()
+    dev = torch.device("cuda", device)
+    ctx = K.Context(device, mode, async_=True)
+    p = gpu_params(nx)
+    nx, ny, nz = p.nx, p.ny, p.nz
+    niter = p.niter if niter_cap is None else min(p.niter, niter_cap)
+    f = _alloc(nx, ny, nz, dtype, dev)
+    Vx0, Pr0 = initial if initial is not None else gpu_initial_fields(p)
+    f.Vx = K.from_numpy(np.asarray(Vx0).astype(np.float64 if dtype == torch.float64 else np.float32), dev)
+    f.Pr = K.from_numpy(np.asarray(Pr0).astype(np.float64 if dtype == torch.float64 else np.float32), dev)
+    cyl = (p.a2, p.b2, p.ox, p.oy, p.sinb, p.cosb, p.lx, p.ly, p.lz, p.dx, p.dy, p.dz)
+    pt = K.pt_params(f.Pr, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, L.NS3D_BC_GPU, False, 0.0, p.g)
+    info = SimpleNamespace(iters=[], errs=[], params=p)
+    for it in range(1, nt + 1):                                                               # :119
+        K.update_tau(f.txx, f.tyy, f.tzz, f.txy, f.txz, f.tyz, f.Vx, f.Vy, f.Vz, p.mu, p.dx, p.dy, p.dz, ctx=ctx)  # :121
+        K.predict_V(f.Vx, f.Vy, f.Vz, f.txx, f.tyy, f.tzz, f.txy, f.txz, f.tyz, p.rho, p.g, p.dt, p.dx, p.dy, p.dz,
+                    ctx=ctx)                                                                  # :122
+        K.set_cylinder(f.C, f.Vx, f.Vy, f.Vz, *cyl, ctx=ctx)                                  # :123
+        K.update_divV(f.divV, f.Vx, f.Vy, f.Vz, p.dx, p.dy, p.dz, ctx=ctx)                    # :124
+        if do_print:
+            print("#it = %d" % it)                                                            # :125
+        if fused:
+            done, errs = K.pt_solve(f.Pr, f.dPrdtau, f.divV, pt, p.eps, niter, p.nchk, p.err_scale, ctx=ctx)
+        else:
+            errs, done = [], niter
+            for itr in range(1, niter + 1):                                                   # :126
+                K.update_dPrdtau(f.Pr, f.dPrdtau, f.divV, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, ctx=ctx)  # :127
+                K.update_Pr(f.Pr, f.dPrdtau, p.dtau, ctx=ctx)                                 # :128
+                K.set_bc_Pr_gpu(f.Pr, p.dz, nz, p.g, p.rho, ctx=ctx)                          # :129
+                if itr % p.nchk == 0:                                                         # :130
+                    K.compute_res(f.Rp, f.Pr, f.divV, p.rho, p.dt, p.dx, p.dy, p.dz, ctx=ctx)  # :131
+                    err = K.max_abs(f.Rp, ctx=ctx) * p.ly * p.ly / p.psc                      # :132
+                    errs.append(err)
+                    if err < p.eps or not math.isfinite(err):                                 # :135
+                        done = itr
+                        break
+        if do_print:
+            for q, e in enumerate(errs):
+                print("  #iter = %d, err = %1.3e" % ((q + 1) * p.nchk, e))                    # :134
+        info.iters.append(done); info.errs.append(errs)
+        K.correct_V(f.Vx, f.Vy, f.Vz, f.Pr, p.dt, p.rho, p.dx, p.dy, p.dz, ctx=ctx)            # :138
+        K.set_cylinder(f.C, f.Vx, f.Vy, f.Vz, *cyl, ctx=ctx)                                  # :139
+        K.set_bc_Vel_gpu(f.Vx, f.Vy, f.Vz, ctx=ctx)                                           # :140
+        K.copy(f.Vx_o, f.Vx, ctx=ctx); K.copy(f.Vy_o, f.Vy, ctx=ctx)                          # :141
+        K.copy(f.Vz_o, f.Vz, ctx=ctx); K.copy(f.C_o, f.C, ctx=ctx)
+        K.advect(f.Vx, f.Vx_o, f.Vy, f.Vy_o, f.Vz, f.Vz_o, f.C, f.C_o, p.dt, p.dx, p.dy, p.dz, faithful, ctx=ctx)  # :142
+    ctx.sync()
+    info.ctx = ctx
+    return f, info

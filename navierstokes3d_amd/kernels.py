@@ -1,0 +1,343 @@
+"""Host-side mirror of the reference's kernel layer (scripts/NavierStokes3D_multi_gpu.jl:15-281,
+scripts/NavierStokes3D_gpu.jl:175-368): the same kernel names and positional argument lists, each one a
+thin call into libns3d.so (hand-written HIP, include/ns3d.h).  `!` is dropped, τ→tau, ∇V→divV.
+
+Arrays are torch CUDA tensors used purely as device-memory handles, shaped like the reference
+(nx,ny,nz) and laid out column-major (x fastest) like Julia arrays: create them with `zeros`/`from_numpy`.
+The launch grid (nx,ny,nz) is derived from the array shapes like ParallelStencil's `@parallel` does.
+
+PyTorch does no arithmetic here and there is no CPU fallback: without the HIP library / a GPU every call
+raises (lib.Ns3dError).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+_DT = {torch.float64: "f64", torch.float32: "f32"}
+
+
+# ---- column-major device arrays -------------------------------------------------------------------------
+def zeros(shape, dtype=torch.float64, device="cuda"):
+    """@zeros(nx,ny,nz) (multi.jl:343): a (nx,ny,nz) tensor with strides (1,nx,nx*ny)."""
+    sx, sy, sz = shape
+    return torch.zeros((sz, sy, sx), dtype=dtype, device=device).permute(2, 1, 0)
+
+
+def from_numpy(a, device="cuda"):
+    """Upload a numpy array (any order) as a column-major device array of the same shape."""
+    a = np.asfortranarray(a)
+    t = torch.from_numpy(np.ascontiguousarray(a.transpose(2, 1, 0))).to(device)
+    return t.permute(2, 1, 0)
+
+
+def to_numpy(t):
+    """Download to a Fortran-ordered numpy array of the same shape."""
+    return np.asfortranarray(t.permute(2, 1, 0).contiguous().cpu().numpy().transpose(2, 1, 0))
+
+
+def clone(t):
+    return t.permute(2, 1, 0).contiguous().clone().permute(2, 1, 0)
+
+
+def _chk(t, shape=None, name="array"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise L.Ns3dError("%s must be a CUDA/HIP tensor (navierstokes3d_amd has no CPU path)" % name)
+    if t.dtype not in _DT:
+        raise L.Ns3dError("%s: unsupported dtype %s" % (name, t.dtype))
+    sx, sy, sz = t.shape
+    if t.stride() != (1, sx, sx * sy):
+        raise L.Ns3dError("%s must be column-major (x fastest): use kernels.zeros / from_numpy" % name)
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise L.Ns3dError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """ns3d_ctx wrapper = what `@init_parallel_stencil(CUDA, Float64, 3)` sets up in the reference
+    (gpu.jl:4-8): device + arithmetic mode.  mode: 'strict' (bit-identical to the reference operation
+    order) or 'fast' (reciprocals + FMA)."""
+
+    def __init__(self, device=None, mode="strict", async_=False):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise L.Ns3dError("no GPU visible: libns3d has no CPU path")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = int(device)
+        flags = {"strict": L.NS3D_STRICT, "fast": L.NS3D_FAST}[mode] | (L.NS3D_ASYNC if async_ else 0)
+        self.mode = mode
+        self.handle = self.lib.ns3d_create(self.device, flags)
+        if not self.handle:
+            raise L.Ns3dError("ns3d_create failed: " + L.last_error())
+        self.use_torch_stream()
+
+    def use_torch_stream(self, stream=None):
+        """Launch on PyTorch's current stream so that tensor ops (uploads, copies) are ordered with kernels."""
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self._stream = s.cuda_stream
+        L.check(self.lib.ns3d_set_stream(self.handle, C.c_void_p(s.cuda_stream)))
+
+    def sync(self):
+        L.check(self.lib.ns3d_sync(self.handle))
+
+    def set_pt_variant(self, v):
+        L.check(self.lib.ns3d_set_pt_variant(self.handle, int(v)))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.ns3d_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def call(self, name, ref, *args):
+        if torch.cuda.current_stream(self.device).cuda_stream != self._stream:
+            self.use_torch_stream()     # follow `with torch.cuda.stream(...)` blocks
+        fn = getattr(self.lib, "ns3d_%s_%s" % (name, _DT[ref.dtype]))
+        L.check(fn(self.handle, *args))
+
+
+_DEFAULT = {}
+
+
+def init_parallel_stencil(device=None, mode="strict", async_=False):
+    """Create (or replace) the default context for `device`; mirrors @init_parallel_stencil (gpu.jl:4-8)."""
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    old = _DEFAULT.pop(int(device), None)
+    if old is not None:
+        old.close()
+    ctx = Context(device, mode, async_)
+    _DEFAULT[int(device)] = ctx
+    return ctx
+
+
+def default_context(t=None):
+    dev = t.device.index if t is not None else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    ctx = _DEFAULT.get(dev)
+    if ctx is None:
+        ctx = init_parallel_stencil(dev)
+    return ctx
+
+
+def _ctx(ctx, t):
+    return ctx if ctx is not None else default_context(t)
+
+
+def _d(*xs):
+    return [C.c_double(float(x)) for x in xs]
+
+
+# ---- the reference's kernels ----------------------------------------------------------------------------
+def update_tau(txx, tyy, tzz, txy, txz, tyz, Vx, Vy, Vz, mu, dx, dy, dz, ctx=None):
+    """update_τ!  multi.jl:36-44 / gpu.jl:177-185"""
+    nx, ny, nz = txx.shape
+    c = (nx, ny, nz); s = (nx - 1, ny - 1, nz - 1)
+    _ctx(ctx, txx).call("update_tau", txx, _chk(txx, c, "txx"), _chk(tyy, c, "tyy"), _chk(tzz, c, "tzz"),
+                        _chk(txy, s, "txy"), _chk(txz, s, "txz"), _chk(tyz, s, "tyz"),
+                        _chk(Vx, (nx + 1, ny, nz), "Vx"), _chk(Vy, (nx, ny + 1, nz), "Vy"),
+                        _chk(Vz, (nx, ny, nz + 1), "Vz"), *_d(mu, dx, dy, dz), nx, ny, nz)
+
+
+def predict_V(Vx, Vy, Vz, txx, tyy, tzz, txy, txz, tyz, rho, g, dt, dx, dy, dz, ctx=None):
+    """predict_V!  multi.jl:50-55 / gpu.jl:187-192"""
+    nx, ny, nz = txx.shape
+    c = (nx, ny, nz); s = (nx - 1, ny - 1, nz - 1)
+    _ctx(ctx, txx).call("predict_V", txx, _chk(Vx, (nx + 1, ny, nz), "Vx"), _chk(Vy, (nx, ny + 1, nz), "Vy"),
+                        _chk(Vz, (nx, ny, nz + 1), "Vz"), _chk(txx, c, "txx"), _chk(tyy, c, "tyy"),
+                        _chk(tzz, c, "tzz"), _chk(txy, s, "txy"), _chk(txz, s, "txz"), _chk(tyz, s, "tyz"),
+                        *_d(rho, g, dt, dx, dy, dz), nx, ny, nz)
+
+
+def set_cylinder(Cf, Vx, Vy, Vz, a2, b2, ox, oy, sinb, cosb, *rest, ctx=None):
+    """set_cylinder!  multi.jl:249-281 (19 arguments: …,xco_g,yco_g,zco_g,lx,ly,lz,dx,dy,dz) or
+    gpu.jl:336-368 (16 arguments: …,lx,ly,lz,dx,dy,dz) — dispatched on the argument count like the two
+    scripts' definitions."""
+    nx, ny, nz = Cf.shape
+    ptrs = (_chk(Cf, (nx, ny, nz), "C"), _chk(Vx, (nx + 1, ny, nz), "Vx"), _chk(Vy, (nx, ny + 1, nz), "Vy"),
+            _chk(Vz, (nx, ny, nz + 1), "Vz"))
+    if len(rest) == 9:
+        _ctx(ctx, Cf).call("set_cylinder", Cf, *ptrs, *_d(a2, b2, ox, oy, sinb, cosb, *rest), nx, ny, nz)
+    elif len(rest) == 6:
+        _ctx(ctx, Cf).call("set_cylinder_local", Cf, *ptrs, *_d(a2, b2, ox, oy, sinb, cosb, *rest), nx, ny, nz)
+    else:
+        raise TypeError("set_cylinder: expected 19 (multi.jl) or 16 (gpu.jl) positional arguments")
+
+
+def update_divV(divV, Vx, Vy, Vz, dx, dy, dz, ctx=None):
+    """update_∇V!  multi.jl:61-64 / gpu.jl:194-197"""
+    nx, ny, nz = divV.shape
+    _ctx(ctx, divV).call("update_divV", divV, _chk(divV, None, "divV"), _chk(Vx, (nx + 1, ny, nz), "Vx"),
+                         _chk(Vy, (nx, ny + 1, nz), "Vy"), _chk(Vz, (nx, ny, nz + 1), "Vz"), *_d(dx, dy, dz),
+                         nx, ny, nz)
+
+
+def update_dPrdtau(Pr, dPrdtau, divV, rho, dt, dtau, damp, dx, dy, dz, ctx=None):
+    """update_dPrdτ!  multi.jl:70-73 / gpu.jl:199-202"""
+    nx, ny, nz = Pr.shape
+    _ctx(ctx, Pr).call("update_dPrdtau", Pr, _chk(Pr, None, "Pr"), _chk(dPrdtau, (nx - 2, ny - 2, nz - 2), "dPrdtau"),
+                       _chk(divV, (nx, ny, nz), "divV"), *_d(rho, dt, dtau, damp, dx, dy, dz), nx, ny, nz)
+
+
+def update_Pr(Pr, dPrdtau, dtau, ctx=None):
+    """update_Pr!  multi.jl:79-82 / gpu.jl:204-207"""
+    nx, ny, nz = Pr.shape
+    _ctx(ctx, Pr).call("update_Pr", Pr, _chk(Pr, None, "Pr"), _chk(dPrdtau, (nx - 2, ny - 2, nz - 2), "dPrdtau"),
+                       *_d(dtau), nx, ny, nz)
+
+
+def compute_res(Rp, Pr, divV, rho, dt, dx, dy, dz, ctx=None):
+    """compute_res!  multi.jl:88-91 / gpu.jl:209-212"""
+    nx, ny, nz = Pr.shape
+    _ctx(ctx, Pr).call("compute_res", Pr, _chk(Rp, (nx - 2, ny - 2, nz - 2), "Rp"), _chk(Pr, None, "Pr"),
+                       _chk(divV, (nx, ny, nz), "divV"), *_d(rho, dt, dx, dy, dz), nx, ny, nz)
+
+
+def max_abs(A, ctx=None):
+    """maximum(abs.(A)) — NaN-propagating  (multi.jl:466 / gpu.jl:132)"""
+    out = C.c_double(0.0)
+    _ctx(ctx, A).call("max_abs", A, _chk(A, None, "A"), C.c_long(A.numel()), C.byref(out))
+    return out.value
+
+
+def correct_V(Vx, Vy, Vz, Pr, dt, rho, dx, dy, dz, ctx=None):
+    """correct_V!  multi.jl:97-102 / gpu.jl:214-219"""
+    nx, ny, nz = Pr.shape
+    _ctx(ctx, Pr).call("correct_V", Pr, _chk(Vx, (nx + 1, ny, nz), "Vx"), _chk(Vy, (nx, ny + 1, nz), "Vy"),
+                       _chk(Vz, (nx, ny, nz + 1), "Vz"), _chk(Pr, None, "Pr"), *_d(dt, rho, dx, dy, dz), nx, ny, nz)
+
+
+def _bc(name, A, *extra, ctx=None):
+    _ctx(ctx, A).call(name, A, _chk(A, None, "A"), *extra, *A.shape)
+
+
+def bc_x(A, ctx=None):
+    """bc_x!  multi.jl:108-112"""
+    _bc("bc_x", A, ctx=ctx)
+
+
+def bc_y(A, ctx=None):
+    """bc_y!  multi.jl:118-122"""
+    _bc("bc_y", A, ctx=ctx)
+
+
+def bc_z(A, ctx=None):
+    """bc_z!  multi.jl:128-132"""
+    _bc("bc_z", A, ctx=ctx)
+
+
+def bc_zV(A, ctx=None):
+    """bc_zV!  gpu.jl:239-243"""
+    _bc("bc_zV", A, ctx=ctx)
+
+
+def bc_xhydstatic(A, dz, nz, g, rho, ctx=None):
+    """bc_xhydstatic!  gpu.jl:257-261"""
+    _bc("bc_xhydstatic", A, C.c_double(dz), C.c_int(nz), C.c_double(g), C.c_double(rho), ctx=ctx)
+
+
+def bc_x_Vx(A, V, ctx=None):
+    """bc_x_Vx!  multi.jl:138-141"""
+    _bc("bc_x_Vx", A, C.c_double(V), ctx=ctx)
+
+
+def bc_x_Pr(A, val, ctx=None):
+    """bc_x_Pr!  multi.jl:147-150"""
+    _bc("bc_x_Pr", A, C.c_double(val), ctx=ctx)
+
+
+def copy(dst, src, ctx=None):
+    """X_o .= X  (multi.jl:475 / gpu.jl:141)"""
+    _ctx(ctx, dst).call("copy", dst, _chk(dst, src.shape, "dst"), _chk(src, None, "src"), C.c_long(src.numel()))
+
+
+def advect(Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, Cf, C_o, dt, dx, dy, dz, faithful=True, ctx=None):
+    """advect!  multi.jl:217-243 / gpu.jl:308-334.  faithful=True reproduces the reference's third branch
+    (back-tracks Vy, never Vz — SURVEY.md App. B1)."""
+    nx, ny, nz = Cf.shape
+    _ctx(ctx, Cf).call("advect", Cf, _chk(Vx, (nx + 1, ny, nz), "Vx"), _chk(Vx_o, (nx + 1, ny, nz), "Vx_o"),
+                       _chk(Vy, (nx, ny + 1, nz), "Vy"), _chk(Vy_o, (nx, ny + 1, nz), "Vy_o"),
+                       _chk(Vz, (nx, ny, nz + 1), "Vz"), _chk(Vz_o, (nx, ny, nz + 1), "Vz_o"),
+                       _chk(Cf, None, "C"), _chk(C_o, (nx, ny, nz), "C_o"), *_d(dt, dx, dy, dz), nx, ny, nz,
+                       1 if faithful else 0)
+
+
+# ---- the reference's host sequences, one library call each ----------------------------------------------
+def set_bc_Pr_multi(Pr, owns_outlet, val=0.0, ctx=None):
+    """set_bc_Pr!(Pr, xve_g, lx, val) of multi.jl:175-181 with `xve_g == lx/2` passed as a flag; the trailing
+    update_halo!(Pr) (multi.jl:182) is the caller's."""
+    nx, ny, nz = Pr.shape
+    _ctx(ctx, Pr).call("set_bc_Pr", Pr, _chk(Pr, None, "Pr"), L.NS3D_BC_MULTI, int(bool(owns_outlet)),
+                       *_d(val, 0.0), 0, *_d(0.0, 0.0), nx, ny, nz)
+
+
+def set_bc_Pr_gpu(Pr, dz, nz_arg, g, rho, ctx=None):
+    """set_bc_Pr!(Pr, dz, nz, g, ρ) of gpu.jl:281-286"""
+    nx, ny, nz = Pr.shape
+    _ctx(ctx, Pr).call("set_bc_Pr", Pr, _chk(Pr, None, "Pr"), L.NS3D_BC_GPU, 0, *_d(0.0, dz), int(nz_arg),
+                       *_d(g, rho), nx, ny, nz)
+
+
+def set_bc_Vel_multi(Vx, Vy, Vz, owns_inlet, vin, ctx=None):
+    """set_bc_Vel!(Vx,Vy,Vz,xvo_g,lx,vin) of multi.jl:156-166 (flag instead of `xvo_g == -lx/2`; halo update
+    multi.jl:167 is the caller's)."""
+    nx, ny, nz = Vx.shape[0] - 1, Vx.shape[1], Vx.shape[2]
+    _ctx(ctx, Vx).call("set_bc_Vel", Vx, _chk(Vx, None, "Vx"), _chk(Vy, (nx, ny + 1, nz), "Vy"),
+                       _chk(Vz, (nx, ny, nz + 1), "Vz"), L.NS3D_BC_MULTI, int(bool(owns_inlet)), *_d(vin), nx, ny, nz)
+
+
+def set_bc_Vel_gpu(Vx, Vy, Vz, ctx=None):
+    """set_bc_Vel!(Vx,Vy,Vz,Vprof) of gpu.jl:264-279 (Vprof is unused there)."""
+    nx, ny, nz = Vx.shape[0] - 1, Vx.shape[1], Vx.shape[2]
+    _ctx(ctx, Vx).call("set_bc_Vel", Vx, _chk(Vx, None, "Vx"), _chk(Vy, (nx, ny + 1, nz), "Vy"),
+                       _chk(Vz, (nx, ny, nz + 1), "Vz"), L.NS3D_BC_GPU, 0, *_d(0.0), nx, ny, nz)
+
+
+# ---- fused pseudo-transient path ------------------------------------------------------------------------
+def pt_params(Pr, rho, dt, dtau, damp, dx, dy, dz, bc_kind=L.NS3D_BC_MULTI, owns_outlet=True, outlet_val=0.0,
+              g=0.0, z_lo_is_halo=False, z_hi_is_halo=False):
+    nx, ny, nz = Pr.shape
+    return L.PtParams(rho, dt, dtau, damp, dx, dy, dz, nx, ny, nz, int(bc_kind), int(bool(owns_outlet)),
+                      outlet_val, g, int(bool(z_lo_is_halo)), int(bool(z_hi_is_halo)))
+
+
+def pt_iterate(Pr, dPrdtau, divV, p, n_iters, ctx=None):
+    """n_iters × {update_dPrdτ!; update_Pr!; set_bc_Pr!} (multi.jl:459-463 / gpu.jl:127-129) as fused sweeps."""
+    nx, ny, nz = Pr.shape
+    _ctx(ctx, Pr).call("pt_iterate", Pr, _chk(Pr, None, "Pr"), _chk(dPrdtau, (nx - 2, ny - 2, nz - 2), "dPrdtau"),
+                       _chk(divV, (nx, ny, nz), "divV"), C.byref(p), int(n_iters))
+
+
+def pt_sweep(Pr_in, Pr_out, dPrdtau, divV, p, k0, k1, ctx=None):
+    """One fused sweep Pr_in → Pr_out over interior planes k0 ≤ k < k1 (0-based)."""
+    nx, ny, nz = Pr_in.shape
+    _ctx(ctx, Pr_in).call("pt_sweep", Pr_in, _chk(Pr_in, None, "Pr_in"), _chk(Pr_out, (nx, ny, nz), "Pr_out"),
+                          _chk(dPrdtau, (nx - 2, ny - 2, nz - 2), "dPrdtau"), _chk(divV, (nx, ny, nz), "divV"),
+                          C.byref(p), int(k0), int(k1))
+
+
+def residual_max(Pr, divV, p, ctx=None):
+    """maximum(abs.(Rp)) after compute_res! (multi.jl:465-466) without materialising Rp."""
+    out = C.c_double(0.0)
+    _ctx(ctx, Pr).call("residual_max", Pr, _chk(Pr, None, "Pr"), _chk(divV, tuple(Pr.shape), "divV"), C.byref(p),
+                       C.byref(out))
+    return out.value
+
+
+def pt_solve(Pr, dPrdtau, divV, p, eps, niter, nchk, err_scale, ctx=None):
+    """The inner loop multi.jl:458-471 / gpu.jl:126-137 on one rank. Returns (iters_done, [err …])."""
+    nx, ny, nz = Pr.shape
+    cap = niter // max(nchk, 1) + 1
+    hist = (C.c_double * cap)()
+    it, nchecks = C.c_int(0), C.c_int(0)
+    _ctx(ctx, Pr).call("pt_solve", Pr, _chk(Pr, None, "Pr"), _chk(dPrdtau, (nx - 2, ny - 2, nz - 2), "dPrdtau"),
+                       _chk(divV, (nx, ny, nz), "divV"), C.byref(p), C.c_double(eps), int(niter), int(nchk),
+                       C.c_double(err_scale), C.byref(it), hist, cap, C.byref(nchecks))
+    return it.value, list(hist[: nchecks.value])

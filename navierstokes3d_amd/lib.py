@@ -1,0 +1,112 @@
+"""ctypes binding of libns3d.so (include/ns3d.h).  There is NO CPU fallback: if the HIP library is missing
+or no GPU is present, every entry point raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libns3d.so")
+
+NS3D_OK = 0
+NS3D_STRICT, NS3D_FAST, NS3D_ASYNC = 0x0, 0x1, 0x2
+NS3D_BC_MULTI, NS3D_BC_GPU = 0, 1
+
+
+class Ns3dError(RuntimeError):
+    pass
+
+
+class PtParams(C.Structure):
+    """struct ns3d_pt_params (include/ns3d.h)."""
+    _fields_ = [
+        ("rho", C.c_double), ("dt", C.c_double), ("dtau", C.c_double), ("damp", C.c_double),
+        ("dx", C.c_double), ("dy", C.c_double), ("dz", C.c_double),
+        ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
+        ("bc_kind", C.c_int), ("owns_outlet", C.c_int),
+        ("outlet_val", C.c_double), ("g", C.c_double),
+        ("z_lo_is_halo", C.c_int), ("z_hi_is_halo", C.c_int),
+    ]
+
+
+_P, _D, _I, _L = C.c_void_p, C.c_double, C.c_int, C.c_long
+
+# name → argument ctypes after the leading ctx pointer (same for _f64 and _f32)
+SIGNATURES = {
+    "update_tau": [_P] * 9 + [_D] * 4 + [_I] * 3,
+    "predict_V": [_P] * 9 + [_D] * 6 + [_I] * 3,
+    "set_cylinder": [_P] * 4 + [_D] * 15 + [_I] * 3,
+    "set_cylinder_local": [_P] * 4 + [_D] * 12 + [_I] * 3,
+    "update_divV": [_P] * 4 + [_D] * 3 + [_I] * 3,
+    "update_dPrdtau": [_P] * 3 + [_D] * 7 + [_I] * 3,
+    "update_Pr": [_P] * 2 + [_D] + [_I] * 3,
+    "compute_res": [_P] * 3 + [_D] * 5 + [_I] * 3,
+    "max_abs": [_P, _L, C.POINTER(_D)],
+    "correct_V": [_P] * 4 + [_D] * 5 + [_I] * 3,
+    "bc_x": [_P] + [_I] * 3,
+    "bc_y": [_P] + [_I] * 3,
+    "bc_z": [_P] + [_I] * 3,
+    "bc_zV": [_P] + [_I] * 3,
+    "bc_xhydstatic": [_P, _D, _I, _D, _D] + [_I] * 3,
+    "bc_x_Vx": [_P, _D] + [_I] * 3,
+    "bc_x_Pr": [_P, _D] + [_I] * 3,
+    "copy": [_P, _P, _L],
+    "advect": [_P] * 8 + [_D] * 4 + [_I] * 4,
+    "set_bc_Pr": [_P, _I, _I, _D, _D, _I, _D, _D] + [_I] * 3,
+    "set_bc_Vel": [_P] * 3 + [_I, _I, _D] + [_I] * 3,
+    "pt_iterate": [_P] * 3 + [C.POINTER(PtParams), _I],
+    "pt_sweep": [_P] * 4 + [C.POINTER(PtParams), _I, _I],
+    "residual_max": [_P] * 2 + [C.POINTER(PtParams), C.POINTER(_D)],
+    "pt_solve": [_P] * 3 + [C.POINTER(PtParams), _D, _I, _I, _D, C.POINTER(_I), C.POINTER(_D), _I, C.POINTER(_I)],
+}
+CONTEXT_SYMBOLS = ["ns3d_version", "ns3d_last_error", "ns3d_create", "ns3d_destroy", "ns3d_flags",
+                   "ns3d_set_stream", "ns3d_get_stream", "ns3d_sync", "ns3d_set_pt_variant"]
+
+
+def exported_symbols():
+    """Every symbol include/ns3d.h declares."""
+    out = list(CONTEXT_SYMBOLS)
+    for n in SIGNATURES:
+        out += ["ns3d_%s_f64" % n, "ns3d_%s_f32" % n]
+    return out
+
+
+_LIB = None
+
+
+def load():
+    """Load libns3d.so (after torch, so that it binds to the HIP runtime already in the process)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise Ns3dError("libns3d.so is not built (run `python -m navierstokes3d_amd.build`); "
+                        "navierstokes3d_amd has no CPU or PyTorch fallback path")
+    import torch  # noqa: F401  (loads libamdhip64.so.7 first)
+    lib = C.CDLL(LIB_PATH)
+    lib.ns3d_version.restype = _I
+    lib.ns3d_last_error.restype = C.c_char_p
+    lib.ns3d_create.restype = _P
+    lib.ns3d_create.argtypes = [_I, _I]
+    lib.ns3d_destroy.restype = None
+    lib.ns3d_destroy.argtypes = [_P]
+    lib.ns3d_flags.argtypes = [_P]
+    lib.ns3d_set_stream.argtypes = [_P, _P]
+    lib.ns3d_get_stream.restype = _P
+    lib.ns3d_get_stream.argtypes = [_P]
+    lib.ns3d_sync.argtypes = [_P]
+    lib.ns3d_set_pt_variant.argtypes = [_P, _I]
+    for name, args in SIGNATURES.items():
+        for suf in ("f64", "f32"):
+            fn = getattr(lib, "ns3d_%s_%s" % (name, suf))
+            fn.restype = _I
+            fn.argtypes = [_P] + args
+    _LIB = lib
+    return lib
+
+
+def last_error():
+    return load().ns3d_last_error().decode(errors="replace")
+
+
+def check(rc):
+    if rc != NS3D_OK:
+        raise Ns3dError("libns3d status %d: %s" % (rc, last_error()))

@@ -1,0 +1,157 @@
+"""GPU parity of the fused pseudo-transient path (the hot loop) against the oracle's UNFUSED reference sequence
+update_dPrdτ! → update_Pr! → set_bc_Pr! (multi.jl:459-463 / gpu.jl:127-129).
+
+STRICT: bit-identical after any number of sweeps, for every sweep variant, both boundary sets, with and without
+the outlet plane, on ragged grids.  FAST: ≤1e-9 relative L2 after 40 sweeps (fp64).
+"""
+import numpy as np
+import pytest
+
+from util import fields, geometry, rel_l2, rnd
+
+pytestmark = pytest.mark.gpu
+
+GRIDS = [(17, 9, 5), (24, 15, 15), (5, 4, 3), (3, 3, 3), (70, 6, 7), (131, 21, 35), (63, 38, 38)]
+VARIANTS = [0, 100, 200, 300, 400, 500, 600, 3, 207, 501]
+
+
+def _oracle_iters(oracle, Pr, d, rhs, g, n, bc_kind, owns_outlet, outlet_val):
+    nx, ny, nz = Pr.shape
+    for _ in range(n):
+        oracle.update_dPrdtau(Pr, d, rhs, g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"])
+        oracle.update_Pr(Pr, d, g["dtau"])
+        oracle.set_bc_Pr(Pr, bc_kind, owns_outlet, outlet_val, g["dz"], nz, g["g"], g["rho"])
+
+
+def _params(hip, dPr, g, bc_kind, owns_outlet, outlet_val, zlo=False, zhi=False):
+    return hip.pt_params(dPr, g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], bc_kind,
+                         owns_outlet, outlet_val, g["g"], zlo, zhi)
+
+
+@pytest.mark.parametrize("bc", [(0, True, 0.0), (0, False, 0.0), (0, True, 0.75), (1, False, 0.0)])
+@pytest.mark.parametrize("grid", GRIDS)
+def test_pt_iterate_strict_bitexact(hip, oracle, grid, bc):
+    import torch
+    nx, ny, nz = grid
+    g = geometry(*grid)
+    bc_kind, owns, val = bc
+    Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 41)
+    ctx = hip.Context(0, "strict")
+    for variant in VARIANTS:
+        ctx.set_pt_variant(variant)
+        for n in (1, 2, 5):
+            Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
+            _oracle_iters(oracle, Pr, d, rhs, g, n, bc_kind, owns, val)
+            dPr, dd, drhs = hip.from_numpy(Pr0), hip.from_numpy(d0), hip.from_numpy(rhs)
+            hip.pt_iterate(dPr, dd, drhs, _params(hip, dPr, g, bc_kind, owns, val), n, ctx=ctx)
+            torch.cuda.synchronize()
+            assert np.array_equal(hip.to_numpy(dd), d), "dPrdτ differs: variant %d n %d" % (variant, n)
+            assert np.array_equal(hip.to_numpy(dPr), Pr), "Pr differs: variant %d n %d" % (variant, n)
+            assert np.array_equal(hip.to_numpy(drhs), rhs)
+    ctx.close()
+
+
+@pytest.mark.parametrize("grid", [(24, 15, 15), (70, 6, 7), (63, 38, 38)])
+def test_pt_iterate_fast_within_tolerance(hip, oracle, grid):
+    import torch
+    nx, ny, nz = grid
+    g = geometry(*grid)
+    Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 43)
+    Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
+    _oracle_iters(oracle, Pr, d, rhs, g, 40, 0, True, 0.0)
+    ctx = hip.Context(0, "fast")
+    dPr, dd, drhs = hip.from_numpy(Pr0), hip.from_numpy(d0), hip.from_numpy(rhs)
+    hip.pt_iterate(dPr, dd, drhs, _params(hip, dPr, g, 0, True, 0.0), 40, ctx=ctx)
+    torch.cuda.synchronize()
+    assert rel_l2(hip.to_numpy(dPr), Pr) < 1e-9 and rel_l2(hip.to_numpy(dd), d) < 1e-9
+    ctx.close()
+
+
+@pytest.mark.parametrize("grid", [(24, 15, 15), (70, 6, 9)])
+def test_pt_sweep_plane_ranges_and_halo_planes(hip, oracle, grid):
+    """Split sweeps (boundary planes first, interior later — the z-slab overlap schedule) equal one full sweep, and
+    halo planes of the output buffer are never written when z_*_is_halo."""
+    import torch
+    nx, ny, nz = grid
+    g = geometry(*grid)
+    Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 47)
+    ctx = hip.Context(0, "strict")
+    for zlo, zhi in ((False, False), (True, False), (False, True), (True, True)):
+        p = _params(hip, hip.from_numpy(Pr0), g, 0, True, 0.0, zlo, zhi)
+        full_in, full_out, dfull = hip.from_numpy(Pr0), hip.from_numpy(np.full_like(Pr0, 777.0)), hip.from_numpy(d0)
+        hip.pt_sweep(full_in, full_out, dfull, hip.from_numpy(rhs), p, 1, nz - 1, ctx=ctx)
+        sp_in, sp_out, dsp = hip.from_numpy(Pr0), hip.from_numpy(np.full_like(Pr0, 777.0)), hip.from_numpy(d0)
+        hip.pt_sweep(sp_in, sp_out, dsp, hip.from_numpy(rhs), p, 1, 2, ctx=ctx)
+        hip.pt_sweep(sp_in, sp_out, dsp, hip.from_numpy(rhs), p, nz - 2, nz - 1, ctx=ctx)
+        hip.pt_sweep(sp_in, sp_out, dsp, hip.from_numpy(rhs), p, 2, nz - 2, ctx=ctx)
+        torch.cuda.synchronize()
+        a, b = hip.to_numpy(full_out), hip.to_numpy(sp_out)
+        assert np.array_equal(a, b) and np.array_equal(hip.to_numpy(dfull), hip.to_numpy(dsp))
+        assert np.all(a[:, :, 0] == 777.0) == zlo and np.all(a[:, :, -1] == 777.0) == zhi
+        # against the oracle: interior + x/y faces of the interior planes
+        Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
+        _oracle_iters(oracle, Pr, d, rhs, g, 1, 0, True, 0.0)
+        assert np.array_equal(a[:, :, 1:-1], Pr[:, :, 1:-1])
+        if not zlo:
+            assert np.array_equal(a[:, :, 0], Pr[:, :, 0])
+        if not zhi:
+            assert np.array_equal(a[:, :, -1], Pr[:, :, -1])
+    ctx.close()
+
+
+@pytest.mark.parametrize("bc_kind", [0, 1])
+def test_residual_max_and_pt_solve(hip, oracle, bc_kind):
+    """ns3d_pt_solve = the whole inner loop incl. the every-nchk residual check and the early exit: identical
+    iteration count, error history and fields as the oracle's loop (multi.jl:458-471 / gpu.jl:126-137)."""
+    import torch
+    nx, ny, nz = 24, 15, 15
+    g = geometry(nx, ny, nz)
+    Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 53)
+    rhs *= 1e-3
+    ctx = hip.Context(0, "strict")
+    dPr = hip.from_numpy(Pr0)
+    p = _params(hip, dPr, g, bc_kind, True, 0.0)
+    Rp = np.zeros((nx - 2, ny - 2, nz - 2), order="F")
+    oracle.compute_res(Rp, Pr0, rhs, g["rho"], g["dt"], g["dx"], g["dy"], g["dz"])
+    assert hip.residual_max(dPr, hip.from_numpy(rhs), p, ctx=ctx) == oracle.max_abs(Rp)
+    for eps, niter, nchk in ((-1.0, 57, 14), (5e4, 400, 14), (1e-30, 45, 7)):
+        Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
+        it_ref, errs_ref = oracle.pt_solve(Pr, d, rhs, Rp, g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"],
+                                           g["dz"], bc_kind, True, 0.0, g["g"], eps, niter, nchk, 0.36e-3)
+        dPr, dd = hip.from_numpy(Pr0), hip.from_numpy(d0)
+        it, errs = hip.pt_solve(dPr, dd, hip.from_numpy(rhs), p, eps, niter, nchk, 0.36e-3, ctx=ctx)
+        torch.cuda.synchronize()
+        assert it == it_ref and errs == errs_ref
+        assert np.array_equal(hip.to_numpy(dPr), Pr) and np.array_equal(hip.to_numpy(dd), d)
+    ctx.close()
+
+
+def test_pt_solve_nan_breaks(hip, oracle):
+    """`!isfinite(err)` exit (multi.jl:469): a NaN in ∇V must stop the loop at the first check."""
+    nx, ny, nz = 17, 9, 5
+    g = geometry(nx, ny, nz)
+    Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 59)
+    rhs[3, 3, 2] = np.nan
+    ctx = hip.Context(0, "strict")
+    dPr = hip.from_numpy(Pr0)
+    it, errs = hip.pt_solve(dPr, hip.from_numpy(d0), hip.from_numpy(rhs), _params(hip, dPr, g, 0, True, 0.0), 1e-3, 100,
+                            8, 1.0, ctx=ctx)
+    assert it == 8 and len(errs) == 1 and np.isnan(errs[0])
+    ctx.close()
+
+
+def test_pt_f32(hip, oracle):
+    """fp32 storage/arithmetic variant (BASELINE.json configs[4] 'fp32 vs fp64 stencil'): bit-identical to the
+    oracle built with REAL=float."""
+    import torch
+    nx, ny, nz = 24, 15, 15
+    g = geometry(nx, ny, nz)
+    Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 61, dtype=np.float32)
+    Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
+    _oracle_iters(oracle, Pr, d, rhs, g, 3, 0, True, 0.0)
+    ctx = hip.Context(0, "strict")
+    dPr, dd = hip.from_numpy(Pr0), hip.from_numpy(d0)
+    hip.pt_iterate(dPr, dd, hip.from_numpy(rhs), _params(hip, dPr, g, 0, True, 0.0), 3, ctx=ctx)
+    torch.cuda.synchronize()
+    assert np.array_equal(hip.to_numpy(dPr), Pr) and np.array_equal(hip.to_numpy(dd), d)
+    ctx.close()
