@@ -51,9 +51,9 @@ def cpu_baseline(n, nzs, iters, dtype):
     rhs = np.asfortranarray((rng.random((p.nz, p.ny, p.nx), dtype=np.float64).transpose(2, 1, 0) * 2e-3 - 1e-3).astype(npdt))
     Rp = O.zeros((p.nx - 2, p.ny - 2, p.nz - 2), npdt)
     args = (p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, 0, False, 0.0, 0.0, -1.0)
-    O.pt_solve(Pr, d, rhs, Rp, *args, 2, 0, 1.0)  # warm-up / page-in
+    O.pt_solve(Pr, d, rhs, Rp, *args, 2, 0, 1.0, 1.0)  # warm-up / page-in
     t0 = time.perf_counter()
-    O.pt_solve(Pr, d, rhs, Rp, *args, iters, 0, 1.0)
+    O.pt_solve(Pr, d, rhs, Rp, *args, iters, 0, 1.0, 1.0)
     t = time.perf_counter() - t0
     cells = p.nx * p.ny * p.nz
     return {
@@ -150,7 +150,7 @@ def main():
         t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, dev_ms = t[0].item(), t[1].item()
-    err = grid.max_g(K.residual_max(Pr, rhs, pt, ctx=ctx)) * p.err_scale
+    err = grid.max_g(K.residual_max(Pr, rhs, pt, ctx=ctx)) * (p.ly * p.ly) / p.psc
     finite = bool(np.isfinite(err))
 
     if rank == 0:

@@ -65,8 +65,10 @@ const char *ns3d_last_error(void);
 ns3d_ctx *ns3d_create(int device, int flags);
 void ns3d_destroy(ns3d_ctx *ctx);
 int ns3d_flags(const ns3d_ctx *ctx);
-/* Use an existing hipStream_t (e.g. PyTorch's current stream); NULL = the context's own stream. */
+/* Launch on an existing hipStream_t (e.g. PyTorch's current stream; NULL is HIP's null stream).  A new context
+ * launches on a private non-blocking stream; ns3d_use_own_stream() returns to it. */
 int ns3d_set_stream(ns3d_ctx *ctx, void *hip_stream);
+int ns3d_use_own_stream(ns3d_ctx *ctx);
 void *ns3d_get_stream(ns3d_ctx *ctx);
 int ns3d_sync(ns3d_ctx *ctx);
 /* Tuning knob for the fused PT sweep (0 = default); see DESIGN.md. */
@@ -163,11 +165,12 @@ typedef struct ns3d_pt_params {
     int ns3d_residual_max_##S(ns3d_ctx *, const T *Pr, const T *divV, const ns3d_pt_params *p,               \
                               double *out_host);                                                             \
     /* The whole inner loop multi.jl:458-471 / gpu.jl:126-137 on one rank: at most niter iterations, every   \
-     * nchk-th computes err = max|Rp|*err_scale, stops on err<eps || !isfinite(err) (eps<0: never stop).     \
+     * nchk-th computes err = max|Rp|*err_mul/err_div (= maximum(abs.(Rp))*ly^2/psc, multi.jl:466), stops  \
+     * on err<eps || !isfinite(err) (eps<0: never stop).                                                      \
      * err_hist (capacity max_checks) may be NULL. */                                                        \
     int ns3d_pt_solve_##S(ns3d_ctx *, T *Pr, T *dPrdtau, const T *divV, const ns3d_pt_params *p, double eps, \
-                          int niter, int nchk, double err_scale, int *iters_done, double *err_hist,          \
-                          int max_checks, int *n_checks);
+                          int niter, int nchk, double err_mul, double err_div, int *iters_done,              \
+                          double *err_hist, int max_checks, int *n_checks);
 
 NS3D_DECL(double, f64)
 NS3D_DECL(float, f32)

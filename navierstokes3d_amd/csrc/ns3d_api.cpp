@@ -129,7 +129,13 @@ int ns3d_flags(const ns3d_ctx *c) { return c ? c->flags : -1; }
 int ns3d_set_stream(ns3d_ctx *c, void *s)
 {
     if (!c) return fail(NS3D_ERR_ARG, "ns3d_set_stream: null context");
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->stream = (hipStream_t)s;
+    return NS3D_OK;
+}
+int ns3d_use_own_stream(ns3d_ctx *c)
+{
+    if (!c) return fail(NS3D_ERR_ARG, "ns3d_use_own_stream: null context");
+    c->stream = c->own_stream;
     return NS3D_OK;
 }
 void *ns3d_get_stream(ns3d_ctx *c) { return c ? (void *)c->stream : nullptr; }
@@ -219,7 +225,8 @@ static int pt_iterate_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_p
 
 template <class T>
 static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_params *p, double eps, int niter,
-                         int nchk, double err_scale, int *iters_done, double *err_hist, int max_checks, int *n_checks)
+                         int nchk, double err_mul, double err_div, int *iters_done, double *err_hist, int max_checks,
+                         int *n_checks)
 {
     T *other = nullptr;
     int rc = ensure_pingpong<T>(c, p, &other);
@@ -236,7 +243,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
             if (e != hipSuccess) return fail(NS3D_ERR_HIP, "residual launch: %s", hipGetErrorString(e));
             double mx;
             if ((rc = fetch_key(c, &mx))) return rc;
-            const double err = mx * err_scale;
+            const double err = mx * err_mul / err_div; // maximum(abs.(Rp))*ly^2/psc, multi.jl:466
             if (err_hist && checks < max_checks) err_hist[checks] = err;
             ++checks;
             if (eps >= 0 && (err < eps || !std::isfinite(err))) { done = iter; break; }
@@ -439,8 +446,8 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
         return fetch_key(c, out_host);                                                                       \
     }                                                                                                        \
     extern "C" int ns3d_pt_solve_##S(ns3d_ctx *c, T *Pr, T *dPrdtau, const T *divV, const ns3d_pt_params *p, \
-                                     double eps, int niter, int nchk, double err_scale, int *iters_done,     \
-                                     double *err_hist, int max_checks, int *n_checks)                        \
+                                     double eps, int niter, int nchk, double err_mul, double err_div,        \
+                                     int *iters_done, double *err_hist, int max_checks, int *n_checks)       \
     {                                                                                                        \
         CHECK_CTX(c); CHECK_PTRS(Pr, dPrdtau, divV);                                                         \
         int rc = check_pt_params(p, "ns3d_pt_solve");                                                        \
@@ -448,7 +455,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
         if (p->z_lo_is_halo || p->z_hi_is_halo)                                                              \
             return fail(NS3D_ERR_ARG, "ns3d_pt_solve: single-rank loop; drive z-slab ranks with ns3d_pt_sweep + halo exchange"); \
         if (niter < 0 || nchk < 0) return fail(NS3D_ERR_ARG, "ns3d_pt_solve: negative niter/nchk");          \
-        if ((rc = pt_solve_impl<T>(c, Pr, dPrdtau, divV, p, eps, niter, nchk, err_scale, iters_done,         \
+        if ((rc = pt_solve_impl<T>(c, Pr, dPrdtau, divV, p, eps, niter, nchk, err_mul, err_div, iters_done,  \
                                    err_hist, max_checks, n_checks))) return rc;                              \
         return finish(c, hipSuccess, "pt_solve");                                                            \
     }

@@ -75,7 +75,7 @@ def pt_loop_reference(ctx, grid, f, p, niter, do_print=False):
         grid.update_halo(f.Pr)                                                                            # :182
         if it % p.nchk == 0:                                                                              # :464
             K.compute_res(f.Rp, f.Pr, f.divV, p.rho, p.dt, p.dx, p.dy, p.dz, ctx=ctx)                     # :465
-            err = grid.max_g(K.max_abs(f.Rp, ctx=ctx)) * p.ly * p.ly / p.psc                              # :466
+            err = grid.max_g(K.max_abs(f.Rp, ctx=ctx)) * (p.ly * p.ly) / p.psc                              # :466
             errs.append(err)
             if grid.me == 0 and do_print:
                 print("  #iter = %d, err = %1.3e" % (it, err))                                            # :468
@@ -104,7 +104,7 @@ def pt_loop_fused_slab(ctx, grid, f, p, pt, niter, do_print=False, scratch=None)
         grid.finish_halo(work)
         Pa, Pb = Pb, Pa
         if it % p.nchk == 0:
-            err = grid.max_g(K.residual_max(Pa, f.divV, pt, ctx=ctx)) * p.ly * p.ly / p.psc
+            err = grid.max_g(K.residual_max(Pa, f.divV, pt, ctx=ctx)) * (p.ly * p.ly) / p.psc
             errs.append(err)
             if grid.me == 0 and do_print:
                 print("  #iter = %d, err = %1.3e" % (it, err))
@@ -169,7 +169,7 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
         if not fused:                                                                         # :458-471
             done, errs = pt_loop_reference(ctx, grid, f, p, niter, do_print)
         elif P == 1:
-            done, errs = K.pt_solve(f.Pr, f.dPrdtau, f.divV, pt, p.eps, niter, p.nchk, p.err_scale, ctx=ctx)
+            done, errs = K.pt_solve(f.Pr, f.dPrdtau, f.divV, pt, p.eps, niter, p.nchk, p.ly * p.ly, p.psc, ctx=ctx)
             if me == 0 and do_print:
                 for q, e in enumerate(errs):
                     print("  #iter = %d, err = %1.3e" % ((q + 1) * p.nchk, e))
@@ -237,7 +237,7 @@ def runme(do_vis=False, do_save=False, *, nx=255, nt=10000, mode="strict", fused
         if do_print:
             print("#it = %d" % it)                                                            # :125
         if fused:
-            done, errs = K.pt_solve(f.Pr, f.dPrdtau, f.divV, pt, p.eps, niter, p.nchk, p.err_scale, ctx=ctx)
+            done, errs = K.pt_solve(f.Pr, f.dPrdtau, f.divV, pt, p.eps, niter, p.nchk, p.ly * p.ly, p.psc, ctx=ctx)
         else:
             errs, done = [], niter
             for itr in range(1, niter + 1):                                                   # :126
@@ -246,7 +246,7 @@ def runme(do_vis=False, do_save=False, *, nx=255, nt=10000, mode="strict", fused
                 K.set_bc_Pr_gpu(f.Pr, p.dz, nz, p.g, p.rho, ctx=ctx)                          # :129
                 if itr % p.nchk == 0:                                                         # :130
                     K.compute_res(f.Rp, f.Pr, f.divV, p.rho, p.dt, p.dx, p.dy, p.dz, ctx=ctx)  # :131
-                    err = K.max_abs(f.Rp, ctx=ctx) * p.ly * p.ly / p.psc                      # :132
+                    err = K.max_abs(f.Rp, ctx=ctx) * (p.ly * p.ly) / p.psc                      # :132
                     errs.append(err)
                     if err < p.eps or not math.isfinite(err):                                 # :135
                         done = itr

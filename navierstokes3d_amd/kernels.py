@@ -48,7 +48,8 @@ def _chk(t, shape=None, name="array"):
     if t.dtype not in _DT:
         raise L.Ns3dError("%s: unsupported dtype %s" % (name, t.dtype))
     sx, sy, sz = t.shape
-    if t.stride() != (1, sx, sx * sy):
+    want = (1, sx, sx * sy)
+    if any(n > 1 and s != w for n, s, w in zip(t.shape, t.stride(), want)):   # strides of extent-1 dims are free
         raise L.Ns3dError("%s must be column-major (x fastest): use kernels.zeros / from_numpy" % name)
     if shape is not None and tuple(t.shape) != tuple(shape):
         raise L.Ns3dError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
@@ -331,13 +332,14 @@ def residual_max(Pr, divV, p, ctx=None):
     return out.value
 
 
-def pt_solve(Pr, dPrdtau, divV, p, eps, niter, nchk, err_scale, ctx=None):
-    """The inner loop multi.jl:458-471 / gpu.jl:126-137 on one rank. Returns (iters_done, [err …])."""
+def pt_solve(Pr, dPrdtau, divV, p, eps, niter, nchk, err_mul, err_div, ctx=None):
+    """The inner loop multi.jl:458-471 / gpu.jl:126-137 on one rank; err = max|Rp|*err_mul/err_div
+    (= maximum(abs.(Rp))*ly^2/psc). Returns (iters_done, [err …])."""
     nx, ny, nz = Pr.shape
     cap = niter // max(nchk, 1) + 1
     hist = (C.c_double * cap)()
     it, nchecks = C.c_int(0), C.c_int(0)
     _ctx(ctx, Pr).call("pt_solve", Pr, _chk(Pr, None, "Pr"), _chk(dPrdtau, (nx - 2, ny - 2, nz - 2), "dPrdtau"),
                        _chk(divV, (nx, ny, nz), "divV"), C.byref(p), C.c_double(eps), int(niter), int(nchk),
-                       C.c_double(err_scale), C.byref(it), hist, cap, C.byref(nchecks))
+                       C.c_double(err_mul), C.c_double(err_div), C.byref(it), hist, cap, C.byref(nchecks))
     return it.value, list(hist[: nchecks.value])

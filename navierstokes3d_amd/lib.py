@@ -55,10 +55,10 @@ SIGNATURES = {
     "pt_iterate": [_P] * 3 + [C.POINTER(PtParams), _I],
     "pt_sweep": [_P] * 4 + [C.POINTER(PtParams), _I, _I],
     "residual_max": [_P] * 2 + [C.POINTER(PtParams), C.POINTER(_D)],
-    "pt_solve": [_P] * 3 + [C.POINTER(PtParams), _D, _I, _I, _D, C.POINTER(_I), C.POINTER(_D), _I, C.POINTER(_I)],
+    "pt_solve": [_P] * 3 + [C.POINTER(PtParams), _D, _I, _I, _D, _D, C.POINTER(_I), C.POINTER(_D), _I, C.POINTER(_I)],
 }
 CONTEXT_SYMBOLS = ["ns3d_version", "ns3d_last_error", "ns3d_create", "ns3d_destroy", "ns3d_flags",
-                   "ns3d_set_stream", "ns3d_get_stream", "ns3d_sync", "ns3d_set_pt_variant"]
+                   "ns3d_set_stream", "ns3d_use_own_stream", "ns3d_get_stream", "ns3d_sync", "ns3d_set_pt_variant"]
 
 
 def exported_symbols():
@@ -90,6 +90,7 @@ def load():
     lib.ns3d_destroy.argtypes = [_P]
     lib.ns3d_flags.argtypes = [_P]
     lib.ns3d_set_stream.argtypes = [_P, _P]
+    lib.ns3d_use_own_stream.argtypes = [_P]
     lib.ns3d_get_stream.restype = _P
     lib.ns3d_get_stream.argtypes = [_P]
     lib.ns3d_sync.argtypes = [_P]

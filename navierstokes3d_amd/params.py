@@ -48,7 +48,6 @@ def multi_params(nx, dims_z=1, coord_z=0):
     p.dt = min(CFL_visc * (m * m) * p.rho / p.mu, CFL_adv * m / p.vin)     # :339
     p.damp = 2 / p.nx                                                      # :340 (local nx)
     p.dtau = CFLtau * m                                                    # :341
-    p.err_scale = p.ly * p.ly / p.psc                                      # :466  err = max*ly^2/psc
     # global-coordinate origins, :363-367, with ImplicitGlobalGrid's x_g [upstream]:
     #   x_g(ix,dx,A) = (coord*(n-2) + ix-1)*dx + 0.5*(n-size(A))*dx
     def x_g(i1, d, size_a, n, coord):
@@ -87,7 +86,6 @@ def gpu_params(nx=255):
     p.dt = min(CFL_visc * (m * m) * p.rho / p.mu, CFL_adv * m / p.vin)     # :59
     p.damp = 2 / p.nx                                                      # :60
     p.dtau = CFLtau * m                                                    # :61
-    p.err_scale = p.ly * p.ly / p.psc                                      # :132
     return p
 
 
@@ -107,5 +105,4 @@ def cavity_params(n=512, nz=None):
     p.damp = 2 / p.nx
     p.g = 0.0
     p.psc = p.rho * p.vin * p.vin
-    p.err_scale = p.ly * p.ly / p.psc
     return p

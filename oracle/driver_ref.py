@@ -147,7 +147,6 @@ def run_navierstokes3D_ref(nx=63, nt=1, dims_z=1, dtype=np.float64, faithful=Tru
         update_halo_z(ranks, n, nz)
 
     info = Obj(iters=[], errs=[], params=p)
-    err_scale = p.err_scale_num / p.psc
     for it in range(1, nt + 1):                                                            # :446
         for f in ranks:                                                                    # :449
             K.update_tau(f.txx, f.tyy, f.tzz, f.txy, f.txz, f.tyz, f.Vx, f.Vy, f.Vz, p.mu, p.dx, p.dy, p.dz)
@@ -168,7 +167,7 @@ def run_navierstokes3D_ref(nx=63, nt=1, dims_z=1, dtype=np.float64, faithful=Tru
             f = ranks[0]
             iters_done, errs = K.pt_solve(f.Pr, f.dPrdtau, f.divV, f.Rp, p.rho, p.dt, p.dtau, p.damp, p.dx,
                                           p.dy, p.dz, 0, f.owns_outlet, 0.0, p.g, p.eps, niter, p.nchk,
-                                          err_scale)
+                                          p.err_scale_num, p.psc)
         else:
             for itr in range(1, niter + 1):                                                # :458
                 for f in ranks:                                                            # :459
@@ -185,7 +184,7 @@ def run_navierstokes3D_ref(nx=63, nt=1, dims_z=1, dtype=np.float64, faithful=Tru
                         K.compute_res(f.Rp, f.Pr, f.divV, p.rho, p.dt, p.dx, p.dy, p.dz)   # :465
                     loc = [K.max_abs(f.Rp) for f in ranks]
                     mx = float("nan") if any(math.isnan(v) for v in loc) else max(loc)     # :21 max_g
-                    err = mx * err_scale                                                   # :466
+                    err = mx * p.err_scale_num / p.psc                                     # :466
                     errs.append(err)
                     if err < p.eps or not math.isfinite(err):                              # :469
                         iters_done = itr
@@ -269,7 +268,6 @@ def runme_ref(nx=255, nt=1, dtype=np.float64, faithful=True, niter_cap=None):
     Vx0, Pr0 = gpu_initial_fields(p)
     f.Vx[...] = Vx0.astype(dtype); f.Pr[...] = Pr0.astype(dtype)
     niter = p.niter if niter_cap is None else min(p.niter, niter_cap)
-    err_scale = p.ly * p.ly / p.psc
     info = Obj(iters=[], errs=[], params=p)
     for it in range(1, nt + 1):                                                            # :119
         K.update_tau(f.txx, f.tyy, f.tzz, f.txy, f.txz, f.tyz, f.Vx, f.Vy, f.Vz, p.mu, p.dx, p.dy, p.dz)
@@ -278,7 +276,7 @@ def runme_ref(nx=255, nt=1, dtype=np.float64, faithful=True, niter_cap=None):
                              p.dx, p.dy, p.dz)
         K.update_divV(f.divV, f.Vx, f.Vy, f.Vz, p.dx, p.dy, p.dz)
         iters_done, errs = K.pt_solve(f.Pr, f.dPrdtau, f.divV, f.Rp, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy,
-                                      p.dz, 1, False, 0.0, p.g, p.eps, niter, p.nchk, err_scale)   # :126-137
+                                      p.dz, 1, False, 0.0, p.g, p.eps, niter, p.nchk, p.ly * p.ly, p.psc)   # :126-137
         info.iters.append(iters_done); info.errs.append(errs)
         K.correct_V(f.Vx, f.Vy, f.Vz, f.Pr, p.dt, p.rho, p.dx, p.dy, p.dz)                 # :138
         K.set_cylinder_local(f.C, f.Vx, f.Vy, f.Vz, p.a2, p.b2, p.ox, p.oy, p.sinb, p.cosb, p.lx, p.ly, p.lz,

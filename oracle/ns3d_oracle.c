@@ -505,15 +505,15 @@ void FN(ns3d_ref_set_bc_Vel)(REAL *Vx, REAL *Vy, REAL *Vz, int bc_kind, int owns
 }
 
 /* The pseudo-transient inner loop, multi.jl:458-471 / gpu.jl:126-137, single rank.
- * Runs at most niter iterations; every nchk iterations computes err = max|Rp|*err_scale
- * (err_scale = ly^2/psc) and stops if err < eps or !isfinite(err).  eps < 0 disables the
+ * Runs at most niter iterations; every nchk iterations computes err = max|Rp|*err_mul/err_div
+ * (= maximum(abs.(Rp))*ly^2/psc, multi.jl:466: err_mul = ly^2, err_div = psc) and stops if err < eps or !isfinite(err).  eps < 0 disables the
  * early exit (fixed-iteration benchmark mode) but residuals are still recorded.
  * Returns the number of iterations done; err_hist[] receives one value per check
  * (capacity max_checks), *n_checks their count.                                                 */
 int FN(ns3d_ref_pt_solve)(REAL *Pr, REAL *dPrdtau, const REAL *divV, REAL *Rp, double rho, double dt,
                           double dtau, double damp, double dx, double dy, double dz, int nx, int ny,
                           int nz, int bc_kind, int owns_outlet, double outlet_val, double g,
-                          double eps, int niter, int nchk, double err_scale, double *err_hist,
+                          double eps, int niter, int nchk, double err_mul, double err_div, double *err_hist,
                           int max_checks, int *n_checks)
 {
     int checks = 0, iter;
@@ -523,7 +523,7 @@ int FN(ns3d_ref_pt_solve)(REAL *Pr, REAL *dPrdtau, const REAL *divV, REAL *Rp, d
         FN(ns3d_ref_set_bc_Pr)(Pr, bc_kind, owns_outlet, outlet_val, dz, nz, g, rho, nx, ny, nz);
         if (nchk > 0 && iter % nchk == 0) {
             FN(ns3d_ref_compute_res)(Rp, Pr, divV, rho, dt, dx, dy, dz, nx, ny, nz);
-            double err = FN(ns3d_ref_max_abs)(Rp, (long)(nx - 2) * (ny - 2) * (nz - 2)) * err_scale;
+            double err = FN(ns3d_ref_max_abs)(Rp, (long)(nx - 2) * (ny - 2) * (nz - 2)) * err_mul / err_div;
             if (err_hist && checks < max_checks) err_hist[checks] = err;
             ++checks;
             if (eps >= 0 && (err < eps || !isfinite(err))) break;

@@ -171,13 +171,13 @@ def set_bc_Vel(Vx, Vy, Vz, bc_kind, owns_inlet=True, vin=0.0):
 
 
 def pt_solve(Pr, dPrdtau, divV, Rp, rho, dt, dtau, damp, dx, dy, dz, bc_kind, owns_outlet, outlet_val, g,
-             eps, niter, nchk, err_scale):
+             eps, niter, nchk, err_mul, err_div):
     """multi.jl:458-471 / gpu.jl:126-137 on one rank. Returns (iters_done, [err per check])."""
     nx, ny, nz = Pr.shape
     cap = niter // max(nchk, 1) + 1
     hist = np.zeros(cap, dtype=np.float64)
     nchecks = C.c_int(0)
     it = _call("pt_solve", Pr, _p(Pr), _p(dPrdtau), _p(divV), _p(Rp), *_d(rho, dt, dtau, damp, dx, dy, dz),
-               *_i(nx, ny, nz, bc_kind, owns_outlet), *_d(outlet_val, g, eps), *_i(niter, nchk), *_d(err_scale),
+               *_i(nx, ny, nz, bc_kind, owns_outlet), *_d(outlet_val, g, eps), *_i(niter, nchk), *_d(err_mul, err_div),
                hist.ctypes.data_as(C.c_void_p), C.c_int(cap), C.byref(nchecks))
     return int(it), hist[: nchecks.value].tolist()

@@ -117,9 +117,9 @@ def test_residual_max_and_pt_solve(hip, oracle, bc_kind):
     for eps, niter, nchk in ((-1.0, 57, 14), (5e4, 400, 14), (1e-30, 45, 7)):
         Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
         it_ref, errs_ref = oracle.pt_solve(Pr, d, rhs, Rp, g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"],
-                                           g["dz"], bc_kind, True, 0.0, g["g"], eps, niter, nchk, 0.36e-3)
+                                           g["dz"], bc_kind, True, 0.0, g["g"], eps, niter, nchk, 0.36, 1000.0)
         dPr, dd = hip.from_numpy(Pr0), hip.from_numpy(d0)
-        it, errs = hip.pt_solve(dPr, dd, hip.from_numpy(rhs), p, eps, niter, nchk, 0.36e-3, ctx=ctx)
+        it, errs = hip.pt_solve(dPr, dd, hip.from_numpy(rhs), p, eps, niter, nchk, 0.36, 1000.0, ctx=ctx)
         torch.cuda.synchronize()
         assert it == it_ref and errs == errs_ref
         assert np.array_equal(hip.to_numpy(dPr), Pr) and np.array_equal(hip.to_numpy(dd), d)
@@ -135,7 +135,7 @@ def test_pt_solve_nan_breaks(hip, oracle):
     ctx = hip.Context(0, "strict")
     dPr = hip.from_numpy(Pr0)
     it, errs = hip.pt_solve(dPr, hip.from_numpy(d0), hip.from_numpy(rhs), _params(hip, dPr, g, 0, True, 0.0), 1e-3, 100,
-                            8, 1.0, ctx=ctx)
+                            8, 1.0, 1.0, ctx=ctx)
     assert it == 8 and len(errs) == 1 and np.isnan(errs[0])
     ctx.close()
 

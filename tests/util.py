@@ -21,9 +21,11 @@ def fields(nx, ny, nz, kinds, seed0=1, dtype=np.float64):
     return [rnd(seed0 + q, SHAPES[k](nx, ny, nz), dtype) for q, k in enumerate(kinds)]
 
 
-def rel_l2(a, b):
+def rel_l2(a, b, den=None):
+    """‖a−b‖₂ / ‖b‖₂ (or / den when a reference norm is given, e.g. the norm of the whole velocity vector for one
+    component that is pure round-off by symmetry)."""
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
-    den = np.sqrt(np.sum(b * b))
+    den = np.sqrt(np.sum(b * b)) if den is None else float(den)
     num = np.sqrt(np.sum((a - b) ** 2))
     return float(num / den) if den > 0 else float(num)
 
