@@ -150,7 +150,7 @@ int ns3d_sync(ns3d_ctx *c)
 int ns3d_set_pt_variant(ns3d_ctx *c, int v)
 {
     if (!c) return fail(NS3D_ERR_ARG, "ns3d_set_pt_variant: null context");
-    if (v < 0 || v >= 700) return fail(NS3D_ERR_ARG, "ns3d_set_pt_variant: unknown variant %d", v);
+    if (v < 0 || v >= 10000) return fail(NS3D_ERR_ARG, "ns3d_set_pt_variant: unknown variant %d", v);
     c->pt_variant = v;
     return NS3D_OK;
 }

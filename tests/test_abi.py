@@ -1,0 +1,89 @@
+"""CPU tests of the boundary: libns3d.so builds for gfx950, loads, exports every symbol include/ns3d.h declares, and
+refuses to run without a GPU (no CPU fallback, no oracle in the product path).  No compute calls here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from navierstokes3d_amd import build, lib
+    build.build()
+    return lib
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "ns3d.h")).read()
+    names = set(re.findall(r"\b(ns3d_[a-zA-Z_0-9]+?)(?:_##S)?\s*\(", src))
+    names.discard("ns3d_ctx")
+    out = set()
+    for n in names:
+        base = n
+        # names inside the NS3D_DECL macro carry the _##S suffix in the text
+        if re.search(r"\b%s_##S\s*\(" % re.escape(n), src):
+            out.update({base + "_f64", base + "_f32"})
+        else:
+            out.add(base)
+    return out
+
+
+def test_header_and_binding_agree(L):
+    assert _header_symbols() == set(L.exported_symbols())
+
+
+def test_library_exports_every_declared_symbol(L):
+    lib = L.load()
+    missing = [s for s in sorted(_header_symbols()) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert lib.ns3d_version() == 1
+
+
+def test_code_object_is_gfx950_only(L):
+    """The fat binary must carry gfx950 code objects and nothing else (no CUDA path, no dual build)."""
+    blob = open(L.LIB_PATH, "rb").read()
+    targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", blob))
+    assert targets == {b"gfx950"}, targets
+    assert b"nvptx" not in blob and b"sm_" + b"90" not in blob
+
+
+def test_no_gpu_fails_loudly(L):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this check is for the GPU-less build container")
+    lib = L.load()
+    h = lib.ns3d_create(0, 0)
+    assert not h
+    assert "no CPU path" in L.last_error()
+    from navierstokes3d_amd import kernels
+    with pytest.raises(L.Ns3dError):
+        kernels.Context(0)
+    with pytest.raises(L.Ns3dError):      # CPU tensors are refused before any library call
+        kernels.bc_x(torch.zeros(4, 4, 4, dtype=torch.float64))
+
+
+def test_null_context_is_an_error_not_a_crash(L):
+    lib = L.load()
+    assert lib.ns3d_sync(None) == 1       # NS3D_ERR_ARG
+    assert "null context" in L.last_error()
+    p = L.PtParams()
+    assert lib.ns3d_pt_iterate_f64(None, None, None, None, ctypes.byref(p), 1) == 1
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(ROOT, "navierstokes3d_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), fn
+                assert "ns3d_ref_" not in txt and "libns3d_oracle" not in txt, fn
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"from oracle", bench)]
+    body = bench[bench.index("def cpu_baseline"):bench.index("def main")]
+    assert len(uses) == 1 and "from oracle" in body
