@@ -16,7 +16,7 @@
  *        Pr,C,C_o,τxx,τyy,τzz,∇V : (nx,ny,nz)      Vx,Vx_o : (nx+1,ny,nz)   Vy,Vy_o : (nx,ny+1,nz)
  *        Vz,Vz_o : (nx,ny,nz+1)    τxy,τxz,τyz : (nx-1,ny-1,nz-1)           dPrdτ,Rp : (nx-2,ny-2,nz-2)
  *    The caller owns every field buffer.  The library owns only its context (stream, reduction scratch,
- *    a lazily allocated ping-pong Pr buffer for the fused PT path).
+ *    lazily allocated ping-pong Pr / dPrdτ buffers for the fused PT path).
  *  - Suffix _f64 / _f32 = element type of the arrays; scalar parameters are always C double (Julia
  *    Float64 host values) and are converted to the element type on entry.
  *  - Every function returns 0 (NS3D_OK) or a non-zero status; the message is available from
@@ -73,6 +73,9 @@ void *ns3d_get_stream(ns3d_ctx *ctx);
 int ns3d_sync(ns3d_ctx *ctx);
 /* Tuning knob for the fused PT sweep (0 = default); see DESIGN.md. */
 int ns3d_set_pt_variant(ns3d_ctx *ctx, int variant);
+/* Temporal blocking: ns3d_pt_iterate / ns3d_pt_solve advance TWO PT iterations per pass over memory where the
+ * schedule allows it (same results).  variant < 0 disables, 0 = default tile shape, see DESIGN.md. */
+int ns3d_set_pt2_variant(ns3d_ctx *ctx, int variant);
 
 /* Parameters of the fused pseudo-transient path (ns3d_pt_iterate / ns3d_pt_solve). */
 typedef struct ns3d_pt_params {
@@ -160,6 +163,11 @@ typedef struct ns3d_pt_params {
      * exchange). */                                                                                         \
     int ns3d_pt_sweep_##S(ns3d_ctx *, const T *Pr_in, T *Pr_out, T *dPrdtau, const T *divV,                  \
                           const ns3d_pt_params *p, int k0, int k1);                                          \
+    /* TWO fused PT iterations (Pr_in,dPrdtau_in) → (Pr_out,dPrdtau_out), all four buffers distinct (tiles       \
+     * overlap, so nothing is updated in place); results identical to two ns3d_pt_sweep calls with a buffer     \
+     * swap.  Not available on z-slab ranks (z_*_is_halo must be 0). */                                          \
+    int ns3d_pt_sweep2_##S(ns3d_ctx *, const T *Pr_in, T *Pr_out, const T *dPrdtau_in, T *dPrdtau_out,       \
+                           const T *divV, const ns3d_pt_params *p);                                          \
     /* max|∇²Pr − ρ/dt ∇V| over the interior = maximum(abs.(Rp)) after compute_res!, without writing Rp.   \
      * NaN-propagating.  (multi.jl:465-466) */                                                               \
     int ns3d_residual_max_##S(ns3d_ctx *, const T *Pr, const T *divV, const ns3d_pt_params *p,               \

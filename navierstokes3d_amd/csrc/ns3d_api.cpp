@@ -29,7 +29,10 @@ struct ns3d_ctx {
     unsigned long long *key_host; // pinned host mirror
     void *pingpong;               // second Pr buffer of the fused PT path (lazily sized)
     size_t pingpong_bytes;
+    void *pingpong_d;             // second dPrdτ buffer (temporal blocking only)
+    size_t pingpong_d_bytes;
     int pt_variant;
+    int pt2_variant; // tile shape of the two-iteration sweep; <0: temporal blocking off
 };
 
 #define HIPCHK(ctx, expr)                                                                                   \
@@ -98,7 +101,10 @@ ns3d_ctx *ns3d_create(int device, int flags)
     c->flags = flags;
     c->pingpong = nullptr;
     c->pingpong_bytes = 0;
+    c->pingpong_d = nullptr;
+    c->pingpong_d_bytes = 0;
     c->pt_variant = 0;
+    c->pt2_variant = 0; // temporal blocking on by default (ns3d_set_pt2_variant(ctx,-1) turns it off)
     c->key_dev = nullptr;
     c->key_host = nullptr;
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
@@ -118,6 +124,7 @@ void ns3d_destroy(ns3d_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->pingpong) (void)hipFree(c->pingpong);
+    if (c->pingpong_d) (void)hipFree(c->pingpong_d);
     if (c->key_dev) (void)hipFree(c->key_dev);
     if (c->key_host) (void)hipHostFree(c->key_host);
     (void)hipStreamDestroy(c->own_stream);
@@ -152,6 +159,14 @@ int ns3d_set_pt_variant(ns3d_ctx *c, int v)
     if (!c) return fail(NS3D_ERR_ARG, "ns3d_set_pt_variant: null context");
     if (v < 0 || v >= 10000) return fail(NS3D_ERR_ARG, "ns3d_set_pt_variant: unknown variant %d", v);
     c->pt_variant = v;
+    return NS3D_OK;
+}
+
+int ns3d_set_pt2_variant(ns3d_ctx *c, int v)
+{
+    if (!c) return fail(NS3D_ERR_ARG, "ns3d_set_pt2_variant: null context");
+    if (v >= 10000) return fail(NS3D_ERR_ARG, "ns3d_set_pt2_variant: unknown variant %d", v);
+    c->pt2_variant = v;
     return NS3D_OK;
 }
 
@@ -198,6 +213,24 @@ static int ensure_pingpong(ns3d_ctx *c, const ns3d_pt_params *p, T **buf)
     return NS3D_OK;
 }
 
+template <class T>
+static int ensure_pingpong_d(ns3d_ctx *c, const ns3d_pt_params *p, T **buf)
+{
+    const size_t need = (size_t)(p->nx - 2) * (p->ny - 2) * (p->nz - 2) * sizeof(T);
+    if (c->pingpong_d_bytes < need) {
+        if (c->pingpong_d) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipFree(c->pingpong_d));
+            c->pingpong_d = nullptr;
+            c->pingpong_d_bytes = 0;
+        }
+        HIPCHK(c, hipMalloc(&c->pingpong_d, need));
+        c->pingpong_d_bytes = need;
+    }
+    *buf = (T *)c->pingpong_d;
+    return NS3D_OK;
+}
+
 // n_iters fused sweeps, result left in Pr (one D2D copy when n_iters is odd).  With z halos the scratch
 // buffer's halo planes are seeded from Pr first (a sweep never writes them).
 template <class T>
@@ -213,11 +246,25 @@ static int pt_iterate_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_p
         HIPCHK(c, hipMemcpyAsync(other + plane * (p->nz - 1), Pr + plane * (p->nz - 1), plane * sizeof(T),
                                  hipMemcpyDeviceToDevice, c->stream));
     T *src = Pr, *dst = other;
-    for (int it = 0; it < n_iters; ++it) {
-        hipError_t e = DISPATCH(c, pt_sweep<T>(c->stream, c->pt_variant, src, dst, D, divV, *p, 1, p->nz - 1));
+    T *dsrc = D, *ddst = nullptr;
+    const bool two = c->pt2_variant >= 0 && !p->z_lo_is_halo && !p->z_hi_is_halo && n_iters >= 2;
+    if (two && (rc = ensure_pingpong_d<T>(c, p, &ddst))) return rc;
+    for (int it = 0; it < n_iters;) {
+        hipError_t e;
+        if (two && it + 2 <= n_iters) {
+            e = DISPATCH(c, pt_sweep2<T>(c->stream, c->pt2_variant, src, dst, dsrc, ddst, divV, *p));
+            T *t = dsrc; dsrc = ddst; ddst = t;
+            it += 2;
+        } else {
+            e = DISPATCH(c, pt_sweep<T>(c->stream, c->pt_variant, src, dst, dsrc, divV, *p, 1, p->nz - 1));
+            it += 1;
+        }
         if (e != hipSuccess) return fail(NS3D_ERR_HIP, "pt_sweep launch: %s", hipGetErrorString(e));
         T *t = src; src = dst; dst = t;
     }
+    if (dsrc != D)
+        HIPCHK(c, hipMemcpyAsync(D, dsrc, (size_t)(p->nx - 2) * (p->ny - 2) * (p->nz - 2) * sizeof(T),
+                                 hipMemcpyDeviceToDevice, c->stream));
     if (src != Pr)
         HIPCHK(c, hipMemcpyAsync(Pr, src, plane * p->nz * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
     return NS3D_OK;
@@ -234,8 +281,21 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
     const size_t plane = (size_t)p->nx * p->ny;
     T *src = Pr, *dst = other;
     int checks = 0, iter = 0, done = niter;
-    for (iter = 1; iter <= niter; ++iter) {
-        hipError_t e = DISPATCH(c, pt_sweep<T>(c->stream, c->pt_variant, src, dst, D, divV, *p, 1, p->nz - 1));
+    const bool two = c->pt2_variant >= 0 && niter >= 2;
+    T *dsrc = D, *ddst = nullptr;
+    if (two && (rc = ensure_pingpong_d<T>(c, p, &ddst))) return rc;
+    while (iter < niter) {
+        hipError_t e;
+        // two iterations per pass unless that would step over a residual check or the iteration budget
+        const int to_check = nchk > 0 ? nchk - iter % nchk : niter - iter;
+        if (two && to_check >= 2 && iter + 2 <= niter) {
+            e = DISPATCH(c, pt_sweep2<T>(c->stream, c->pt2_variant, src, dst, dsrc, ddst, divV, *p));
+            T *t = dsrc; dsrc = ddst; ddst = t;
+            iter += 2;
+        } else {
+            e = DISPATCH(c, pt_sweep<T>(c->stream, c->pt_variant, src, dst, dsrc, divV, *p, 1, p->nz - 1));
+            iter += 1;
+        }
         if (e != hipSuccess) return fail(NS3D_ERR_HIP, "pt_sweep launch: %s", hipGetErrorString(e));
         T *t = src; src = dst; dst = t;
         if (nchk > 0 && iter % nchk == 0) { // multi.jl:464-469
@@ -251,6 +311,9 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
     }
     if (src != Pr)
         HIPCHK(c, hipMemcpyAsync(Pr, src, plane * p->nz * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+    if (dsrc != D)
+        HIPCHK(c, hipMemcpyAsync(D, dsrc, (size_t)(p->nx - 2) * (p->ny - 2) * (p->nz - 2) * sizeof(T),
+                                 hipMemcpyDeviceToDevice, c->stream));
     if (iters_done) *iters_done = done;
     if (n_checks) *n_checks = checks;
     return NS3D_OK;
@@ -434,6 +497,19 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
             return fail(NS3D_ERR_ARG, "ns3d_pt_sweep: plane range [%d,%d) outside [1,%d)", k0, k1, p->nz - 1);\
         return finish(c, DISPATCH(c, pt_sweep<T>(c->stream, c->pt_variant, Pr_in, Pr_out, dPrdtau, divV, *p, \
                                                  k0, k1)), "pt_sweep");                                      \
+    }                                                                                                        \
+    extern "C" int ns3d_pt_sweep2_##S(ns3d_ctx *c, const T *Pr_in, T *Pr_out, const T *dPrdtau, T *dPrdtau_out,\
+                                      const T *divV, const ns3d_pt_params *p)                               \
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(Pr_in, Pr_out, dPrdtau, dPrdtau_out, divV);                                 \
+        if (dPrdtau == dPrdtau_out) return fail(NS3D_ERR_ARG, "ns3d_pt_sweep2: dPrdtau_in and dPrdtau_out must differ"); \
+        int rc = check_pt_params(p, "ns3d_pt_sweep2");                                                       \
+        if (rc) return rc;                                                                                   \
+        if (Pr_in == Pr_out) return fail(NS3D_ERR_ARG, "ns3d_pt_sweep2: Pr_in and Pr_out must differ");      \
+        if (p->z_lo_is_halo || p->z_hi_is_halo)                                                              \
+            return fail(NS3D_ERR_ARG, "ns3d_pt_sweep2: z-slab halos need the single-sweep schedule");        \
+        return finish(c, DISPATCH(c, pt_sweep2<T>(c->stream, c->pt2_variant < 0 ? 0 : c->pt2_variant, Pr_in, \
+                                                  Pr_out, dPrdtau, dPrdtau_out, divV, *p)), "pt_sweep2");    \
     }                                                                                                        \
     extern "C" int ns3d_residual_max_##S(ns3d_ctx *c, const T *Pr, const T *divV, const ns3d_pt_params *p,   \
                                          double *out_host)                                                   \

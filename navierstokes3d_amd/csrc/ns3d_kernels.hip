@@ -572,7 +572,8 @@ template <class T>
 struct SweepArgs {
     const T *__restrict__ Pin;
     T *__restrict__ Pout;
-    T *__restrict__ D;
+    T *__restrict__ D;         // dPrdτ (updated in place by the single sweep; OUTPUT of the two-iteration sweep)
+    const T *__restrict__ Din; // dPrdτ input of the two-iteration sweep (tiles overlap, so it cannot update in place)
     const T *__restrict__ RHS; // ∇V
     Geo<T> g;
     T rho_dt, dtau, one_m_damp;
@@ -1164,12 +1165,270 @@ static hipError_t launch_xcd_auto(hipStream_t s, SweepArgs<T> &a, int kz, int wx
     }
 }
 
+// =========================================================================================================
+// TWO PT iterations per pass over memory (temporal blocking)  —  k_pt_sweep2
+//
+// A single sweep is pinned to its 40 B/cell of HBM traffic.  Two consecutive Jacobi sweeps
+//     level 1:  d¹ = d⁰(1−damp) + dτ(∇²P⁰ − ρ/dt ∇V),  P¹ = P⁰ + dτ d¹,  faces of P¹ by the boundary rule
+//     level 2:  d² = d¹(1−damp) + dτ(∇²P¹ − ρ/dt ∇V),  P² = P¹ + dτ d²,  faces of P² by the boundary rule
+// need P⁰ on a radius-2 diamond but only write d² and P², so a workgroup that keeps level 1 on chip moves
+// ≈(24·overlap + 16) B per cell per TWO iterations.  Every value is computed with exactly the arithmetic of the
+// single sweep (same expression tree per cell), so the result is bit-identical to two k_pt_sweep launches.
+//
+// Workgroup = 512 threads = WX×WY waves; tile = TX×TY columns (TX = 64·WX in x, TY = CPT·WY in y, CPT consecutive
+// rows per thread), marched in z.  Per z-step s the workgroup produces level 1 of plane k1 and level 2 of plane
+// k2 = k1−1:
+//   registers (per column): P⁰[k1−1], P⁰[k1], P⁰[k1+1]; P¹[k2−1], P¹[k2]; d¹[k2], ∇V[k2]           (own-column z rings)
+//   LDS (double-buffered):  plane k1 of P⁰ incl. a one-cell halo ring (x/y neighbours for level 1),
+//                           plane k2 of P¹                              (x/y neighbours for level 2)
+//   one __syncthreads() per step; the loads of step s+1 (P⁰[k1+2], d⁰[k1+1], ∇V[k1+1], halo ring of plane k1+2) are
+//   issued between the two levels so that level 2's arithmetic hides their latency.
+// Level 1 is evaluated on every interior column of the tile (its x/y neighbours outside the tile come from the
+// halo ring, loaded straight from P⁰), level 2 on the columns whose four neighbours are in the tile or are domain
+// faces; tiles therefore overlap by two columns/rows, z-chunks by two planes.  Faces of P¹ are never materialised:
+// where a level-2 stencil touches a face the boundary rule is substituted (Neumann: the cell's own P¹; outlet:
+// outlet_val; gpu.jl x planes: hydrostatic value).  Faces of P² are stored by the producing thread as in the
+// single sweep.  z planes that are inter-slab halos are not supported here (the z-slab schedule uses single sweeps).
+// =========================================================================================================
+template <class T, int WX, int WY, int CPT, bool NT>
+__global__ __launch_bounds__(64 * WX * WY) void k_pt_sweep2(SweepArgs<T> a, int ntx, int nty)
+{
+    constexpr int TX = 64 * WX, TY = CPT * WY, PX = TX + 2;
+    __shared__ T L0[2][(TY + 2) * PX]; // P⁰ plane with halo ring: element (lx+1, lr+1)
+    __shared__ T L1[2][TY * TX];       // P¹ plane
+    const int nx = a.nx, ny = a.ny, nz = a.nz;
+    const Geo<T> &g = a.g;
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int q = nb >> 3, rem = nb & 7, xcd = b & 7, loc = b >> 3;
+    const int tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
+    const int tx_t = tile % ntx, ty_t = (tile / ntx) % nty, tz_t = tile / (ntx * nty);
+    const int ox = 1 + tx_t * (TX - 2), oy = 1 + ty_t * (TY - 2);
+    const int kb = a.k0 + tz_t * a.kz;
+    const int ke = min(kb + a.kz, a.k1);
+    if (kb >= ke) return; // workgroup-uniform, before any barrier
+
+    const int lx = threadIdx.x, wy = threadIdx.y;
+    const int tid = wy * TX + lx;
+    const int gi = ox + lx;
+    const int ci = min(gi, nx - 1), cii = min(gi, nx - 2);
+    const idx_t sz = (idx_t)nx * ny;
+    const idx_t dsz = (idx_t)(nx - 2) * (ny - 2);
+    const bool xlo_adj = (gi == 1), xhi_adj = (gi == nx - 2);
+    const bool x_s1 = (gi <= nx - 2);
+    const bool x_out = x_s1 && (lx >= 1 || xlo_adj) && (lx <= TX - 2 || xhi_adj);
+
+    int poff[CPT], roff[CPT], doff[CPT];
+    bool s1[CPT], outc[CPT], ylo_adj[CPT], yhi_adj[CPT];
+#pragma unroll
+    for (int r = 0; r < CPT; ++r) {
+        const int lr = wy * CPT + r, gj = oy + lr;
+        const int cj = min(gj, ny - 1), cjj = min(gj, ny - 2);
+        poff[r] = cj * nx + ci;
+        roff[r] = cjj * nx + cii;
+        doff[r] = (cjj - 1) * (nx - 2) + (cii - 1);
+        ylo_adj[r] = (gj == 1); yhi_adj[r] = (gj == ny - 2);
+        s1[r] = x_s1 && (gj <= ny - 2);
+        outc[r] = x_out && (gj <= ny - 2) && (lr >= 1 || ylo_adj[r]) && (lr <= TY - 2 || yhi_adj[r]);
+    }
+    // halo ring duties (P⁰ only): A = row below the tile, B = row above, C = the two columns beside it
+    const bool hasA = (wy == 0), hasB = (wy == WY - 1), hasC = (tid < 2 * TY);
+    const int offA = (oy - 1) * nx + ci;
+    const int offB = min(oy + TY, ny - 1) * nx + ci;
+    const int cside = tid / TY, crow = tid % TY;
+    const int offC = min(oy + crow, ny - 1) * nx + (cside ? min(ox + TX, nx - 1) : ox - 1);
+    const int ldsA = 0 * PX + (lx + 1), ldsB = (TY + 1) * PX + (lx + 1);
+    const int ldsC = (crow + 1) * PX + (cside ? TX + 1 : 0);
+
+    const T *__restrict__ P = a.Pin;
+    const T *__restrict__ RHS = a.RHS;
+    const T *__restrict__ Din = a.Din;
+    T *__restrict__ D = a.D;
+
+    T p0m[CPT], p0c[CPT], p0p[CPT];     // P⁰ planes k1-1, k1, k1+1
+    T p1m[CPT], p1c[CPT];               // P¹ planes k2-1, k2
+    T d1c[CPT], r1c[CPT];               // d¹[k2], ∇V[k2]
+    T d0[CPT], r0[CPT];                 // d⁰[k1], ∇V[k1]
+    T hA = (T)0, hB = (T)0, hC = (T)0;  // halo ring values of plane k1+1 (to be published at the end of the step)
+
+    // ---- prologue: planes kb-2 (clamped), kb-1, kb of P⁰; streams of plane kb-1; publish plane kb-1 ----
+    {
+        const int k1 = kb - 1;
+        const T *__restrict__ Pm = P + (idx_t)max(k1 - 1, 0) * sz;
+        const T *__restrict__ Pc = P + (idx_t)k1 * sz;
+        const T *__restrict__ Pp = P + (idx_t)(k1 + 1) * sz;
+        const int ka = min(max(k1, 1), nz - 2);
+#pragma unroll
+        for (int r = 0; r < CPT; ++r) {
+            p0m[r] = Pm[poff[r]]; p0c[r] = Pc[poff[r]]; p0p[r] = Pp[poff[r]];
+            d0[r] = ld_stream<T, NT>(Din + (idx_t)(ka - 1) * dsz + doff[r]);
+            r0[r] = ld_stream<T, NT>(RHS + (idx_t)ka * sz + roff[r]);
+            p1m[r] = p1c[r] = d1c[r] = r1c[r] = (T)0;
+            L0[0][(wy * CPT + r + 1) * PX + lx + 1] = p0c[r];
+        }
+        if (hasA) L0[0][ldsA] = Pc[offA];
+        if (hasB) L0[0][ldsB] = Pc[offB];
+        if (hasC) L0[0][ldsC] = Pc[offC];
+        if (hasA) hA = Pp[offA];
+        if (hasB) hB = Pp[offB];
+        if (hasC) hC = Pp[offC];
+    }
+    __syncthreads();
+
+    const int nsteps = (ke - kb) + 2;
+    int cur = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        const int k1 = kb - 1 + s, k2 = k1 - 1;
+        const T *__restrict__ l0 = L0[cur];
+        const T *__restrict__ l1 = L1[cur];
+        // ---------------- level 1 at plane k1 (interior planes only) ----------------
+        const bool k1_valid = (k1 >= 1) && (k1 <= nz - 2);
+        T p1p[CPT], d1n[CPT];
+#pragma unroll
+        for (int r = 0; r < CPT; ++r) {
+            const int lr = wy * CPT + r;
+            const T c = p0c[r];
+            const T w = l0[(lr + 1) * PX + lx], e = l0[(lr + 1) * PX + lx + 2];
+            const T sv = r == 0 ? l0[lr * PX + lx + 1] : p0c[r - 1 < 0 ? 0 : r - 1];
+            const T nv = r == CPT - 1 ? l0[(lr + 2) * PX + lx + 1] : p0c[r + 1 > CPT - 1 ? CPT - 1 : r + 1];
+            const T res = poisson_rhs<T>(c, w, e, sv, nv, p0m[r], p0p[r], r0[r], a.rho_dt, g);
+            d1n[r] = d0[r] * a.one_m_damp + a.dtau * res;
+            p1p[r] = c + a.dtau * d1n[r];
+        }
+        // ---------------- issue the loads of the next step (hidden behind level 2) ----------------
+        T p0n[CPT], hAn = (T)0, hBn = (T)0, hCn = (T)0;
+        {
+            const int kp = min(k1 + 2, nz - 1);
+            const int ka = min(max(k1 + 1, 1), nz - 2);
+            const T *__restrict__ Pn = P + (idx_t)kp * sz;
+#pragma unroll
+            for (int r = 0; r < CPT; ++r) {
+                p0n[r] = Pn[poff[r]];
+                r1c[r] = r1c[r]; // (kept: ∇V[k2] is last step's r0)
+            }
+            if (hasA) hAn = Pn[offA];
+            if (hasB) hBn = Pn[offB];
+            if (hasC) hCn = Pn[offC];
+            // d⁰/∇V of plane k1+1 overwrite d0/r0 only after level 1 consumed them (below, after level 2's use of r1c)
+            (void)ka;
+        }
+        // ---------------- level 2 at plane k2 ----------------
+        if (s >= 2) {
+            const bool zlo = (k2 == 1), zhi = (k2 == nz - 2);
+            const bool plain_k = !(zlo || zhi);
+            T *__restrict__ Dk = D + (idx_t)(k2 - 1) * dsz;
+#pragma unroll
+            for (int r = 0; r < CPT; ++r) {
+                const int lr = wy * CPT + r;
+                const T c = p1c[r];
+                T w = l1[lr * TX + max(lx - 1, 0)], e = l1[lr * TX + min(lx + 1, TX - 1)];
+                T sv = r == 0 ? l1[max(lr - 1, 0) * TX + lx] : p1c[r - 1 < 0 ? 0 : r - 1];
+                T nv = r == CPT - 1 ? l1[min(lr + 1, TY - 1) * TX + lx] : p1c[r + 1 > CPT - 1 ? CPT - 1 : r + 1];
+                // boundary rule substituted where the stencil touches a face of P¹
+                if (xlo_adj) w = xface_val<T>(a, false, c, k2);
+                if (xhi_adj) e = xface_val<T>(a, true, c, k2);
+                if (ylo_adj[r]) sv = c;
+                if (yhi_adj[r]) nv = c;
+                const T bv = zlo ? c : p1m[r];
+                const T tv = zhi ? c : p1p[r];
+                const T res = poisson_rhs<T>(c, w, e, sv, nv, bv, tv, r1c[r], a.rho_dt, g);
+                const T dn = d1c[r] * a.one_m_damp + a.dtau * res;
+                const T pn = c + a.dtau * dn;
+                if (outc[r]) {
+                    st_stream<T, NT>(Dk + doff[r], dn);
+                    const int gj = oy + lr;
+                    if (plain_k && !(xlo_adj | xhi_adj | ylo_adj[r] | yhi_adj[r]))
+                        st_stream<T, NT>(a.Pout + (idx_t)k2 * sz + gj * nx + gi, pn);
+                    else
+                        store_with_bc<T, NT>(a, gi, gj, k2, pn);
+                }
+            }
+        }
+        // ---------------- streams of plane k1+1 for the next level 1 ----------------
+        {
+            const int ka = min(max(k1 + 1, 1), nz - 2);
+#pragma unroll
+            for (int r = 0; r < CPT; ++r) {
+                r1c[r] = r0[r];
+                d0[r] = ld_stream<T, NT>(Din + (idx_t)(ka - 1) * dsz + doff[r]);
+                r0[r] = ld_stream<T, NT>(RHS + (idx_t)ka * sz + roff[r]);
+            }
+        }
+        // ---------------- publish plane k1+1 of P⁰ and plane k1 of P¹ into the other LDS buffers ----------------
+        T *__restrict__ n0 = L0[cur ^ 1];
+        T *__restrict__ n1 = L1[cur ^ 1];
+#pragma unroll
+        for (int r = 0; r < CPT; ++r) {
+            const int lr = wy * CPT + r;
+            n0[(lr + 1) * PX + lx + 1] = p0p[r];
+            n1[lr * TX + lx] = p1p[r];
+        }
+        if (hasA) n0[ldsA] = hA;
+        if (hasB) n0[ldsB] = hB;
+        if (hasC) n0[ldsC] = hC;
+        // ---------------- rotate the z rings ----------------
+#pragma unroll
+        for (int r = 0; r < CPT; ++r) {
+            p0m[r] = p0c[r]; p0c[r] = p0p[r]; p0p[r] = p0n[r];
+            p1m[r] = p1c[r]; p1c[r] = p1p[r];
+            d1c[r] = d1n[r];
+        }
+        hA = hAn; hB = hBn; hC = hCn;
+        (void)k1_valid; (void)s1;
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+template <class T, int WX, int WY, int CPT, bool NT>
+static hipError_t launch_sweep2(hipStream_t s, SweepArgs<T> &a, int kz)
+{
+    constexpr int TX = 64 * WX, TY = CPT * WY;
+    a.kz = kz;
+    const int nk = a.k1 - a.k0;
+    const int ntx = max(1, (a.nx - 4 + (TX - 2) - 1) / (TX - 2)), nty = max(1, (a.ny - 4 + (TY - 2) - 1) / (TY - 2));
+    const int ntz = (nk + kz - 1) / kz;
+    hipLaunchKernelGGL((k_pt_sweep2<T, WX, WY, CPT, NT>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX, WY, 1), 0, s, a,
+                       ntx, nty);
+    return hipGetLastError();
+}
+
+// Two fused PT iterations Pin → Pout over interior planes [k0,k1) (k0 = 1, k1 = nz-1: the whole slab).
+template <class T>
+hipError_t pt_sweep2(hipStream_t s, int variant, const T *Pin, T *Pout, const T *Din, T *Dout, const T *RHS,
+                     const ns3d_pt_params &p)
+{
+    SweepArgs<T> a;
+    a.Pin = Pin; a.Pout = Pout; a.D = Dout; a.Din = Din; a.RHS = RHS;
+    a.g = make_geo<T>(p.dx, p.dy, p.dz);
+    a.rho_dt = (T)p.rho / (T)p.dt; a.dtau = (T)p.dtau; a.one_m_damp = (T)1.0 - (T)p.damp;
+    a.outlet_val = (T)p.outlet_val; a.rho_g = (T)p.rho * (T)p.g;
+    a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
+    a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = 0; a.zhi_halo = 0;
+    a.k0 = 1; a.k1 = p.nz - 1; a.kz = 1;
+    const int shape = variant / 100;
+    int kz = variant % 100;
+    if (kz <= 0) kz = 32;
+    const int nxi = p.nx - 2;
+    switch (shape) {
+    case 1: return launch_sweep2<T, 4, 2, 4, true>(s, a, kz);   // 256 x 8
+    case 2: return launch_sweep2<T, 2, 4, 4, true>(s, a, kz);   // 128 x 16
+    case 3: return launch_sweep2<T, 1, 8, 4, true>(s, a, kz);   //  64 x 32
+    case 4: return launch_sweep2<T, 4, 2, 4, false>(s, a, kz);  // 256 x 8, plain loads/stores
+    case 5: return launch_sweep2<T, 4, 1, 4, true>(s, a, kz);   // 256 x 4 (256 threads)
+    case 6: return launch_sweep2<T, 2, 2, 4, true>(s, a, kz);   // 128 x 8 (256 threads)
+    default: // shape by row length: the widest tile whose overlap-2 tiling wastes the fewest lanes
+        if (nxi > 128) return launch_sweep2<T, 4, 2, 4, true>(s, a, kz);
+        if (nxi > 64) return launch_sweep2<T, 2, 4, 4, true>(s, a, kz);
+        return launch_sweep2<T, 1, 8, 4, true>(s, a, kz);
+    }
+}
+
 template <class T>
 hipError_t pt_sweep(hipStream_t s, int variant, const T *Pin, T *Pout, T *D, const T *RHS, const ns3d_pt_params &p,
                     int k0, int k1)
 {
     SweepArgs<T> a;
-    a.Pin = Pin; a.Pout = Pout; a.D = D; a.RHS = RHS;
+    a.Pin = Pin; a.Pout = Pout; a.D = D; a.Din = D; a.RHS = RHS;
     a.g = make_geo<T>(p.dx, p.dy, p.dz);
     a.rho_dt = (T)p.rho / (T)p.dt; a.dtau = (T)p.dtau; a.one_m_damp = (T)1.0 - (T)p.damp;
     a.outlet_val = (T)p.outlet_val; a.rho_g = (T)p.rho * (T)p.g;
@@ -1284,6 +1543,8 @@ hipError_t residual_max_key(hipStream_t s, const T *Pr, const T *divV, const ns3
                                   const T *, double, double, double, double, int, int, int, int);            \
     template hipError_t pt_sweep<T>(hipStream_t, int, const T *, T *, T *, const T *, const ns3d_pt_params &,\
                                     int, int);                                                               \
+    template hipError_t pt_sweep2<T>(hipStream_t, int, const T *, T *, const T *, T *, const T *,            \
+                                     const ns3d_pt_params &);                                                \
     template hipError_t residual_max_key<T>(hipStream_t, const T *, const T *, const ns3d_pt_params &,       \
                                             unsigned long long *);
 INST(double)

@@ -87,6 +87,10 @@ class Context:
     def set_pt_variant(self, v):
         L.check(self.lib.ns3d_set_pt_variant(self.handle, int(v)))
 
+    def set_pt2_variant(self, v):
+        """Temporal blocking (two PT iterations per pass) in pt_iterate / pt_solve: v < 0 off, 0 default tile."""
+        L.check(self.lib.ns3d_set_pt2_variant(self.handle, int(v)))
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.ns3d_destroy(self.handle)
@@ -322,6 +326,16 @@ def pt_sweep(Pr_in, Pr_out, dPrdtau, divV, p, k0, k1, ctx=None):
     _ctx(ctx, Pr_in).call("pt_sweep", Pr_in, _chk(Pr_in, None, "Pr_in"), _chk(Pr_out, (nx, ny, nz), "Pr_out"),
                           _chk(dPrdtau, (nx - 2, ny - 2, nz - 2), "dPrdtau"), _chk(divV, (nx, ny, nz), "divV"),
                           C.byref(p), int(k0), int(k1))
+
+
+def pt_sweep2(Pr_in, Pr_out, dPrdtau_in, dPrdtau_out, divV, p, ctx=None):
+    """TWO fused PT iterations (Pr_in, dPrdtau_in) → (Pr_out, dPrdtau_out) in one pass over memory (same result
+    as two pt_sweep calls); all four buffers distinct."""
+    nx, ny, nz = Pr_in.shape
+    _ctx(ctx, Pr_in).call("pt_sweep2", Pr_in, _chk(Pr_in, None, "Pr_in"), _chk(Pr_out, (nx, ny, nz), "Pr_out"),
+                          _chk(dPrdtau_in, (nx - 2, ny - 2, nz - 2), "dPrdtau_in"),
+                          _chk(dPrdtau_out, (nx - 2, ny - 2, nz - 2), "dPrdtau_out"), _chk(divV, (nx, ny, nz), "divV"),
+                          C.byref(p))
 
 
 def residual_max(Pr, divV, p, ctx=None):

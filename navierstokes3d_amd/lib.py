@@ -54,11 +54,13 @@ SIGNATURES = {
     "set_bc_Vel": [_P] * 3 + [_I, _I, _D] + [_I] * 3,
     "pt_iterate": [_P] * 3 + [C.POINTER(PtParams), _I],
     "pt_sweep": [_P] * 4 + [C.POINTER(PtParams), _I, _I],
+    "pt_sweep2": [_P] * 5 + [C.POINTER(PtParams)],
     "residual_max": [_P] * 2 + [C.POINTER(PtParams), C.POINTER(_D)],
     "pt_solve": [_P] * 3 + [C.POINTER(PtParams), _D, _I, _I, _D, _D, C.POINTER(_I), C.POINTER(_D), _I, C.POINTER(_I)],
 }
 CONTEXT_SYMBOLS = ["ns3d_version", "ns3d_last_error", "ns3d_create", "ns3d_destroy", "ns3d_flags",
-                   "ns3d_set_stream", "ns3d_use_own_stream", "ns3d_get_stream", "ns3d_sync", "ns3d_set_pt_variant"]
+                   "ns3d_set_stream", "ns3d_use_own_stream", "ns3d_get_stream", "ns3d_sync", "ns3d_set_pt_variant",
+                   "ns3d_set_pt2_variant"]
 
 
 def exported_symbols():
@@ -95,6 +97,7 @@ def load():
     lib.ns3d_get_stream.argtypes = [_P]
     lib.ns3d_sync.argtypes = [_P]
     lib.ns3d_set_pt_variant.argtypes = [_P, _I]
+    lib.ns3d_set_pt2_variant.argtypes = [_P, _I]
     for name, args in SIGNATURES.items():
         for suf in ("f64", "f32"):
             fn = getattr(lib, "ns3d_%s_%s" % (name, suf))

@@ -155,3 +155,66 @@ def test_pt_f32(hip, oracle):
     torch.cuda.synchronize()
     assert np.array_equal(hip.to_numpy(dPr), Pr) and np.array_equal(hip.to_numpy(dd), d)
     ctx.close()
+
+
+# ---- temporal blocking: two PT iterations per pass over memory -------------------------------------------------
+SHAPES2 = [0, 100, 200, 300, 400, 500, 600, 103, 207, 101]
+GRIDS2 = GRIDS + [(260, 19, 9), (131, 40, 6), (66, 70, 5)]
+
+
+@pytest.mark.parametrize("bc", [(0, True, 0.0), (0, False, 0.0), (0, True, 0.75), (1, False, 0.0)])
+@pytest.mark.parametrize("grid", GRIDS2)
+def test_pt_sweep2_equals_two_sweeps_bitexact(hip, oracle, grid, bc):
+    """One k_pt_sweep2 launch == two reference iterations, bit for bit, for every tile shape / z-chunk, both boundary
+    sets, tiles larger and smaller than the grid, overlapping tiles in x, y and z."""
+    import torch
+    nx, ny, nz = grid
+    g = geometry(*grid)
+    bc_kind, owns, val = bc
+    Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 71)
+    Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
+    _oracle_iters(oracle, Pr, d, rhs, g, 2, bc_kind, owns, val)
+    ctx = hip.Context(0, "strict")
+    for shape in SHAPES2:
+        ctx.set_pt2_variant(shape)
+        dPr, dout, dd, drhs = hip.from_numpy(Pr0), hip.from_numpy(np.full_like(Pr0, 555.0)), hip.from_numpy(d0), hip.from_numpy(rhs)
+        ddout = hip.from_numpy(np.full_like(d0, 444.0))
+        hip.pt_sweep2(dPr, dout, dd, ddout, drhs, _params(hip, dPr, g, bc_kind, owns, val), ctx=ctx)
+        torch.cuda.synchronize()
+        assert np.array_equal(hip.to_numpy(ddout), d), "dPrdτ differs: shape %d" % shape
+        assert np.array_equal(hip.to_numpy(dout), Pr), "Pr differs: shape %d" % shape
+        assert np.array_equal(hip.to_numpy(dPr), Pr0) and np.array_equal(hip.to_numpy(drhs), rhs)
+        assert np.array_equal(hip.to_numpy(dd), d0)
+    ctx.close()
+
+
+@pytest.mark.parametrize("grid", [(24, 15, 15), (70, 6, 7), (63, 38, 38)])
+def test_pt_iterate_and_solve_with_temporal_blocking(hip, oracle, grid):
+    """pt_iterate / pt_solve with two-iterations-per-pass enabled: odd and even counts, residual checks on odd nchk,
+    early exits — identical counts, err history and fields."""
+    import torch
+    nx, ny, nz = grid
+    g = geometry(*grid)
+    Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 73)
+    rhs *= 1e-3
+    ctx = hip.Context(0, "strict")
+    ctx.set_pt2_variant(0)
+    for n in (1, 2, 3, 8, 11):
+        Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
+        _oracle_iters(oracle, Pr, d, rhs, g, n, 0, True, 0.0)
+        dPr, dd = hip.from_numpy(Pr0), hip.from_numpy(d0)
+        hip.pt_iterate(dPr, dd, hip.from_numpy(rhs), _params(hip, dPr, g, 0, True, 0.0), n, ctx=ctx)
+        torch.cuda.synchronize()
+        assert np.array_equal(hip.to_numpy(dPr), Pr) and np.array_equal(hip.to_numpy(dd), d), n
+    Rp = np.zeros((nx - 2, ny - 2, nz - 2), order="F")
+    for eps, niter, nchk in ((-1.0, 57, 14), (5e4, 400, 13), (1e-30, 45, 7), (-1.0, 30, 1)):
+        Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
+        it_ref, errs_ref = oracle.pt_solve(Pr, d, rhs, Rp, g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"],
+                                           g["dz"], 0, True, 0.0, g["g"], eps, niter, nchk, 0.36, 1000.0)
+        dPr, dd = hip.from_numpy(Pr0), hip.from_numpy(d0)
+        it, errs = hip.pt_solve(dPr, dd, hip.from_numpy(rhs), _params(hip, dPr, g, 0, True, 0.0), eps, niter, nchk,
+                                0.36, 1000.0, ctx=ctx)
+        torch.cuda.synchronize()
+        assert it == it_ref and errs == errs_ref
+        assert np.array_equal(hip.to_numpy(dPr), Pr) and np.array_equal(hip.to_numpy(dd), d)
+    ctx.close()

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--variants", default="0,100,200,300,400,500,600")
     ap.add_argument("--modes", default="strict,fast")
+    ap.add_argument("--variants2", default="", help="temporal-blocking (two iterations per launch) shapes to time")
     ap.add_argument("--dtype", default="f64")
     a = ap.parse_args()
     p = cavity_params(a.n, a.nz)
@@ -31,6 +32,7 @@ def main():
     isz = 8 if a.dtype == "f64" else 4
     Pr, Pb = K.zeros((nx, ny, nz), tdt), K.zeros((nx, ny, nz), tdt)
     D, rhs = K.zeros((nx - 2, ny - 2, nz - 2), tdt), K.zeros((nx, ny, nz), tdt)
+    D2 = K.zeros((nx - 2, ny - 2, nz - 2), tdt)
     rhs.permute(2, 1, 0).uniform_(-1e-3, 1e-3)
     abytes = isz * (nx * ny * nz + 4 * (nx - 2) * (ny - 2) * (nz - 2))
     ctxs = {m: K.Context(0, m, async_=True) for m in a.modes.split(",")}
@@ -50,12 +52,26 @@ def main():
                 torch.cuda.synchronize()
                 if rnd > 0:
                     res.setdefault((m, v), []).append(e0.elapsed_time(e1) / (2 * (a.iters // 2)))
+    variants2 = [int(v) for v in a.variants2.split(",") if v != ""]
+    for rnd in range(a.rounds + 1):
+        for m, ctx in ctxs.items():
+            for v in variants2:
+                ctx.set_pt2_variant(v)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.iters // 4):
+                    K.pt_sweep2(Pr, Pb, D, D2, rhs, pt, ctx=ctx)
+                    K.pt_sweep2(Pb, Pr, D2, D, rhs, pt, ctx=ctx)
+                e1.record()
+                torch.cuda.synchronize()
+                if rnd > 0:   # per ITERATION (a launch does two)
+                    res.setdefault((m + "-x2", v), []).append(e0.elapsed_time(e1) / (4 * (a.iters // 4)))
     print("grid %dx%dx%d %s  algorithmic bytes/launch %.1f MB" % (nx, ny, nz, a.dtype, abytes / 1e6))
-    print("%-8s %-8s %10s %10s %12s %8s" % ("mode", "variant", "min ms", "med ms", "Mcell-it/s", "%8TB/s"))
+    print("%-10s %-8s %10s %10s %12s %8s   (ms per PT iteration)" % ("mode", "variant", "min ms", "med ms", "Mcell-it/s", "%8TB/s"))
     for (m, v), ts in sorted(res.items()):
         ts = sorted(ts)
         tmin, tmed = ts[0], ts[len(ts) // 2]
-        print("%-8s %-8d %10.4f %10.4f %12.0f %8.1f" % (m, v, tmin, tmed, nx * ny * nz / tmin / 1e3,
+        print("%-10s %-8d %10.4f %10.4f %12.0f %8.1f" % (m, v, tmin, tmed, nx * ny * nz / tmin / 1e3,
                                                        abytes / (tmin * 1e-3) / 8e12 * 100))
 
 
