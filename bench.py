@@ -91,10 +91,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+    backend = os.environ.get("NS3D_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N>1 path on a single-GPU box
+    local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from navierstokes3d_amd import build
     if rank == 0:
@@ -125,6 +130,12 @@ def main():
                      grid.z_lo_is_halo(), grid.z_hi_is_halo())
 
     use2 = (world == 1) and not a.no_temporal_blocking
+    slab = None
+    if world > 1:
+        from navierstokes3d_amd.slab import SlabPTSolver
+        slab = SlabPTSolver(ctx, grid, Pr, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, L.NS3D_BC_MULTI, False, 0.0, 0.0)
+        slab.set_temporal_blocking(not a.no_temporal_blocking)
+        slab.load(Pr, D, rhs)
     if a.variant2 is not None:
         ctx.set_pt2_variant(a.variant2)
     D2 = K.zeros((nx - 2, ny - 2, nz - 2), tdt, dev) if use2 else None
@@ -143,13 +154,7 @@ def main():
                 K.pt_sweep(Pr, Pb, D, rhs, pt, 1, nz - 1, ctx=ctx)
                 Pr, Pb = Pb, Pr
             return
-        for _ in range(n):
-            K.pt_sweep(Pr, Pb, D, rhs, pt, 1, 2, ctx=ctx)
-            K.pt_sweep(Pr, Pb, D, rhs, pt, nz - 2, nz - 1, ctx=ctx)
-            work = grid.start_halo(Pb)
-            K.pt_sweep(Pr, Pb, D, rhs, pt, 2, nz - 2, ctx=ctx)
-            grid.finish_halo(work)
-            Pr, Pb = Pb, Pr
+        slab.iterate(n)      # seam planes first, 2-plane ghost exchange behind the interior sweep (slab.py)
 
     run(a.warmup)
     if world > 1:
@@ -166,17 +171,17 @@ def main():
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, dev_ms = t[0].item(), t[1].item()
-    err = grid.max_g(K.residual_max(Pr, rhs, pt, ctx=ctx)) * (p.ly * p.ly) / p.psc
+    err = (slab.residual() if slab is not None else K.residual_max(Pr, rhs, pt, ctx=ctx)) * (p.ly * p.ly) / p.psc
     finite = bool(np.isfinite(err))
 
     if rank == 0:
         cells_g = nx * ny * grid.nz_g()
         itemsize = 8 if a.dtype == "f64" else 4
         # the dominant kernel: k_pt_sweep2 advances TWO iterations per launch (k_pt_sweep: one)
-        its_per_launch = 2 if use2 and a.steps >= 2 else 1
+        its_per_launch = 2 if (not a.no_temporal_blocking) and a.steps >= 2 else 1
         launches = a.steps // 2 + a.steps % 2 if its_per_launch == 2 else a.steps
         kern_ms = dev_ms / launches                  # HIP events around the timed launches on the launch stream
         abytes = its_per_launch * algorithmic_bytes(nx, ny, nz, itemsize)
@@ -205,7 +210,8 @@ def main():
             "hbm_gbps_algorithmic": achieved * world,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "k_pt_sweep2" if its_per_launch == 2 else "k_pt_sweep", "kernel_ms": kern_ms,
+                         "kernel": "k_pt_sweep2" if its_per_launch == 2 else "k_pt_sweep",
+                         "kernel_ms": kern_ms if world == 1 else None,
                          "pt_iterations_per_launch": its_per_launch, "algorithmic_bytes_per_launch": abytes},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -165,9 +165,10 @@ typedef struct ns3d_pt_params {
                           const ns3d_pt_params *p, int k0, int k1);                                          \
     /* TWO fused PT iterations (Pr_in,dPrdtau_in) → (Pr_out,dPrdtau_out), all four buffers distinct (tiles       \
      * overlap, so nothing is updated in place); results identical to two ns3d_pt_sweep calls with a buffer     \
-     * swap.  Not available on z-slab ranks (z_*_is_halo must be 0). */                                          \
+     * swap, for the output planes k0 ≤ k < k1 (reads planes k0-2 … k1+1 of Pr_in).  z_*_is_halo must be 0:   \
+     * z-slab ranks run it on buffers extended by a second ghost plane per seam. */              \
     int ns3d_pt_sweep2_##S(ns3d_ctx *, const T *Pr_in, T *Pr_out, const T *dPrdtau_in, T *dPrdtau_out,       \
-                           const T *divV, const ns3d_pt_params *p);                                          \
+                           const T *divV, const ns3d_pt_params *p, int k0, int k1);                          \
     /* max|∇²Pr − ρ/dt ∇V| over the interior = maximum(abs.(Rp)) after compute_res!, without writing Rp.   \
      * NaN-propagating.  (multi.jl:465-466) */                                                               \
     int ns3d_residual_max_##S(ns3d_ctx *, const T *Pr, const T *divV, const ns3d_pt_params *p,               \

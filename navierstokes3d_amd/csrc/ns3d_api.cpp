@@ -252,7 +252,7 @@ static int pt_iterate_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_p
     for (int it = 0; it < n_iters;) {
         hipError_t e;
         if (two && it + 2 <= n_iters) {
-            e = DISPATCH(c, pt_sweep2<T>(c->stream, c->pt2_variant, src, dst, dsrc, ddst, divV, *p));
+            e = DISPATCH(c, pt_sweep2<T>(c->stream, c->pt2_variant, src, dst, dsrc, ddst, divV, *p, 1, p->nz - 1));
             T *t = dsrc; dsrc = ddst; ddst = t;
             it += 2;
         } else {
@@ -289,7 +289,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
         // two iterations per pass unless that would step over a residual check or the iteration budget
         const int to_check = nchk > 0 ? nchk - iter % nchk : niter - iter;
         if (two && to_check >= 2 && iter + 2 <= niter) {
-            e = DISPATCH(c, pt_sweep2<T>(c->stream, c->pt2_variant, src, dst, dsrc, ddst, divV, *p));
+            e = DISPATCH(c, pt_sweep2<T>(c->stream, c->pt2_variant, src, dst, dsrc, ddst, divV, *p, 1, p->nz - 1));
             T *t = dsrc; dsrc = ddst; ddst = t;
             iter += 2;
         } else {
@@ -499,7 +499,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
                                                  k0, k1)), "pt_sweep");                                      \
     }                                                                                                        \
     extern "C" int ns3d_pt_sweep2_##S(ns3d_ctx *c, const T *Pr_in, T *Pr_out, const T *dPrdtau, T *dPrdtau_out,\
-                                      const T *divV, const ns3d_pt_params *p)                               \
+                                      const T *divV, const ns3d_pt_params *p, int k0, int k1)               \
     {                                                                                                        \
         CHECK_CTX(c); CHECK_PTRS(Pr_in, Pr_out, dPrdtau, dPrdtau_out, divV);                                 \
         if (dPrdtau == dPrdtau_out) return fail(NS3D_ERR_ARG, "ns3d_pt_sweep2: dPrdtau_in and dPrdtau_out must differ"); \
@@ -507,9 +507,12 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
         if (rc) return rc;                                                                                   \
         if (Pr_in == Pr_out) return fail(NS3D_ERR_ARG, "ns3d_pt_sweep2: Pr_in and Pr_out must differ");      \
         if (p->z_lo_is_halo || p->z_hi_is_halo)                                                              \
-            return fail(NS3D_ERR_ARG, "ns3d_pt_sweep2: z-slab halos need the single-sweep schedule");        \
+            return fail(NS3D_ERR_ARG, "ns3d_pt_sweep2: z-slab ranks pass ghost-extended buffers, not halo flags"); \
+        if (k0 < 1 || k1 > p->nz - 1 || k0 > k1)                                                             \
+            return fail(NS3D_ERR_ARG, "ns3d_pt_sweep2: plane range [%d,%d) outside [1,%d)", k0, k1, p->nz - 1); \
         return finish(c, DISPATCH(c, pt_sweep2<T>(c->stream, c->pt2_variant < 0 ? 0 : c->pt2_variant, Pr_in, \
-                                                  Pr_out, dPrdtau, dPrdtau_out, divV, *p)), "pt_sweep2");    \
+                                                  Pr_out, dPrdtau, dPrdtau_out, divV, *p, k0, k1)),          \
+                      "pt_sweep2");                                                                          \
     }                                                                                                        \
     extern "C" int ns3d_residual_max_##S(ns3d_ctx *c, const T *Pr, const T *divV, const ns3d_pt_params *p,   \
                                          double *out_host)                                                   \

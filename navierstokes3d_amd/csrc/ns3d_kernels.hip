@@ -1392,10 +1392,10 @@ static hipError_t launch_sweep2(hipStream_t s, SweepArgs<T> &a, int kz)
     return hipGetLastError();
 }
 
-// Two fused PT iterations Pin → Pout over interior planes [k0,k1) (k0 = 1, k1 = nz-1: the whole slab).
+// Two fused PT iterations (Pin,Din) → (Pout,Dout) for the output planes [k0,k1) (k0 = 1, k1 = nz-1: the whole slab).
 template <class T>
 hipError_t pt_sweep2(hipStream_t s, int variant, const T *Pin, T *Pout, const T *Din, T *Dout, const T *RHS,
-                     const ns3d_pt_params &p)
+                     const ns3d_pt_params &p, int k0, int k1)
 {
     SweepArgs<T> a;
     a.Pin = Pin; a.Pout = Pout; a.D = Dout; a.Din = Din; a.RHS = RHS;
@@ -1404,7 +1404,8 @@ hipError_t pt_sweep2(hipStream_t s, int variant, const T *Pin, T *Pout, const T 
     a.outlet_val = (T)p.outlet_val; a.rho_g = (T)p.rho * (T)p.g;
     a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
     a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = 0; a.zhi_halo = 0;
-    a.k0 = 1; a.k1 = p.nz - 1; a.kz = 1;
+    a.k0 = k0; a.k1 = k1; a.kz = 1;
+    if (k1 <= k0) return hipSuccess;
     const int shape = variant / 100;
     int kz = variant % 100;
     if (kz <= 0) kz = 32;
@@ -1544,7 +1545,7 @@ hipError_t residual_max_key(hipStream_t s, const T *Pr, const T *divV, const ns3
     template hipError_t pt_sweep<T>(hipStream_t, int, const T *, T *, T *, const T *, const ns3d_pt_params &,\
                                     int, int);                                                               \
     template hipError_t pt_sweep2<T>(hipStream_t, int, const T *, T *, const T *, T *, const T *,            \
-                                     const ns3d_pt_params &);                                                \
+                                     const ns3d_pt_params &, int, int);                                      \
     template hipError_t residual_max_key<T>(hipStream_t, const T *, const T *, const ns3d_pt_params &,       \
                                             unsigned long long *);
 INST(double)

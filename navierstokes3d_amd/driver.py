@@ -21,6 +21,7 @@ import torch
 from . import kernels as K
 from . import lib as L
 from .halo import ZSlabGrid
+from .slab import SlabPTSolver
 from .params import gpu_params, multi_params
 
 
@@ -117,7 +118,7 @@ def pt_loop_fused_slab(ctx, grid, f, p, pt, niter, do_print=False, scratch=None)
 
 
 def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=10, *, mode="strict", fused=True,
-                       dtype=torch.float64, faithful=True, grid=None, device=None, niter_cap=None,
+                       temporal=True, dtype=torch.float64, faithful=True, grid=None, device=None, niter_cap=None,
                        return_info=False):
     """run_navierstokes3D (multi.jl:287-536).  nx is the LOCAL streamwise size (ny = nz = ceil(0.6 nx) local);
     with an initialised torch.distributed process group the domain is decomposed into one z-slab per rank."""
@@ -152,7 +153,13 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
     iframe += 1
     pt = K.pt_params(f.Pr, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, L.NS3D_BC_MULTI, p.owns_outlet, 0.0,
                      p.g, grid.z_lo_is_halo(), grid.z_hi_is_halo())
-    scratch = K.clone(f.Pr) if (fused and P > 1) else None
+    if not temporal:
+        ctx.set_pt2_variant(-1)
+    slab = None
+    if fused and P > 1 and temporal and nz >= 4:
+        slab = SlabPTSolver(ctx, grid, f.Pr, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, L.NS3D_BC_MULTI,
+                            p.owns_outlet, 0.0, p.g)
+    scratch = K.clone(f.Pr) if (fused and P > 1 and slab is None) else None
     info = SimpleNamespace(iters=[], errs=[], params=p)
     nsave = 10                                                                                # :332
     for it in range(1, nt + 1):                                                               # :446
@@ -173,6 +180,11 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
             if me == 0 and do_print:
                 for q, e in enumerate(errs):
                     print("  #iter = %d, err = %1.3e" % ((q + 1) * p.nchk, e))
+        elif slab is not None:                                  # z-slab rank, two iterations per pass, deep ghosts
+            slab.load(f.Pr, f.dPrdtau, f.divV)
+            show = (lambda i, e: print("  #iter = %d, err = %1.3e" % (i, e))) if (me == 0 and do_print) else None
+            done, errs = slab.solve(p.eps, niter, p.nchk, p.ly * p.ly, p.psc, show)
+            slab.store(f.Pr, f.dPrdtau)
         else:
             done, errs = pt_loop_fused_slab(ctx, grid, f, p, pt, niter, do_print, scratch)
         info.iters.append(done); info.errs.append(errs)

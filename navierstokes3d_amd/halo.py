@@ -116,6 +116,41 @@ class ZSlabGrid:
                 unpack.append((self.plane(A, r_k), rbuf, sbuf))
         return ("host", reqs, unpack)
 
+    def planes(self, A, k, n):
+        """n consecutive xy-planes starting at plane k: one contiguous (n,sy,sx) row-major block."""
+        return A.permute(2, 1, 0)[k:k + n]
+
+    def start_exchange(self, to_lower=(), from_lower=(), to_upper=(), from_upper=()):
+        """Post a neighbour exchange of arbitrary contiguous blocks (used by the two-plane-deep ghost exchange of the
+        temporally blocked PT loop).  The i-th block sent to a neighbour lands in that neighbour's i-th receive block
+        from this side.  Returns a handle for finish_halo."""
+        if self.P == 1:
+            return None
+        sides = []
+        if self.lower is not None:
+            sides.append((self.lower, list(to_lower), list(from_lower), 0))
+        if self.upper is not None:
+            sides.append((self.upper, list(to_upper), list(from_upper), 1))
+        if self.transport == "device":
+            ops = []
+            for nb, sends, recvs, _ in sides:
+                for t in sends:
+                    ops.append(dist.P2POp(dist.isend, t, self._global_rank(nb), self.group))
+                for t in recvs:
+                    ops.append(dist.P2POp(dist.irecv, t, self._global_rank(nb), self.group))
+            return ("device", dist.batch_isend_irecv(ops) if ops else [])
+        reqs, unpack = [], []
+        for nb, sends, recvs, side in sides:
+            for idx, t in enumerate(sends):
+                sbuf = t.detach().to("cpu", copy=True).contiguous()
+                reqs.append(dist.isend(sbuf, self._global_rank(nb), self.group, tag=1000 + 2 * idx + side))
+                unpack.append((None, None, sbuf))
+            for idx, t in enumerate(recvs):
+                rbuf = torch.empty(t.shape, dtype=t.dtype, device="cpu")
+                reqs.append(dist.irecv(rbuf, self._global_rank(nb), self.group, tag=1000 + 2 * idx + (1 - side)))
+                unpack.append((t, rbuf, None))
+        return ("host", reqs, unpack)
+
     def finish_halo(self, work):
         if work is None:
             return
@@ -127,7 +162,8 @@ class ZSlabGrid:
         for r in reqs:
             r.wait()
         for dst, rbuf, _keep in unpack:
-            dst.copy_(rbuf)
+            if dst is not None:
+                dst.copy_(rbuf)
 
     # ---- max_g --------------------------------------------------------------------------------------------
     def max_g(self, local_max):

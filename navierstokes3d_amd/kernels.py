@@ -328,14 +328,14 @@ def pt_sweep(Pr_in, Pr_out, dPrdtau, divV, p, k0, k1, ctx=None):
                           C.byref(p), int(k0), int(k1))
 
 
-def pt_sweep2(Pr_in, Pr_out, dPrdtau_in, dPrdtau_out, divV, p, ctx=None):
+def pt_sweep2(Pr_in, Pr_out, dPrdtau_in, dPrdtau_out, divV, p, k0=None, k1=None, ctx=None):
     """TWO fused PT iterations (Pr_in, dPrdtau_in) → (Pr_out, dPrdtau_out) in one pass over memory (same result
     as two pt_sweep calls); all four buffers distinct."""
     nx, ny, nz = Pr_in.shape
     _ctx(ctx, Pr_in).call("pt_sweep2", Pr_in, _chk(Pr_in, None, "Pr_in"), _chk(Pr_out, (nx, ny, nz), "Pr_out"),
                           _chk(dPrdtau_in, (nx - 2, ny - 2, nz - 2), "dPrdtau_in"),
                           _chk(dPrdtau_out, (nx - 2, ny - 2, nz - 2), "dPrdtau_out"), _chk(divV, (nx, ny, nz), "divV"),
-                          C.byref(p))
+                          C.byref(p), 1 if k0 is None else int(k0), nz - 1 if k1 is None else int(k1))
 
 
 def residual_max(Pr, divV, p, ctx=None):

@@ -54,7 +54,7 @@ SIGNATURES = {
     "set_bc_Vel": [_P] * 3 + [_I, _I, _D] + [_I] * 3,
     "pt_iterate": [_P] * 3 + [C.POINTER(PtParams), _I],
     "pt_sweep": [_P] * 4 + [C.POINTER(PtParams), _I, _I],
-    "pt_sweep2": [_P] * 5 + [C.POINTER(PtParams)],
+    "pt_sweep2": [_P] * 5 + [C.POINTER(PtParams), _I, _I],
     "residual_max": [_P] * 2 + [C.POINTER(PtParams), C.POINTER(_D)],
     "pt_solve": [_P] * 3 + [C.POINTER(PtParams), _D, _I, _I, _D, _D, C.POINTER(_I), C.POINTER(_D), _I, C.POINTER(_I)],
 }

@@ -101,7 +101,7 @@ def _worker(rank, world, port, nx, nt, q):
 @pytest.mark.parametrize("world", [2, 3])
 def test_zslab_ranks_match_virtual_rank_oracle(world):
     from oracle.driver_ref import run_navierstokes3D_ref
-    nx, nt = 20, 2
+    nx, nt = 32, 2          # stays finite (smaller grids run into the reference's known instability)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -116,6 +116,7 @@ def test_zslab_ranks_match_virtual_rank_oracle(world):
     for pr in procs:
         pr.join(timeout=60)
     ref = run_navierstokes3D_ref(nx=nx, nt=nt, dims_z=world)
+    assert all(np.isfinite(a).all() for a in ref[:5]) and ref[-1].iters[-1] > ref[-1].params.nchk   # a meaningful case
     info = ref[-1]
     for r in range(world):
         _, iters, local, gathered, nanmax = results[r]
