@@ -75,8 +75,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=512, help="local grid is n x n x nz")
-    ap.add_argument("--nz", type=int, default=None)
+    ap.add_argument("--grid", dest="n", type=int, default=512, help="local grid is n x n x nz")
+    ap.add_argument("--grid-nz", dest="nz", type=int, default=None)
     ap.add_argument("--mode", default=os.environ.get("NS3D_BENCH_MODE", "strict"), choices=["strict", "fast"])
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--variant", type=int, default=int(os.environ.get("NS3D_PT_VARIANT", "0")))

@@ -25,9 +25,12 @@
  *    NS3D_ASYNC (then calls only enqueue on the context's stream; use ns3d_sync()).
  *  - One host thread per context (as in the reference: one thread per rank); contexts are not
  *    thread-safe.
- *  - Arithmetic modes: NS3D_STRICT reproduces the reference's operation order with IEEE division and no
- *    FMA contraction (bit-identical to the CPU oracle); NS3D_FAST uses reciprocal constants and FMA
- *    (≤1e-6 relative L2 at equal iteration counts).
+ *  - Arithmetic modes: NS3D_STRICT reproduces the reference's operation order with correctly rounded division
+ *    and no FMA contraction (bit-identical to the CPU oracle); NS3D_FAST uses reciprocal constants and FMA
+ *    (≤1e-6 relative L2 at equal iteration counts).  In STRICT mode x/dx is evaluated as the correctly rounded
+ *    quotient by the divisor-known-in-advance sequence q=RN(x·r), e=x−q·dx (FMA), RN(q+e·r) with r=RN(1/dx)
+ *    whenever dx,dy,dz are eligible (same bits as the division instruction sequence, ≈⅓ of the instructions;
+ *    ns3d_selftest_exact_div compares the two on the device); NS3D_IEEE_DIV forces the plain sequence.
  */
 #ifndef NS3D_H
 #define NS3D_H
@@ -48,7 +51,8 @@ enum {
 enum {
     NS3D_STRICT = 0x0,
     NS3D_FAST = 0x1,
-    NS3D_ASYNC = 0x2
+    NS3D_ASYNC = 0x2,
+    NS3D_IEEE_DIV = 0x4 /* STRICT only: always use the plain IEEE division instruction sequence (see below) */
 };
 
 /* bc_kind for the pressure / velocity boundary sequences */
@@ -173,6 +177,9 @@ typedef struct ns3d_pt_params {
      * NaN-propagating.  (multi.jl:465-466) */                                                               \
     int ns3d_residual_max_##S(ns3d_ctx *, const T *Pr, const T *divV, const ns3d_pt_params *p,               \
                               double *out_host);                                                             \
+    /* Compares the divisor-known-in-advance division with the plain IEEE division for n pseudo-random dividends  \
+     * (bitwise); *mismatches must come back 0. */                                                           \
+    int ns3d_selftest_exact_div_##S(ns3d_ctx *, double d, long n, unsigned long long seed, long *mismatches);\
     /* The whole inner loop multi.jl:458-471 / gpu.jl:126-137 on one rank: at most niter iterations, every   \
      * nchk-th computes err = max|Rp|*err_mul/err_div (= maximum(abs.(Rp))*ly^2/psc, multi.jl:466), stops  \
      * on err<eps || !isfinite(err) (eps<0: never stop).                                                      \

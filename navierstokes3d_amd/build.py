@@ -2,8 +2,9 @@
 
     python -m navierstokes3d_amd.build [--force]
 
-The kernel translation unit is compiled twice: STRICT (-ffp-contract=off: reference operation order, IEEE
-division, no FMA — bit-identical to the CPU oracle) and FAST (-ffp-contract=fast + reciprocal constants).
+The kernel translation unit is compiled three times: STRICT (-ffp-contract=off: reference operation order, IEEE
+division, no FMA — bit-identical to the CPU oracle), STRICT with exact division-by-known-divisor (same results,
+fewer instructions) and FAST (-ffp-contract=fast + reciprocal constants).
 hipcc cross-compiles without a GPU; the resulting .so is git-ignored but travels to the GPU box.
 """
 import os
@@ -20,6 +21,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-fno-fast-mat
 UNITS = [
     # (source, object, extra flags)
     ("ns3d_kernels.hip", "ns3d_kernels_strict.o", ["-DNS3D_MODE_STRICT", "-ffp-contract=off"]),
+    ("ns3d_kernels.hip", "ns3d_kernels_strictx.o", ["-DNS3D_MODE_STRICT", "-DNS3D_EXACT_RECIP", "-ffp-contract=off"]),
     ("ns3d_kernels.hip", "ns3d_kernels_fast.o", ["-DNS3D_MODE_FAST", "-ffp-contract=fast"]),
     ("ns3d_api.cpp", "ns3d_api.o", ["-x", "hip"]),
 ]

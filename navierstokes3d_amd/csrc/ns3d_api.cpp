@@ -73,7 +73,29 @@ static int finish(ns3d_ctx *ctx, hipError_t e, const char *what)
     return NS3D_OK;
 }
 
-#define DISPATCH(ctx, call) (((ctx)->flags & NS3D_FAST) ? ns3d_fast::call : ns3d_strict::call)
+// arithmetic mode of a launch: 2 = FAST, 1 = STRICT with the exact division-by-known-divisor sequence (bit-identical
+// to 0, chosen when every spacing passes recip_ok), 0 = STRICT with plain IEEE divisions
+static bool recip_ok(double d)
+{
+    if (!(d > 0x1p-100 && d < 0x1p100)) return false;           // also rejects NaN, 0, negatives
+    unsigned long long bits;
+    std::memcpy(&bits, &d, sizeof bits);
+    if ((bits & 0x000FFFFFFFFFFFFFull) == 0x000FFFFFFFFFFFFFull) return false; // significand all ones
+    const float f = (float)d;                                     // the f32 kernels divide by (float)d
+    unsigned int fb;
+    std::memcpy(&fb, &f, sizeof fb);
+    if (!(f > 0x1p-20f && f < 0x1p20f) || (fb & 0x007FFFFFu) == 0x007FFFFFu) return false;
+    return true;
+}
+static int mode_of(const ns3d_ctx *c, double dx, double dy, double dz)
+{
+    if (c->flags & NS3D_FAST) return 2;
+    if (c->flags & NS3D_IEEE_DIV) return 0;
+    return (recip_ok(dx) && recip_ok(dy) && recip_ok(dz)) ? 1 : 0;
+}
+#define DISPATCHM(mode, call) ((mode) == 2 ? ns3d_fast::call : (mode) == 1 ? ns3d_strictx::call : ns3d_strict::call)
+#define DISPATCH(ctx, call) DISPATCHM(((ctx)->flags & NS3D_FAST) ? 2 : 0, call)      /* kernels without divisions */
+#define DISPATCHG(ctx, dx, dy, dz, call) DISPATCHM(mode_of((ctx), (dx), (dy), (dz)), call)
 
 extern "C" {
 
@@ -252,11 +274,11 @@ static int pt_iterate_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_p
     for (int it = 0; it < n_iters;) {
         hipError_t e;
         if (two && it + 2 <= n_iters) {
-            e = DISPATCH(c, pt_sweep2<T>(c->stream, c->pt2_variant, src, dst, dsrc, ddst, divV, *p, 1, p->nz - 1));
+            e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_sweep2<T>(c->stream, c->pt2_variant, src, dst, dsrc, ddst, divV, *p, 1, p->nz - 1));
             T *t = dsrc; dsrc = ddst; ddst = t;
             it += 2;
         } else {
-            e = DISPATCH(c, pt_sweep<T>(c->stream, c->pt_variant, src, dst, dsrc, divV, *p, 1, p->nz - 1));
+            e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_sweep<T>(c->stream, c->pt_variant, src, dst, dsrc, divV, *p, 1, p->nz - 1));
             it += 1;
         }
         if (e != hipSuccess) return fail(NS3D_ERR_HIP, "pt_sweep launch: %s", hipGetErrorString(e));
@@ -289,17 +311,17 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
         // two iterations per pass unless that would step over a residual check or the iteration budget
         const int to_check = nchk > 0 ? nchk - iter % nchk : niter - iter;
         if (two && to_check >= 2 && iter + 2 <= niter) {
-            e = DISPATCH(c, pt_sweep2<T>(c->stream, c->pt2_variant, src, dst, dsrc, ddst, divV, *p, 1, p->nz - 1));
+            e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_sweep2<T>(c->stream, c->pt2_variant, src, dst, dsrc, ddst, divV, *p, 1, p->nz - 1));
             T *t = dsrc; dsrc = ddst; ddst = t;
             iter += 2;
         } else {
-            e = DISPATCH(c, pt_sweep<T>(c->stream, c->pt_variant, src, dst, dsrc, divV, *p, 1, p->nz - 1));
+            e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_sweep<T>(c->stream, c->pt_variant, src, dst, dsrc, divV, *p, 1, p->nz - 1));
             iter += 1;
         }
         if (e != hipSuccess) return fail(NS3D_ERR_HIP, "pt_sweep launch: %s", hipGetErrorString(e));
         T *t = src; src = dst; dst = t;
         if (nchk > 0 && iter % nchk == 0) { // multi.jl:464-469
-            e = DISPATCH(c, residual_max_key<T>(c->stream, src, divV, *p, c->key_dev));
+            e = DISPATCHG(c, p->dx, p->dy, p->dz, residual_max_key<T>(c->stream, src, divV, *p, c->key_dev));
             if (e != hipSuccess) return fail(NS3D_ERR_HIP, "residual launch: %s", hipGetErrorString(e));
             double mx;
             if ((rc = fetch_key(c, &mx))) return rc;
@@ -325,7 +347,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
                                        double dy, double dz, int nx, int ny, int nz)                         \
     {                                                                                                        \
         CHECK_CTX(c); CHECK_PTRS(txx, tyy, tzz, txy, txz, tyz, Vx, Vy, Vz); CHECK_GRID(nx, ny, nz, 2);       \
-        return finish(c, DISPATCH(c, update_tau<T>(c->stream, txx, tyy, tzz, txy, txz, tyz, Vx, Vy, Vz, mu,  \
+        return finish(c, DISPATCHG(c, dx, dy, dz, update_tau<T>(c->stream, txx, tyy, tzz, txy, txz, tyz, Vx, Vy, Vz, mu,  \
                                                    dx, dy, dz, nx, ny, nz)), "update_tau");                  \
     }                                                                                                        \
     extern "C" int ns3d_predict_V_##S(ns3d_ctx *c, T *Vx, T *Vy, T *Vz, const T *txx, const T *tyy,          \
@@ -334,7 +356,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
                                       int nz)                                                                \
     {                                                                                                        \
         CHECK_CTX(c); CHECK_PTRS(Vx, Vy, Vz, txx, tyy, tzz, txy, txz, tyz); CHECK_GRID(nx, ny, nz, 2);       \
-        return finish(c, DISPATCH(c, predict_V<T>(c->stream, Vx, Vy, Vz, txx, tyy, tzz, txy, txz, tyz, rho,  \
+        return finish(c, DISPATCHG(c, dx, dy, dz, predict_V<T>(c->stream, Vx, Vy, Vz, txx, tyy, tzz, txy, txz, tyz, rho,  \
                                                   g, dt, dx, dy, dz, nx, ny, nz)), "predict_V");             \
     }                                                                                                        \
     extern "C" int ns3d_set_cylinder_##S(ns3d_ctx *c, T *C, T *Vx, T *Vy, T *Vz, double a2, double b2,       \
@@ -363,7 +385,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
                                         double dx, double dy, double dz, int nx, int ny, int nz)             \
     {                                                                                                        \
         CHECK_CTX(c); CHECK_PTRS(divV, Vx, Vy, Vz); CHECK_GRID(nx, ny, nz, 1);                               \
-        return finish(c, DISPATCH(c, update_divV<T>(c->stream, divV, Vx, Vy, Vz, dx, dy, dz, nx, ny, nz)),   \
+        return finish(c, DISPATCHG(c, dx, dy, dz, update_divV<T>(c->stream, divV, Vx, Vy, Vz, dx, dy, dz, nx, ny, nz)),   \
                       "update_divV");                                                                        \
     }                                                                                                        \
     extern "C" int ns3d_update_dPrdtau_##S(ns3d_ctx *c, const T *Pr, T *dPrdtau, const T *divV, double rho,  \
@@ -371,7 +393,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
                                            double dz, int nx, int ny, int nz)                                \
     {                                                                                                        \
         CHECK_CTX(c); CHECK_PTRS(Pr, dPrdtau, divV); CHECK_GRID(nx, ny, nz, 3);                              \
-        return finish(c, DISPATCH(c, update_dPrdtau<T>(c->stream, Pr, dPrdtau, divV, rho, dt, dtau, damp,    \
+        return finish(c, DISPATCHG(c, dx, dy, dz, update_dPrdtau<T>(c->stream, Pr, dPrdtau, divV, rho, dt, dtau, damp,    \
                                                        dx, dy, dz, nx, ny, nz)), "update_dPrdtau");          \
     }                                                                                                        \
     extern "C" int ns3d_update_Pr_##S(ns3d_ctx *c, T *Pr, const T *dPrdtau, double dtau, int nx, int ny,     \
@@ -384,7 +406,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
                                         double dt, double dx, double dy, double dz, int nx, int ny, int nz)  \
     {                                                                                                        \
         CHECK_CTX(c); CHECK_PTRS(Rp, Pr, divV); CHECK_GRID(nx, ny, nz, 3);                                   \
-        return finish(c, DISPATCH(c, compute_res<T>(c->stream, Rp, Pr, divV, rho, dt, dx, dy, dz, nx, ny,    \
+        return finish(c, DISPATCHG(c, dx, dy, dz, compute_res<T>(c->stream, Rp, Pr, divV, rho, dt, dx, dy, dz, nx, ny,    \
                                                     nz)), "compute_res");                                    \
     }                                                                                                        \
     extern "C" int ns3d_max_abs_##S(ns3d_ctx *c, const T *A, long n, double *out_host)                       \
@@ -399,7 +421,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
                                       double dx, double dy, double dz, int nx, int ny, int nz)               \
     {                                                                                                        \
         CHECK_CTX(c); CHECK_PTRS(Vx, Vy, Vz, Pr); CHECK_GRID(nx, ny, nz, 2);                                 \
-        return finish(c, DISPATCH(c, correct_V<T>(c->stream, Vx, Vy, Vz, Pr, dt, rho, dx, dy, dz, nx, ny,    \
+        return finish(c, DISPATCHG(c, dx, dy, dz, correct_V<T>(c->stream, Vx, Vy, Vz, Pr, dt, rho, dx, dy, dz, nx, ny,    \
                                                   nz)), "correct_V");                                        \
     }                                                                                                        \
     static int bc_##S(ns3d_ctx *c, int which, T *A, int sx, int sy, int sz, double a, double b, int nz_arg,  \
@@ -433,7 +455,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
                                    double dz, int nx, int ny, int nz, int faithful)                          \
     {                                                                                                        \
         CHECK_CTX(c); CHECK_PTRS(Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, C, C_o); CHECK_GRID(nx, ny, nz, 1);           \
-        return finish(c, DISPATCH(c, advect<T>(c->stream, Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, C, C_o, dt, dx, dy,  \
+        return finish(c, DISPATCHG(c, dx, dy, dz, advect<T>(c->stream, Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, C, C_o, dt, dx, dy,  \
                                                dz, nx, ny, nz, faithful)), "advect");                        \
     }                                                                                                        \
     extern "C" int ns3d_set_bc_Pr_##S(ns3d_ctx *c, T *Pr, int bc_kind, int owns_outlet, double outlet_val,   \
@@ -495,7 +517,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
         if (Pr_in == Pr_out) return fail(NS3D_ERR_ARG, "ns3d_pt_sweep: Pr_in and Pr_out must differ");       \
         if (k0 < 1 || k1 > p->nz - 1 || k0 > k1)                                                             \
             return fail(NS3D_ERR_ARG, "ns3d_pt_sweep: plane range [%d,%d) outside [1,%d)", k0, k1, p->nz - 1);\
-        return finish(c, DISPATCH(c, pt_sweep<T>(c->stream, c->pt_variant, Pr_in, Pr_out, dPrdtau, divV, *p, \
+        return finish(c, DISPATCHG(c, p->dx, p->dy, p->dz, pt_sweep<T>(c->stream, c->pt_variant, Pr_in, Pr_out, dPrdtau, divV, *p, \
                                                  k0, k1)), "pt_sweep");                                      \
     }                                                                                                        \
     extern "C" int ns3d_pt_sweep2_##S(ns3d_ctx *c, const T *Pr_in, T *Pr_out, const T *dPrdtau, T *dPrdtau_out,\
@@ -510,7 +532,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
             return fail(NS3D_ERR_ARG, "ns3d_pt_sweep2: z-slab ranks pass ghost-extended buffers, not halo flags"); \
         if (k0 < 1 || k1 > p->nz - 1 || k0 > k1)                                                             \
             return fail(NS3D_ERR_ARG, "ns3d_pt_sweep2: plane range [%d,%d) outside [1,%d)", k0, k1, p->nz - 1); \
-        return finish(c, DISPATCH(c, pt_sweep2<T>(c->stream, c->pt2_variant < 0 ? 0 : c->pt2_variant, Pr_in, \
+        return finish(c, DISPATCHG(c, p->dx, p->dy, p->dz, pt_sweep2<T>(c->stream, c->pt2_variant < 0 ? 0 : c->pt2_variant, Pr_in, \
                                                   Pr_out, dPrdtau, dPrdtau_out, divV, *p, k0, k1)),          \
                       "pt_sweep2");                                                                          \
     }                                                                                                        \
@@ -520,9 +542,22 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
         CHECK_CTX(c); CHECK_PTRS(Pr, divV, out_host);                                                        \
         int rc = check_pt_params(p, "ns3d_residual_max");                                                    \
         if (rc) return rc;                                                                                   \
-        hipError_t e = DISPATCH(c, residual_max_key<T>(c->stream, Pr, divV, *p, c->key_dev));                \
+        hipError_t e = DISPATCHG(c, p->dx, p->dy, p->dz, residual_max_key<T>(c->stream, Pr, divV, *p, c->key_dev));                \
         if (e != hipSuccess) return fail(NS3D_ERR_HIP, "residual launch: %s", hipGetErrorString(e));         \
         return fetch_key(c, out_host);                                                                       \
+    }                                                                                                        \
+    extern "C" int ns3d_selftest_exact_div_##S(ns3d_ctx *c, double d, long n, unsigned long long seed,        \
+                                               long *mismatches)                                             \
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(mismatches);                                                                \
+        if (!recip_ok(d)) return fail(NS3D_ERR_ARG, "ns3d_selftest_exact_div: divisor %g is not eligible", d);\
+        hipError_t e = ns3d_strictx::divtest<T>(c->stream, d, n, seed, c->key_dev);                          \
+        if (e != hipSuccess) return fail(NS3D_ERR_HIP, "divtest launch: %s", hipGetErrorString(e));          \
+        HIPCHK(c, hipMemcpyAsync(c->key_host, c->key_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, \
+                                 c->stream));                                                                \
+        HIPCHK(c, hipStreamSynchronize(c->stream));                                                          \
+        *mismatches = (long)*c->key_host;                                                                    \
+        return NS3D_OK;                                                                                      \
     }                                                                                                        \
     extern "C" int ns3d_pt_solve_##S(ns3d_ctx *c, T *Pr, T *dPrdtau, const T *divV, const ns3d_pt_params *p, \
                                      double eps, int niter, int nchk, double err_mul, double err_div,        \

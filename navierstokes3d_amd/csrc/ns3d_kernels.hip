@@ -14,6 +14,9 @@
 #if defined(NS3D_MODE_FAST)
 #define NS3D_NS ns3d_fast
 #define NS3D_FASTMATH 1
+#elif defined(NS3D_MODE_STRICT) && defined(NS3D_EXACT_RECIP)
+#define NS3D_NS ns3d_strictx
+#define NS3D_FASTMATH 0
 #elif defined(NS3D_MODE_STRICT)
 #define NS3D_NS ns3d_strict
 #define NS3D_FASTMATH 0
@@ -39,10 +42,42 @@ static Geo<T> make_geo(double dx, double dy, double dz)
 {
     Geo<T> g;
     g.dx = (T)dx; g.dy = (T)dy; g.dz = (T)dz;
-    g.rdx = (T)(1.0 / dx); g.rdy = (T)(1.0 / dy); g.rdz = (T)(1.0 / dz);
+    g.rdx = (T)1 / g.dx; g.rdy = (T)1 / g.dy; g.rdz = (T)1 / g.dz;   // RN(1/d) in the element type
     g.rdx2 = (T)(1.0 / (dx * dx)); g.rdy2 = (T)(1.0 / (dy * dy)); g.rdz2 = (T)(1.0 / (dz * dz));
     return g;
 }
+// ---- correctly rounded division by a divisor known in advance -------------------------------------------
+// STRICT mode must return RN(x/d) bit for bit, but the generic IEEE fp64 division costs ≈14 dependent VALU
+// instructions and the PT stencil does six of them per cell.  With r = RN(1/d) precomputed (Markstein 1990; Brisebarre,
+// Muller & Raina, IEEE TC 2004: "the advanced computation of 1/y allows performing correctly rounded division in one
+// multiplication plus two FMACs"):
+//        q = RN(x·r);   e = x − q·d  (exact, one FMA);   q' = RN(q + e·r)  =  RN(x/d)
+// valid while no intermediate over/underflows, i.e. for 2^-900 < |q| < 2^900 with 2^-100 < d < 2^100 (checked on the
+// host, which also refuses divisors whose significand is all ones); everything else — zeros (sign preserved), huge,
+// tiny, Inf, NaN — takes the plain division.  `ns3d_selftest_exact_div` compares the two on the GPU bit for bit.
+template <class T> struct DivLim;
+template <> struct DivLim<double> { static constexpr double lo = 0x1p-900, hi = 0x1p900; };
+template <> struct DivLim<float> { static constexpr float lo = 0x1p-100f, hi = 0x1p100f; };
+template <class T>
+__device__ __forceinline__ T div_by_known(T x, T d, T r)
+{
+    const T q = x * r;
+    const T e = __builtin_fma(-q, d, x);
+    T q1 = __builtin_fma(e, r, q);
+    const T aq = __builtin_fabs(q);
+    if (!(aq > DivLim<T>::lo && aq < DivLim<T>::hi)) q1 = (x == (T)0) ? x : x / d;
+    return q1;
+}
+__device__ __forceinline__ float div_by_known(float x, float d, float r)
+{
+    const float q = x * r;
+    const float e = __builtin_fmaf(-q, d, x);
+    float q1 = __builtin_fmaf(e, r, q);
+    const float aq = __builtin_fabsf(q);
+    if (!(aq > DivLim<float>::lo && aq < DivLim<float>::hi)) q1 = (x == 0.0f) ? x : x / d;
+    return q1;
+}
+
 #if NS3D_FASTMATH
 #define DIV_X(v) ((v)*g.rdx)
 #define DIV_Y(v) ((v)*g.rdy)
@@ -51,6 +86,14 @@ static Geo<T> make_geo(double dx, double dy, double dz)
 #define DIV_YY(v) ((v)*g.rdy2)
 #define DIV_ZZ(v) ((v)*g.rdz2)
 #define DIV_3(v) ((v) * (T)(1.0 / 3.0))
+#elif defined(NS3D_EXACT_RECIP)
+#define DIV_X(v) div_by_known((v), g.dx, g.rdx)
+#define DIV_Y(v) div_by_known((v), g.dy, g.rdy)
+#define DIV_Z(v) div_by_known((v), g.dz, g.rdz)
+#define DIV_XX(v) div_by_known(div_by_known((v), g.dx, g.rdx), g.dx, g.rdx)
+#define DIV_YY(v) div_by_known(div_by_known((v), g.dy, g.rdy), g.dy, g.rdy)
+#define DIV_ZZ(v) div_by_known(div_by_known((v), g.dz, g.rdz), g.dz, g.rdz)
+#define DIV_3(v) ((v) / (T)3.0)
 #else
 #define DIV_X(v) ((v) / g.dx)
 #define DIV_Y(v) ((v) / g.dy)
@@ -198,6 +241,67 @@ __device__ __forceinline__ T poisson_rhs(T c, T w, T e, T s, T n, T b, T t, T dv
     const T lap = (DIV_XX(d2x) + DIV_YY(d2y)) + DIV_ZZ(d2z);
     return lap - rho_dt * dv;
 }
+
+// Hot-kernel form: the same value as poisson_rhs, evaluated without branches.  In the exact-reciprocal STRICT build
+// every x/d/d is two divisor-known-in-advance divisions in straight-line code; `ok` is cleared for the lanes whose
+// dividend is outside the range in which that sequence is proven exact (|x| ∉ (2^-700, 2^700), Inf, NaN — zeros are
+// exact and keep their sign), and the caller then re-evaluates those lanes with plain divisions (poisson_rhs_slow).
+// One rare branch per stage instead of one per division keeps the independent columns interleavable.
+#if defined(NS3D_EXACT_RECIP)
+template <class T> struct Div2Lim;
+template <> struct Div2Lim<double> { static constexpr double lo = 0x1p-700, hi = 0x1p700; };
+template <> struct Div2Lim<float> { static constexpr float lo = 0x1p-40f, hi = 0x1p40f; };
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double abs_(double a) { return __builtin_fabs(a); }
+__device__ __forceinline__ float abs_(float a) { return __builtin_fabsf(a); }
+template <class T>
+__device__ __forceinline__ T div2_known(T x, T d, T r, bool &ok)
+{
+    T q = x * r;
+    T e = fma_(-q, d, x);
+    q = fma_(e, r, q);              // RN(x/d)
+    T q2 = q * r;
+    e = fma_(-q2, d, q);
+    q2 = fma_(e, r, q2);            // RN(RN(x/d)/d)
+    const T ax = abs_(x);
+    const bool z = (x == (T)0);
+    ok = ok & (z | ((ax > Div2Lim<T>::lo) & (ax < Div2Lim<T>::hi)));   // bitwise on purpose: no short-circuit branches
+    return z ? x : q2;
+}
+template <class T>
+__device__ __forceinline__ T poisson_rhs_ok(T c, T w, T e, T s, T n, T b, T t, T dv, T rho_dt, const Geo<T> &g, bool &ok)
+{
+    const T d2x = (e - c) - (c - w);
+    const T d2y = (n - c) - (c - s);
+    const T d2z = (t - c) - (c - b);
+    const T lap = (div2_known<T>(d2x, g.dx, g.rdx, ok) + div2_known<T>(d2y, g.dy, g.rdy, ok)) +
+                  div2_known<T>(d2z, g.dz, g.rdz, ok);
+    return lap - rho_dt * dv;
+}
+template <class T>
+__device__ __forceinline__ T poisson_rhs_slow(T c, T w, T e, T s, T n, T b, T t, T dv, T rho_dt, const Geo<T> &g)
+{
+    const T d2x = (e - c) - (c - w);
+    const T d2y = (n - c) - (c - s);
+    const T d2z = (t - c) - (c - b);
+    const T lap = ((d2x / g.dx / g.dx) + (d2y / g.dy / g.dy)) + (d2z / g.dz / g.dz);
+    return lap - rho_dt * dv;
+}
+#define NS3D_HAS_SLOW_PATH 1
+#else
+template <class T>
+__device__ __forceinline__ T poisson_rhs_ok(T c, T w, T e, T s, T n, T b, T t, T dv, T rho_dt, const Geo<T> &g, bool &)
+{
+    return poisson_rhs<T>(c, w, e, s, n, b, t, dv, rho_dt, g);
+}
+template <class T>
+__device__ __forceinline__ T poisson_rhs_slow(T c, T w, T e, T s, T n, T b, T t, T dv, T rho_dt, const Geo<T> &g)
+{
+    return poisson_rhs<T>(c, w, e, s, n, b, t, dv, rho_dt, g);
+}
+#define NS3D_HAS_SLOW_PATH 0
+#endif
 
 // Drop-in, signature-preserving (unfused) PT kernels: one thread per interior cell.
 template <class T, int MODE> // MODE 0: update_dPrdτ!   1: compute_res!
@@ -960,7 +1064,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep_pipe(SweepArgs<
             e = lane == 63 ? hx[r] : e;
             const T s = r == 0 ? ylo : pc[r - 1 < 0 ? 0 : r - 1];
             const T n = r == RY - 1 ? yhi : pc[r + 1 > RY - 1 ? RY - 1 : r + 1];
-            const T res = poisson_rhs<T>(c, w, e, s, n, pm[r], pp[r], rv[r], a.rho_dt, g);
+            bool ok = true;
+            T res = poisson_rhs_ok<T>(c, w, e, s, n, pm[r], pp[r], rv[r], a.rho_dt, g, ok);
+            if (NS3D_HAS_SLOW_PATH && __builtin_expect(!ok, 0)) res = poisson_rhs_slow<T>(c, w, e, s, n, pm[r], pp[r], rv[r], a.rho_dt, g);
             const T dn = dv[r] * a.one_m_damp + a.dtau * res;
             if (ract[r]) {
                 st_stream<T, NT>(Dk + drow[r], dn);
@@ -1290,7 +1396,9 @@ __global__ __launch_bounds__(64 * WX * WY) void k_pt_sweep2(SweepArgs<T> a, int 
             const T w = l0[(lr + 1) * PX + lx], e = l0[(lr + 1) * PX + lx + 2];
             const T sv = r == 0 ? l0[lr * PX + lx + 1] : p0c[r - 1 < 0 ? 0 : r - 1];
             const T nv = r == CPT - 1 ? l0[(lr + 2) * PX + lx + 1] : p0c[r + 1 > CPT - 1 ? CPT - 1 : r + 1];
-            const T res = poisson_rhs<T>(c, w, e, sv, nv, p0m[r], p0p[r], r0[r], a.rho_dt, g);
+            bool ok = true;
+            T res = poisson_rhs_ok<T>(c, w, e, sv, nv, p0m[r], p0p[r], r0[r], a.rho_dt, g, ok);
+            if (NS3D_HAS_SLOW_PATH && __builtin_expect(!ok, 0)) res = poisson_rhs_slow<T>(c, w, e, sv, nv, p0m[r], p0p[r], r0[r], a.rho_dt, g);
             d1n[r] = d0[r] * a.one_m_damp + a.dtau * res;
             p1p[r] = c + a.dtau * d1n[r];
         }
@@ -1330,7 +1438,9 @@ __global__ __launch_bounds__(64 * WX * WY) void k_pt_sweep2(SweepArgs<T> a, int 
                 if (yhi_adj[r]) nv = c;
                 const T bv = zlo ? c : p1m[r];
                 const T tv = zhi ? c : p1p[r];
-                const T res = poisson_rhs<T>(c, w, e, sv, nv, bv, tv, r1c[r], a.rho_dt, g);
+                bool ok = true;
+                T res = poisson_rhs_ok<T>(c, w, e, sv, nv, bv, tv, r1c[r], a.rho_dt, g, ok);
+                if (NS3D_HAS_SLOW_PATH && __builtin_expect(!ok, 0)) res = poisson_rhs_slow<T>(c, w, e, sv, nv, bv, tv, r1c[r], a.rho_dt, g);
                 const T dn = d1c[r] * a.one_m_damp + a.dtau * res;
                 const T pn = c + a.dtau * dn;
                 if (outc[r]) {
@@ -1494,17 +1604,25 @@ hipError_t pt_sweep(hipStream_t s, int variant, const T *Pin, T *Pout, T *D, con
 // ---------------------------------------------------------------------------------------------------------
 template <class T>
 __global__ __launch_bounds__(256) void k_residual_max(const T *__restrict__ P, const T *__restrict__ RHS, T rho_dt,
-                                                      Geo<T> g, int nx, int ny, int nz, unsigned long long *out)
+                                                      Geo<T> g, int nx, int ny, int nz, int kz, unsigned long long *out)
 {
+    // block = 64×4 columns, marching kz planes: one atomicMax per block, ≤ a few thousand blocks per launch
+    // (one atomic per 256-thread block of a one-thread-per-cell grid serialises ≈0.5 M same-address atomics)
     const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
-    const int k = 1 + blockIdx.z * blockDim.z + threadIdx.z;
+    const int kb = 1 + blockIdx.z * kz, ke = min(kb + kz, nz - 1);
     unsigned long long key = 0ull;
-    if (i <= nx - 2 && j <= ny - 2 && k <= nz - 2) {
-        const idx_t p = IX3(i, j, k, nx, ny);
+    if (i <= nx - 2 && j <= ny - 2) {
         const idx_t sy = nx, sz = (idx_t)nx * ny;
-        const T r = poisson_rhs<T>(P[p], P[p - 1], P[p + 1], P[p - sy], P[p + sy], P[p - sz], P[p + sz], RHS[p], rho_dt, g);
-        key = abs_key((double)r);
+        idx_t p = IX3(i, j, kb, nx, ny);
+        T b = P[p - sz], c = P[p];
+        for (int k = kb; k < ke; ++k, p += sz) {
+            const T t = P[p + sz];
+            const T r = poisson_rhs<T>(c, P[p - 1], P[p + 1], P[p - sy], P[p + sy], b, t, RHS[p], rho_dt, g);
+            const unsigned long long u = abs_key((double)r);
+            key = u > key ? u : key;
+            b = c; c = t;
+        }
     }
     block_max_to_global(key, out);
 }
@@ -1514,8 +1632,73 @@ hipError_t residual_max_key(hipStream_t s, const T *Pr, const T *divV, const ns3
 {
     hipError_t e = hipMemsetAsync(key_dev, 0, sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_residual_max<T>, grid3(p.nx - 2, p.ny - 2, p.nz - 2, BLK3), BLK3, 0, s, Pr, divV,
-                       (T)p.rho / (T)p.dt, make_geo<T>(p.dx, p.dy, p.dz), p.nx, p.ny, p.nz, key_dev);
+    const int kz = 16;
+    const dim3 blk(64, 4, 1);
+    const dim3 grd((unsigned)((p.nx - 2 + 63) / 64), (unsigned)((p.ny - 2 + 3) / 4), (unsigned)((p.nz - 2 + kz - 1) / kz));
+    hipLaunchKernelGGL(k_residual_max<T>, grd, blk, 0, s, Pr, divV, (T)p.rho / (T)p.dt, make_geo<T>(p.dx, p.dy, p.dz),
+                       p.nx, p.ny, p.nz, kz, key_dev);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Self-test of div_by_known against the hardware's IEEE division: n pseudo-random dividends per launch (random
+// significands over 120 binades, plus quotients planted next to representable numbers and rounding midpoints).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long splitmix(unsigned long long &st)
+{
+    unsigned long long z = (st += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_divtest(T d, T r, long n, unsigned long long seed, unsigned long long *bad)
+{
+    unsigned long long st = seed + 0x632BE59BD9B4E019ull * ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x + 1);
+    unsigned long long nb = 0;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long)gridDim.x * blockDim.x) {
+        const unsigned long long u = splitmix(st), v = splitmix(st);
+        T x;
+        if (sizeof(T) == 8) {
+            const unsigned long long mant = u & 0x000FFFFFFFFFFFFFull, sign = u & 0x8000000000000000ull;
+            const unsigned long long expo = 1023 - 60 + (v % 120);
+            double xd = __longlong_as_double((long long)(sign | (expo << 52) | mant));
+            if ((v >> 60) & 1) { // plant the quotient next to a representable number / midpoint: x ≈ qc·d
+                double qc = xd, prod = qc * (double)d;
+                long long pb = __double_as_longlong(prod) + (long long)((v >> 56) & 7) - 3;
+                xd = __longlong_as_double(pb);
+            }
+            x = (T)xd;
+        } else {
+            const unsigned int w = (unsigned int)u;
+            const unsigned int mant = w & 0x007FFFFFu, sign = w & 0x80000000u, expo = 127 - 20 + (unsigned int)(v % 40);
+            float xf = __uint_as_float(sign | (expo << 23) | mant);
+            if ((v >> 60) & 1) xf = __uint_as_float(__float_as_uint(xf * (float)d) + (unsigned int)((v >> 56) & 7) - 3u);
+            x = (T)xf;
+        }
+        const T a = div_by_known(x, d, r), b = x / d;
+        bool same;
+        if (sizeof(T) == 8) same = __double_as_longlong((double)a) == __double_as_longlong((double)b);
+        else same = __float_as_uint((float)a) == __float_as_uint((float)b);
+#if defined(NS3D_EXACT_RECIP)
+        bool ok = true;                       // the branch-free double division of the hot kernels: x/d/d
+        const T a2 = div2_known<T>(x, d, r, ok), b2 = x / d / d;
+        if (ok) {
+            if (sizeof(T) == 8) same = same && (__double_as_longlong((double)a2) == __double_as_longlong((double)b2));
+            else same = same && (__float_as_uint((float)a2) == __float_as_uint((float)b2));
+        }
+#endif
+        nb += same ? 0 : 1;
+    }
+    if (nb) atomicAdd(bad, nb);
+}
+template <class T>
+hipError_t divtest(hipStream_t s, double d, long n, unsigned long long seed, unsigned long long *bad_dev)
+{
+    hipError_t e = hipMemsetAsync(bad_dev, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    const T dd = (T)d, rr = (T)1 / dd;
+    hipLaunchKernelGGL(k_divtest<T>, dim3(2048), dim3(256), 0, s, dd, rr, n, seed, bad_dev);
     return hipGetLastError();
 }
 
@@ -1547,7 +1730,8 @@ hipError_t residual_max_key(hipStream_t s, const T *Pr, const T *divV, const ns3
     template hipError_t pt_sweep2<T>(hipStream_t, int, const T *, T *, const T *, T *, const T *,            \
                                      const ns3d_pt_params &, int, int);                                      \
     template hipError_t residual_max_key<T>(hipStream_t, const T *, const T *, const ns3d_pt_params &,       \
-                                            unsigned long long *);
+                                            unsigned long long *);                                           \
+    template hipError_t divtest<T>(hipStream_t, double, long, unsigned long long, unsigned long long *);
 INST(double)
 INST(float)
 #undef INST

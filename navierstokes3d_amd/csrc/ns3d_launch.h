@@ -47,7 +47,10 @@
     template <class T>                                                                                       \
     hipError_t residual_max_key(hipStream_t, const T *, const T *, const ns3d_pt_params &,                   \
                                 unsigned long long *key_dev);                                                \
+    template <class T>                                                                                       \
+    hipError_t divtest(hipStream_t, double d, long n, unsigned long long seed, unsigned long long *bad_dev); \
     }
 
 NS3D_LAUNCHER_DECLS(ns3d_strict)
+NS3D_LAUNCHER_DECLS(ns3d_strictx)
 NS3D_LAUNCHER_DECLS(ns3d_fast)

@@ -61,7 +61,7 @@ class Context:
     (gpu.jl:4-8): device + arithmetic mode.  mode: 'strict' (bit-identical to the reference operation
     order) or 'fast' (reciprocals + FMA)."""
 
-    def __init__(self, device=None, mode="strict", async_=False):
+    def __init__(self, device=None, mode="strict", async_=False, ieee_div=False):
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise L.Ns3dError("no GPU visible: libns3d has no CPU path")
@@ -69,6 +69,7 @@ class Context:
             device = torch.cuda.current_device()
         self.device = int(device)
         flags = {"strict": L.NS3D_STRICT, "fast": L.NS3D_FAST}[mode] | (L.NS3D_ASYNC if async_ else 0)
+        flags |= L.NS3D_IEEE_DIV if ieee_div else 0
         self.mode = mode
         self.handle = self.lib.ns3d_create(self.device, flags)
         if not self.handle:
@@ -90,6 +91,13 @@ class Context:
     def set_pt2_variant(self, v):
         """Temporal blocking (two PT iterations per pass) in pt_iterate / pt_solve: v < 0 off, 0 default tile."""
         L.check(self.lib.ns3d_set_pt2_variant(self.handle, int(v)))
+
+    def selftest_exact_div(self, d, n=1 << 24, seed=1, dtype=torch.float64):
+        """Mismatches between the divisor-known-in-advance division and the plain IEEE division over n dividends."""
+        out = C.c_long(-1)
+        fn = getattr(self.lib, "ns3d_selftest_exact_div_" + _DT[dtype])
+        L.check(fn(self.handle, C.c_double(d), C.c_long(n), C.c_ulonglong(seed), C.byref(out)))
+        return out.value
 
     def close(self):
         if getattr(self, "handle", None):

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libns3d.so")
 
 NS3D_OK = 0
-NS3D_STRICT, NS3D_FAST, NS3D_ASYNC = 0x0, 0x1, 0x2
+NS3D_STRICT, NS3D_FAST, NS3D_ASYNC, NS3D_IEEE_DIV = 0x0, 0x1, 0x2, 0x4
 NS3D_BC_MULTI, NS3D_BC_GPU = 0, 1
 
 
@@ -56,6 +56,7 @@ SIGNATURES = {
     "pt_sweep": [_P] * 4 + [C.POINTER(PtParams), _I, _I],
     "pt_sweep2": [_P] * 5 + [C.POINTER(PtParams), _I, _I],
     "residual_max": [_P] * 2 + [C.POINTER(PtParams), C.POINTER(_D)],
+    "selftest_exact_div": [_D, _L, C.c_ulonglong, C.POINTER(_L)],
     "pt_solve": [_P] * 3 + [C.POINTER(PtParams), _D, _I, _I, _D, _D, C.POINTER(_I), C.POINTER(_D), _I, C.POINTER(_I)],
 }
 CONTEXT_SYMBOLS = ["ns3d_version", "ns3d_last_error", "ns3d_create", "ns3d_destroy", "ns3d_flags",

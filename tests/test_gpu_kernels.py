@@ -213,3 +213,43 @@ def test_copy_and_errors(hip):
         hip.update_Pr(hip.zeros((8, 8, 8)), hip.zeros((5, 6, 6)), 0.1)
     with pytest.raises(L.Ns3dError):      # grid too small for the stencil: status from the C ABI
         hip.update_Pr(hip.zeros((2, 8, 8)), hip.zeros((0, 6, 6)), 0.1)
+
+
+def test_exact_division_by_known_divisor(hip):
+    """STRICT mode evaluates x/dx as q=RN(x·r), e=x−q·dx (FMA), RN(q+e·r), r=RN(1/dx) — the correctly rounded quotient
+    (Markstein).  The device self-test compares it bit for bit with the plain IEEE division on pseudo-random dividends
+    (random significands over 120 binades plus quotients planted next to representable numbers and midpoints)."""
+    import numpy as np
+    ctx = hip.Context(0, "strict")
+    rng = np.random.Generator(np.random.MT19937(2024))
+    divisors = [1.0 / 63, 0.6 / 38, 1.0 / 255, 0.6 / 153, 1.0 / 512, 0.7 / 5, 1.0 / 17, 0.6 / 9, 3.0, 0.1, 1.0 / 3,
+                float(np.nextafter(2.0, 0.0)) / 4.0 * 0 + 0.0078125]
+    divisors += [float(x) for x in np.exp(rng.uniform(np.log(1e-5), np.log(50.0), 60))]
+    total = 0
+    for q, d in enumerate(divisors):
+        n = 1 << 24
+        assert ctx.selftest_exact_div(d, n, seed=q + 1) == 0, "f64 divisor %r" % d
+        assert ctx.selftest_exact_div(d, 1 << 22, seed=q + 1, dtype=__import__("torch").float32) == 0, "f32 divisor %r" % d
+        total += n
+    # a long run on the spacings of the reference configurations
+    for d in (1.0 / 63, 0.6 / 38, 1.0 / 255, 0.6 / 153):
+        assert ctx.selftest_exact_div(d, 1 << 30, seed=99) == 0
+    ctx.close()
+
+
+def test_ieee_div_flag_gives_identical_results(hip, oracle):
+    """NS3D_IEEE_DIV (plain division sequence) and the default STRICT path produce the same bits."""
+    import torch
+    nx, ny, nz = 24, 15, 15
+    g = geometry(nx, ny, nz)
+    Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 77)
+    outs = []
+    for ieee in (False, True):
+        ctx = hip.Context(0, "strict", ieee_div=ieee)
+        dPr, dd = hip.from_numpy(Pr0), hip.from_numpy(d0)
+        p = hip.pt_params(dPr, g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"])
+        hip.pt_iterate(dPr, dd, hip.from_numpy(rhs), p, 9, ctx=ctx)
+        torch.cuda.synchronize()
+        outs.append((hip.to_numpy(dPr), hip.to_numpy(dd)))
+        ctx.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
