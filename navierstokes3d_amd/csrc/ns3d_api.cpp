@@ -217,6 +217,15 @@ static int check_pt_params(const ns3d_pt_params *p, const char *fn)
     return NS3D_OK;
 }
 
+// Temporal blocking pays once the grid no longer lives in the caches (≈4 M cells: profiles/r1_sweep*_final.log);
+// an explicit ns3d_set_pt2_variant(ctx, v>0) forces it, v<0 disables it.
+static bool use_two(const ns3d_ctx *c, const ns3d_pt_params *p)
+{
+    if (c->pt2_variant < 0) return false;
+    if (c->pt2_variant > 0) return true;
+    return (long long)p->nx * p->ny * p->nz >= 4ll * 1000 * 1000;
+}
+
 template <class T>
 static int ensure_pingpong(ns3d_ctx *c, const ns3d_pt_params *p, T **buf)
 {
@@ -269,7 +278,7 @@ static int pt_iterate_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_p
                                  hipMemcpyDeviceToDevice, c->stream));
     T *src = Pr, *dst = other;
     T *dsrc = D, *ddst = nullptr;
-    const bool two = c->pt2_variant >= 0 && !p->z_lo_is_halo && !p->z_hi_is_halo && n_iters >= 2;
+    const bool two = use_two(c, p) && !p->z_lo_is_halo && !p->z_hi_is_halo && n_iters >= 2;
     if (two && (rc = ensure_pingpong_d<T>(c, p, &ddst))) return rc;
     for (int it = 0; it < n_iters;) {
         hipError_t e;
@@ -303,7 +312,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
     const size_t plane = (size_t)p->nx * p->ny;
     T *src = Pr, *dst = other;
     int checks = 0, iter = 0, done = niter;
-    const bool two = c->pt2_variant >= 0 && niter >= 2;
+    const bool two = use_two(c, p) && niter >= 2;
     T *dsrc = D, *ddst = nullptr;
     if (two && (rc = ensure_pingpong_d<T>(c, p, &ddst))) return rc;
     while (iter < niter) {

@@ -1296,8 +1296,8 @@ static hipError_t launch_xcd_auto(hipStream_t s, SweepArgs<T> &a, int kz, int wx
 // outlet_val; gpu.jl x planes: hydrostatic value).  Faces of P² are stored by the producing thread as in the
 // single sweep.  z planes that are inter-slab halos are not supported here (the z-slab schedule uses single sweeps).
 // =========================================================================================================
-template <class T, int WX, int WY, int CPT, bool NT>
-__global__ __launch_bounds__(64 * WX * WY) void k_pt_sweep2(SweepArgs<T> a, int ntx, int nty)
+template <class T, int WX, int WY, int CPT, bool NT, int MINW = 1>
+__global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a, int ntx, int nty)
 {
     constexpr int TX = 64 * WX, TY = CPT * WY, PX = TX + 2;
     __shared__ T L0[2][(TY + 2) * PX]; // P⁰ plane with halo ring: element (lx+1, lr+1)
@@ -1489,7 +1489,7 @@ __global__ __launch_bounds__(64 * WX * WY) void k_pt_sweep2(SweepArgs<T> a, int 
     }
 }
 
-template <class T, int WX, int WY, int CPT, bool NT>
+template <class T, int WX, int WY, int CPT, bool NT, int MINW = 1>
 static hipError_t launch_sweep2(hipStream_t s, SweepArgs<T> &a, int kz)
 {
     constexpr int TX = 64 * WX, TY = CPT * WY;
@@ -1497,8 +1497,8 @@ static hipError_t launch_sweep2(hipStream_t s, SweepArgs<T> &a, int kz)
     const int nk = a.k1 - a.k0;
     const int ntx = max(1, (a.nx - 4 + (TX - 2) - 1) / (TX - 2)), nty = max(1, (a.ny - 4 + (TY - 2) - 1) / (TY - 2));
     const int ntz = (nk + kz - 1) / kz;
-    hipLaunchKernelGGL((k_pt_sweep2<T, WX, WY, CPT, NT>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX, WY, 1), 0, s, a,
-                       ntx, nty);
+    hipLaunchKernelGGL((k_pt_sweep2<T, WX, WY, CPT, NT, MINW>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX, WY, 1), 0,
+                       s, a, ntx, nty);
     return hipGetLastError();
 }
 
@@ -1516,10 +1516,19 @@ hipError_t pt_sweep2(hipStream_t s, int variant, const T *Pin, T *Pout, const T 
     a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = 0; a.zhi_halo = 0;
     a.k0 = k0; a.k1 = k1; a.kz = 1;
     if (k1 <= k0) return hipSuccess;
-    const int shape = variant / 100;
+    int shape = variant / 100;
     int kz = variant % 100;
-    if (kz <= 0) kz = 32;
     const int nxi = p.nx - 2;
+    if (variant == 0) {
+        // tile shape by grid size (measured: profiles/r1_sweep*_final.log): large grids → 64×32 columns per workgroup
+        // (least overlap), long z-chunks; cache-resident grids → wide 256×8 tiles, short chunks so that every CU gets
+        // work.  Explicit variants (shape·100 + kz) override.
+        const long long cells = (long long)p.nx * p.ny * p.nz;
+        const int nzi = p.nz - 2;
+        if (cells >= 32ll * 1000 * 1000) { shape = 3; kz = nzi >= 384 ? 64 : (nzi >= 192 ? 32 : 16); }
+        else { shape = nxi > 128 ? 1 : (nxi > 64 ? 2 : 3); kz = nzi >= 64 ? 16 : 8; }
+    }
+    if (kz <= 0) kz = 32;
     switch (shape) {
     case 1: return launch_sweep2<T, 4, 2, 4, true>(s, a, kz);   // 256 x 8
     case 2: return launch_sweep2<T, 2, 4, 4, true>(s, a, kz);   // 128 x 16
@@ -1547,10 +1556,13 @@ hipError_t pt_sweep(hipStream_t s, int variant, const T *Pin, T *Pout, T *D, con
     a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = p.z_lo_is_halo; a.zhi_halo = p.z_hi_is_halo;
     a.k0 = k0; a.k1 = k1; a.kz = 1;
     if (k1 <= k0) return hipSuccess;
-    // variant = family*100 + kz  (kz = planes marched per block; 0 → default)
-    const int fam = variant / 100;
+    // variant = family*100 + kz  (kz = planes marched per block; 0 → default); variant 0 = choose by grid size:
+    // grids whose four PT arrays stay resident in L2 / Infinity Cache run best with one thread per cell (neighbours are
+    // cache hits); beyond that the z-marching register pipeline wins (tools/sweep_variants.py, profiles/).
+    int fam = variant / 100;
     int kz = variant % 100;
     if (kz <= 0) kz = 32;
+    if (variant == 0) fam = ((long long)p.nx * p.ny * p.nz <= 64ll * 1000 * 1000) ? 1 : 22;
     switch (fam) {
     case 1: {
         dim3 blk(64, 4, 1);

@@ -158,7 +158,7 @@ def test_pt_f32(hip, oracle):
 
 
 # ---- temporal blocking: two PT iterations per pass over memory -------------------------------------------------
-SHAPES2 = [0, 100, 200, 300, 400, 500, 600, 103, 207, 101]
+SHAPES2 = [0, 100, 200, 300, 400, 500, 600, 103, 207, 101, 364, 316]
 GRIDS2 = GRIDS + [(260, 19, 9), (131, 40, 6), (66, 70, 5)]
 
 
@@ -198,7 +198,7 @@ def test_pt_iterate_and_solve_with_temporal_blocking(hip, oracle, grid):
     Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 73)
     rhs *= 1e-3
     ctx = hip.Context(0, "strict")
-    ctx.set_pt2_variant(0)
+    ctx.set_pt2_variant(300 if nx > 60 else 100)   # explicit shape: the automatic choice keeps small grids on single sweeps
     for n in (1, 2, 3, 8, 11):
         Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
         _oracle_iters(oracle, Pr, d, rhs, g, n, 0, True, 0.0)
