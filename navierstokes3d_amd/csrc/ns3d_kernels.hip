@@ -858,15 +858,7 @@ static hipError_t launch_zmarch(hipStream_t s, SweepArgs<T> &a, int kz)
     return hipGetLastError();
 }
 
-// ---- variant X: z-marching register pipeline, blocks span WX waves along x, XCD-aware tile order ---------
-// Same arithmetic and register pipeline as variant Z.  What changes is WHERE the halo traffic lands:
-//  * a block is WX waves wide in x (for nx ≤ 64·WX+2 a block owns whole rows), so the one-lane x-halo loads hit
-//    lines the neighbouring wave of the SAME workgroup has just brought in, instead of crossing to another XCD;
-//  * the grid is 1-D and the hardware's round-robin block→XCD dealing (block b → XCD b mod 8) is undone so that
-//    each XCD sweeps one contiguous range of tiles (x fastest, then y, then z-chunk): y-neighbour tiles share
-//    an L2 and run at the same time, so their halo rows are L2 hits rather than second fetches over the fabric;
-//  * NT: dPrdτ / ∇V are streamed with nontemporal loads and dPrdτ / P⁺ with nontemporal stores (each byte is
-//    touched once per sweep) so that they do not evict the P rows the neighbours still need.
+// streaming accessors: nontemporal loads/stores for data touched once per sweep (dPrdτ, ∇V, new Pr)
 template <class T, bool NT> __device__ __forceinline__ T ld_stream(const T *p)
 {
     if (NT) return __builtin_nontemporal_load(p);
@@ -878,106 +870,11 @@ template <class T, bool NT> __device__ __forceinline__ void st_stream(T *p, T v)
     else *p = v;
 }
 
-template <class T, int RY, int WX, int WY, bool NT>
-__global__ __launch_bounds__(64 * WX * WY) void k_pt_sweep_xcd(SweepArgs<T> a, int ntx, int nty)
-{
-    const int nx = a.nx, ny = a.ny;
-    const Geo<T> &g = a.g;
-    // undo the round-robin XCD dealing: XCD c owns tiles [first(c), first(c)+count(c))
-    const int nb = gridDim.x, b = blockIdx.x;
-    const int q = nb >> 3, rem = nb & 7, xcd = b & 7, loc = b >> 3;
-    const int tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
-    const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
-
-    const int lane = threadIdx.x & 63;
-    const int i = 1 + tx * (64 * WX) + threadIdx.x;              // P index of this lane's column
-    const int j0 = 1 + (ty * WY + threadIdx.y) * RY;             // first row of this thread
-    const int kb = a.k0 + tz * a.kz;
-    const int ke = min(kb + a.kz, a.k1);
-    if (j0 > ny - 2 || kb >= ke) return;                         // wave-uniform
-    if (1 + tx * (64 * WX) + (int)(threadIdx.x & ~63) > nx - 2) return; // whole wave beyond the interior
-    const bool lane_act = (i <= nx - 2);
-    const int ic = min(i, nx - 1);
-    const bool edge = (lane == 0) | (lane == 63);
-    const int ih = lane == 0 ? i - 1 : min(i + 1, nx - 1);
-    const int sy = nx;
-    const idx_t sz = (idx_t)nx * ny;
-    const int dsy = nx - 2;
-    const idx_t dsz = (idx_t)(nx - 2) * (ny - 2);
-
-    int prow[RY], hrow[RY], rrow[RY], drow[RY]; // in-plane offsets (32-bit): P column, x-halo column, ∇V, dPrdτ
-    bool ract[RY];
-#pragma unroll
-    for (int r = 0; r < RY; ++r) {
-        const int j = j0 + r;
-        ract[r] = (j <= ny - 2);
-        const int jr = min(j, ny - 1);
-        prow[r] = jr * sy + ic;
-        hrow[r] = jr * sy + ih;
-        rrow[r] = min(jr, ny - 2) * sy + min(i, nx - 2);
-        drow[r] = (min(j, ny - 2) - 1) * dsy + (min(i, nx - 2) - 1);
-    }
-    const int ylo_off = (j0 - 1) * sy + ic, yhi_off = min(j0 + RY, ny - 1) * sy + ic;
-
-    const T *__restrict__ Pk = a.Pin + (idx_t)kb * sz;       // plane k
-    const T *__restrict__ Rk = a.RHS + (idx_t)kb * sz;
-    T *__restrict__ Dk = a.D + (idx_t)(kb - 1) * dsz;
-
-    T pm[RY], pc[RY], pp[RY], hx[RY], dv[RY], rv[RY], ylo, yhi;
-#pragma unroll
-    for (int r = 0; r < RY; ++r) {
-        pm[r] = Pk[prow[r] - sz];
-        pc[r] = Pk[prow[r]];
-        hx[r] = edge ? Pk[hrow[r]] : (T)0;
-        dv[r] = ld_stream<T, NT>(Dk + drow[r]);
-        rv[r] = ld_stream<T, NT>(Rk + rrow[r]);
-    }
-    ylo = Pk[ylo_off];
-    yhi = Pk[yhi_off];
-    for (int k = kb; k < ke; ++k) {
-        const T *__restrict__ Pn = Pk + sz;
-        const bool more = (k + 1 < ke);
-        T hxn[RY], dvn[RY], rvn[RY], ylon = (T)0, yhin = (T)0;
-#pragma unroll
-        for (int r = 0; r < RY; ++r) {
-            pp[r] = Pn[prow[r]];
-            hxn[r] = (T)0; dvn[r] = (T)0; rvn[r] = (T)0;
-            if (more) {
-                hxn[r] = edge ? Pn[hrow[r]] : (T)0;
-                dvn[r] = ld_stream<T, NT>(Dk + dsz + drow[r]);
-                rvn[r] = ld_stream<T, NT>(Rk + sz + rrow[r]);
-            }
-        }
-        if (more) {
-            ylon = Pn[ylo_off];
-            yhin = Pn[yhi_off];
-        }
-#pragma unroll
-        for (int r = 0; r < RY; ++r) {
-            const T c = pc[r];
-            T w = lane_prev<T>(c), e = lane_next<T>(c);
-            w = lane == 0 ? hx[r] : w;
-            e = lane == 63 ? hx[r] : e;
-            const T s = r == 0 ? ylo : pc[r - 1 < 0 ? 0 : r - 1];
-            const T n = r == RY - 1 ? yhi : pc[r + 1 > RY - 1 ? RY - 1 : r + 1];
-            const T res = poisson_rhs<T>(c, w, e, s, n, pm[r], pp[r], rv[r], a.rho_dt, g);
-            const T dn = dv[r] * a.one_m_damp + a.dtau * res;
-            if (lane_act && ract[r]) {
-                st_stream<T, NT>(Dk + drow[r], dn);
-                store_with_bc<T, NT>(a, i, j0 + r, k, c + a.dtau * dn);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < RY; ++r) {
-            pm[r] = pc[r]; pc[r] = pp[r];
-            hx[r] = hxn[r]; dv[r] = dvn[r]; rv[r] = rvn[r];
-        }
-        ylo = ylon; yhi = yhin;
-        Pk = Pn; Rk += sz; Dk += dsz;
-    }
-}
-
-// ---- variant P: as X, but the memory pipeline is written for the waitcnt pass ---------------------------
+// ---- variant P: z-marching register pipeline, whole-row workgroups, XCD-aware tile order -----------------
+// Same arithmetic as variant Z.  A workgroup is WX waves wide in x (for nx ≤ 64·WX+2 it owns whole rows, so the x-halo
+// lines are hits in its own CU); the grid is 1-D and the hardware's round-robin block→XCD dealing (block b → XCD b mod 8)
+// is undone so that every XCD sweeps one contiguous range of tiles (y-neighbour tiles share an L2 and run together);
+// dPrdτ / ∇V / new Pr are streamed with nontemporal accesses.
 // Every load of the loop body is unconditional (clamped addresses instead of `if`s; the two x-halo lanes share one
 // instruction whose other lanes all read lane 0's address, i.e. one extra cache line), and the z loop is unrolled
 // UNR times so that the plane-ring rotation is pure register renaming: no v_mov of a freshly loaded value, hence no
@@ -1104,170 +1001,6 @@ static hipError_t launch_pipe_auto(hipStream_t s, SweepArgs<T> &a, int kz)
     case 4: return launch_pipe<T, RY, (WY <= 2 ? 4 : 1), WY, NT, UNR, MINW>(s, a, kz);
     case 2: return launch_pipe<T, RY, (WY <= 4 ? 2 : 1), WY, NT, UNR, MINW>(s, a, kz);
     default: return launch_pipe<T, RY, 1, WY, NT, UNR, MINW>(s, a, kz);
-    }
-}
-
-// ---- variant R: plane RING in registers, everything prefetched TWO planes ahead --------------------------
-// hipcc cannot runtime-unroll a loop that contains cross-lane (convergent) operations, so the ring rotation is
-// unrolled by hand: four slots S0..S3 hold planes k-1, k, k+1, k+2; step k issues every load of plane k+2 into the
-// free slot and then computes plane k from registers that were loaded two steps earlier.  No register is moved,
-// no load is conditional (addresses are clamped, stores are predicated), so the waitcnt pass emits counted
-// `s_waitcnt vmcnt(N)` and ≈2 planes × (4·RY+2) wave-loads stay in flight per wave.
-template <class T, int RY>
-struct Slot {
-    T p[RY], hx[RY], dv[RY], rv[RY];
-    T ylo, yhi;
-};
-
-template <class T, int RY, int WX, int WY, bool NT, int MINW>
-__global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep_ring(SweepArgs<T> a, int ntx, int nty)
-{
-    const int nx = a.nx, ny = a.ny, nz = a.nz;
-    const Geo<T> &g = a.g;
-    const int nb = gridDim.x, b = blockIdx.x;
-    const int q = nb >> 3, rem = nb & 7, xcd = b & 7, loc = b >> 3;
-    const int tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
-    const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
-
-    const int lane = threadIdx.x & 63;
-    const int iw = 1 + tx * (64 * WX) + (int)(threadIdx.x & ~63u);
-    const int i = iw + lane;
-    const int j0 = 1 + (ty * WY + threadIdx.y) * RY;
-    const int kb = a.k0 + tz * a.kz;
-    const int ke = min(kb + a.kz, a.k1);
-    if (j0 > ny - 2 || kb >= ke || iw > nx - 2) return;          // wave-uniform
-    const bool lane_act = (i <= nx - 2);
-    const int ic = min(i, nx - 1);
-    const int ih = lane == 63 ? min(i + 1, nx - 1) : iw - 1;
-    const int sy = nx;
-    const idx_t sz = (idx_t)nx * ny;
-    const int dsy = nx - 2;
-    const idx_t dsz = (idx_t)(nx - 2) * (ny - 2);
-    // does this wave touch an x or y face at all?  (wave-uniform: selects the plain-store fast path)
-    const bool wave_xy_face = (iw == 1) || (iw + 63 >= nx - 2) || (j0 == 1) || (j0 + RY - 1 >= ny - 2);
-
-    int prow[RY], hrow[RY], rrow[RY], drow[RY];
-    bool ract[RY];
-#pragma unroll
-    for (int r = 0; r < RY; ++r) {
-        const int j = j0 + r;
-        ract[r] = (j <= ny - 2) && lane_act;
-        const int jr = min(j, ny - 1);
-        prow[r] = jr * sy + ic;
-        hrow[r] = jr * sy + ih;
-        rrow[r] = min(jr, ny - 2) * sy + min(i, nx - 2);
-        drow[r] = (min(j, ny - 2) - 1) * dsy + (min(i, nx - 2) - 1);
-    }
-    const int ylo_off = (j0 - 1) * sy + ic, yhi_off = min(j0 + RY, ny - 1) * sy + ic;
-    const T *__restrict__ P = a.Pin;
-    const T *__restrict__ RHS = a.RHS;
-    T *__restrict__ D = a.D;
-
-    auto load_slot = [&](Slot<T, RY> &s, int kp) {
-        const int kP = min(kp, nz - 1);                 // P plane (faces are valid neighbours)
-        const int kA = min(max(kp, 1), nz - 2);         // plane for the streams that exist on interior planes only
-        const T *__restrict__ Pp = P + (idx_t)kP * sz;
-        const T *__restrict__ Pa = P + (idx_t)kA * sz;
-        const T *__restrict__ Ra = RHS + (idx_t)kA * sz;
-        const T *__restrict__ Da = D + (idx_t)(kA - 1) * dsz;
-#pragma unroll
-        for (int r = 0; r < RY; ++r) {
-            s.p[r] = Pp[prow[r]];
-            s.hx[r] = Pa[hrow[r]];
-            s.dv[r] = ld_stream<T, NT>(Da + drow[r]);
-            s.rv[r] = ld_stream<T, NT>(Ra + rrow[r]);
-        }
-        s.ylo = Pa[ylo_off];
-        s.yhi = Pa[yhi_off];
-    };
-    auto step = [&](const Slot<T, RY> &m, const Slot<T, RY> &c, const Slot<T, RY> &n, Slot<T, RY> &f, int k) {
-        load_slot(f, k + 2);
-        const bool kact = (k < ke);
-        const bool plain = !(wave_xy_face || k == 1 || k == nz - 2);
-        T *__restrict__ Dk = D + (idx_t)(k - 1) * dsz;
-#pragma unroll
-        for (int r = 0; r < RY; ++r) {
-            const T cc = c.p[r];
-            T w = lane_prev<T>(cc), e = lane_next<T>(cc);
-            w = lane == 0 ? c.hx[r] : w;
-            e = lane == 63 ? c.hx[r] : e;
-            const T sv = r == 0 ? c.ylo : c.p[r - 1 < 0 ? 0 : r - 1];
-            const T nv = r == RY - 1 ? c.yhi : c.p[r + 1 > RY - 1 ? RY - 1 : r + 1];
-            const T res = poisson_rhs<T>(cc, w, e, sv, nv, m.p[r], n.p[r], c.rv[r], a.rho_dt, g);
-            const T dn = c.dv[r] * a.one_m_damp + a.dtau * res;
-            const T pn = cc + a.dtau * dn;
-            if (ract[r] && kact) {
-                st_stream<T, NT>(Dk + drow[r], dn);
-                if (plain) st_stream<T, NT>(a.Pout + (idx_t)k * sz + (j0 + r) * sy + i, pn);
-                else store_with_bc<T, NT>(a, i, j0 + r, k, pn);
-            }
-        }
-    };
-
-    Slot<T, RY> S0, S1, S2, S3;
-    {   // prologue: plane kb-1 needs only P
-        const T *__restrict__ Pm = P + (idx_t)(kb - 1) * sz;
-#pragma unroll
-        for (int r = 0; r < RY; ++r) { S0.p[r] = Pm[prow[r]]; S0.hx[r] = S0.dv[r] = S0.rv[r] = (T)0; }
-        S0.ylo = S0.yhi = (T)0;
-    }
-    load_slot(S1, kb);
-    load_slot(S2, kb + 1);
-    for (int k = kb; k < ke; k += 4) {
-        step(S0, S1, S2, S3, k);
-        step(S1, S2, S3, S0, k + 1);
-        step(S2, S3, S0, S1, k + 2);
-        step(S3, S0, S1, S2, k + 3);
-    }
-}
-
-template <class T, int RY, int WX, int WY, bool NT, int MINW>
-static hipError_t launch_ring(hipStream_t s, SweepArgs<T> &a, int kz)
-{
-    a.kz = kz;
-    const int nxi = a.nx - 2, nyi = a.ny - 2, nk = a.k1 - a.k0;
-    const int ntx = (nxi + 64 * WX - 1) / (64 * WX), nty = (nyi + RY * WY - 1) / (RY * WY), ntz = (nk + kz - 1) / kz;
-    hipLaunchKernelGGL((k_pt_sweep_ring<T, RY, WX, WY, NT, MINW>), dim3((unsigned)(ntx * nty * ntz)),
-                       dim3(64 * WX, WY, 1), 0, s, a, ntx, nty);
-    return hipGetLastError();
-}
-template <class T, int RY, int WY, bool NT, int MINW>
-static hipError_t launch_ring_auto(hipStream_t s, SweepArgs<T> &a, int kz)
-{
-    const int nxi = a.nx - 2;
-    int wx = (nxi > 256 ? 8 : nxi > 128 ? 4 : nxi > 64 ? 2 : 1);
-    if (wx * WY > 8) wx = 8 / WY;
-    switch (wx) {
-    case 8: return launch_ring<T, RY, (WY == 1 ? 8 : 1), WY, NT, MINW>(s, a, kz);
-    case 4: return launch_ring<T, RY, (WY <= 2 ? 4 : 1), WY, NT, MINW>(s, a, kz);
-    case 2: return launch_ring<T, RY, (WY <= 4 ? 2 : 1), WY, NT, MINW>(s, a, kz);
-    default: return launch_ring<T, RY, 1, WY, NT, MINW>(s, a, kz);
-    }
-}
-
-template <class T, int RY, int WX, int WY, bool NT>
-static hipError_t launch_xcd(hipStream_t s, SweepArgs<T> &a, int kz)
-{
-    a.kz = kz;
-    const int nxi = a.nx - 2, nyi = a.ny - 2, nk = a.k1 - a.k0;
-    const int ntx = (nxi + 64 * WX - 1) / (64 * WX), nty = (nyi + RY * WY - 1) / (RY * WY), ntz = (nk + kz - 1) / kz;
-    hipLaunchKernelGGL((k_pt_sweep_xcd<T, RY, WX, WY, NT>), dim3((unsigned)(ntx * nty * ntz)), dim3(64 * WX, WY, 1), 0, s,
-                       a, ntx, nty);
-    return hipGetLastError();
-}
-
-// pick the block width from the row length: whole rows per block up to 512 interior cells
-template <class T, int RY, int WY, bool NT>
-static hipError_t launch_xcd_auto(hipStream_t s, SweepArgs<T> &a, int kz, int wx_req)
-{
-    const int nxi = a.nx - 2;
-    int wx = wx_req > 0 ? wx_req : (nxi > 256 ? 8 : nxi > 128 ? 4 : nxi > 64 ? 2 : 1);
-    if (wx * WY > 8) wx = 8 / WY;
-    switch (wx) {
-    case 8: return launch_xcd<T, RY, (WY == 1 ? 8 : 1), WY, NT>(s, a, kz);
-    case 4: return launch_xcd<T, RY, (WY <= 2 ? 4 : 1), WY, NT>(s, a, kz);
-    case 2: return launch_xcd<T, RY, (WY <= 4 ? 2 : 1), WY, NT>(s, a, kz);
-    default: return launch_xcd<T, RY, 1, WY, NT>(s, a, kz);
     }
 }
 
@@ -1570,44 +1303,13 @@ hipError_t pt_sweep(hipStream_t s, int variant, const T *Pin, T *Pout, T *D, con
         return hipGetLastError();
     }
     case 2: return launch_zmarch<T, 2, 4>(s, a, kz);
-    case 3: return launch_zmarch<T, 4, 2>(s, a, kz);
-    case 4: return launch_zmarch<T, 8, 2>(s, a, kz);
-    case 5: return launch_zmarch<T, 1, 4>(s, a, kz);
-    case 6: return launch_zmarch<T, 2, 8>(s, a, kz);
     case 7: return launch_zmarch<T, 4, 4>(s, a, kz);
-    // X family: RY rows/thread, WY wave-rows/block, whole-row blocks, XCD-contiguous tiles; +1 = nontemporal streams
-    case 10: return launch_xcd_auto<T, 2, 1, false>(s, a, kz, 0);
-    case 11: return launch_xcd_auto<T, 2, 1, true>(s, a, kz, 0);
-    case 12: return launch_xcd_auto<T, 4, 1, false>(s, a, kz, 0);
-    case 13: return launch_xcd_auto<T, 4, 1, true>(s, a, kz, 0);
-    case 14: return launch_xcd_auto<T, 2, 2, false>(s, a, kz, 0);
-    case 15: return launch_xcd_auto<T, 2, 2, true>(s, a, kz, 0);
-    case 16: return launch_xcd_auto<T, 1, 2, false>(s, a, kz, 0);
-    case 17: return launch_xcd_auto<T, 1, 2, true>(s, a, kz, 0);
-    case 18: return launch_xcd_auto<T, 2, 4, true>(s, a, kz, 2);   // 2 waves wide, 4 wave-rows
-    case 19: return launch_xcd_auto<T, 1, 4, true>(s, a, kz, 2);
-    // P family: branch-free loads, unrolled plane ring.  <RY, WY, NT, UNR, min waves/SIMD>
+    // P family: <RY rows/thread, WY wave-rows/workgroup, nontemporal streams, unroll, min waves/SIMD>
     case 20: return launch_pipe_auto<T, 2, 1, true, 3, 1>(s, a, kz);
-    case 21: return launch_pipe_auto<T, 2, 1, true, 6, 1>(s, a, kz);
     case 22: return launch_pipe_auto<T, 1, 1, true, 3, 1>(s, a, kz);
-    case 23: return launch_pipe_auto<T, 1, 1, true, 6, 1>(s, a, kz);
-    case 24: return launch_pipe_auto<T, 4, 1, true, 3, 1>(s, a, kz);
-    case 25: return launch_pipe_auto<T, 2, 1, true, 1, 1>(s, a, kz);
     case 26: return launch_pipe_auto<T, 2, 1, false, 3, 1>(s, a, kz);
     case 27: return launch_pipe_auto<T, 1, 2, true, 3, 1>(s, a, kz);
-    case 28: return launch_pipe_auto<T, 2, 2, true, 3, 1>(s, a, kz);
-    case 29: return launch_pipe_auto<T, 1, 1, true, 3, 4>(s, a, kz);   // ≤128 VGPR
-    case 30: return launch_pipe_auto<T, 2, 1, true, 3, 4>(s, a, kz);
-    // R family: 4-slot register ring, 2-plane prefetch.  <RY, WY, NT, min waves/SIMD>
-    case 40: return launch_ring_auto<T, 1, 1, true, 1>(s, a, kz);
-    case 41: return launch_ring_auto<T, 2, 1, true, 1>(s, a, kz);
-    case 42: return launch_ring_auto<T, 1, 2, true, 1>(s, a, kz);
-    case 43: return launch_ring_auto<T, 2, 2, true, 1>(s, a, kz);
-    case 44: return launch_ring_auto<T, 1, 1, false, 1>(s, a, kz);
-    case 45: return launch_ring_auto<T, 2, 1, false, 1>(s, a, kz);
-    case 46: return launch_ring_auto<T, 1, 4, true, 1>(s, a, kz);
-    case 47: return launch_ring_auto<T, 3, 1, true, 1>(s, a, kz);
-    default: return launch_xcd_auto<T, 2, 1, true>(s, a, kz, 0);
+    default: return launch_pipe_auto<T, 1, 1, true, 3, 1>(s, a, kz);
     }
 }
 

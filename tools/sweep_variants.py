@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--nz", type=int, default=None)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--iters", type=int, default=30)
-    ap.add_argument("--variants", default="0,100,200,300,400,500,600")
+    ap.add_argument("--variants", default="0,100,200,700,2000,2200")
     ap.add_argument("--modes", default="strict,fast")
     ap.add_argument("--variants2", default="", help="temporal-blocking (two iterations per launch) shapes to time")
     ap.add_argument("--dtype", default="f64")
