@@ -38,6 +38,15 @@ class SlabPTSolver:
         self.pt = K.pt_params(self.P[0], rho, dt, dtau, damp, dx, dy, dz, bc_kind, owns_outlet, outlet_val, g)
         self.k0, self.k1 = 1 + self.glo, nz - 1 + self.glo          # own interior planes in extended indices
         self.ip, self.id = 0, 0                                    # current Pr / dPrdτ buffer
+        # the exchanged blocks are fixed views of the four buffers: build them once (keeps the per-launch host work small)
+        gr, g, nze = grid, self.glo, self.nze
+        self._blk = {}
+        for ib, Pq in enumerate(self.P):
+            self._blk["P", ib] = (gr.planes(Pq, 1 + g, 2), gr.planes(Pq, 0, 2), gr.planes(Pq, nz - 3 + g, 2),
+                                  gr.planes(Pq, nze - 2, 2))
+        for ib, Dq in enumerate(self.D):
+            self._blk["D", ib] = (gr.planes(Dq, g, 1), gr.planes(Dq, 0, 1), gr.planes(Dq, g + nz - 3, 1),
+                                  gr.planes(Dq, nze - 3, 1))
 
     # ---- state in / out -----------------------------------------------------------------------------------
     def load(self, Pr, dPrdtau, divV):
@@ -46,7 +55,7 @@ class SlabPTSolver:
         self.P[0][:, :, g:g + nz] = Pr
         self.D[0][:, :, g:g + nz - 2] = dPrdtau
         self.R[:, :, g:g + nz] = divV
-        self._exchange(self.P[0], self.D[0], wait=True)            # deep ghosts of the incoming state
+        self._exchange(0, 0, wait=True)                            # deep ghosts of the incoming state
 
     def store(self, Pr, dPrdtau):
         g, nz = self.glo, self.nz
@@ -54,13 +63,14 @@ class SlabPTSolver:
         dPrdtau[:, :, :] = self.D[self.id][:, :, g:g + nz - 2]
 
     # ---- ghost exchange: 2 planes of Pr + 1 plane of dPrdτ per seam ------------------------------------------
-    def _exchange(self, Pq, Dq, wait):
-        gr, g, nz, nze = self.grid, self.glo, self.nz, self.nze
+    def _exchange(self, ip, idd, wait):
+        """Own planes (1,2 | nz-3,nz-2 of Pr; first | last of dPrdτ) → the neighbours' ghost planes, buffers ip / idd."""
+        gr = self.grid
+        ps_lo, pr_lo, ps_hi, pr_hi = self._blk["P", ip]
+        ds_lo, dr_lo, ds_hi, dr_hi = self._blk["D", idd]
         work = gr.start_exchange(
-            to_lower=[gr.planes(Pq, 1 + g, 2), gr.planes(Dq, g, 1)] if g else [],
-            from_lower=[gr.planes(Pq, 0, 2), gr.planes(Dq, 0, 1)] if g else [],
-            to_upper=[gr.planes(Pq, nz - 3 + g, 2), gr.planes(Dq, g + nz - 3, 1)] if self.ghi else [],
-            from_upper=[gr.planes(Pq, nze - 2, 2), gr.planes(Dq, nze - 3, 1)] if self.ghi else [])
+            to_lower=[ps_lo, ds_lo] if self.glo else [], from_lower=[pr_lo, dr_lo] if self.glo else [],
+            to_upper=[ps_hi, ds_hi] if self.ghi else [], from_upper=[pr_hi, dr_hi] if self.ghi else [])
         if wait:
             gr.finish_halo(work)
             return None
@@ -70,7 +80,8 @@ class SlabPTSolver:
         """One pass: two PT iterations (ns3d_pt_sweep2) or one (ns3d_pt_sweep), seam planes first."""
         src, dst = self.P[self.ip], self.P[self.ip ^ 1]
         dsrc = self.D[self.id]
-        ddst = self.D[self.id ^ 1] if two else dsrc
+        idd_out = self.id ^ 1 if two else self.id
+        ddst = self.D[idd_out]
         k0, k1 = self.k0, self.k1
         lo_end = min(k0 + 2, k1) if self.glo else k0
         hi_beg = max(k1 - 2, lo_end) if self.ghi else k1
@@ -85,7 +96,7 @@ class SlabPTSolver:
 
         sweep(k0, lo_end)
         sweep(hi_beg, k1)
-        work = self._exchange(dst, ddst, wait=False)
+        work = self._exchange(self.ip ^ 1, idd_out, wait=False)
         sweep(lo_end, hi_beg)
         self.grid.finish_halo(work)
         self.ip ^= 1

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""End-to-end timing of the reference configurations on one MI355X (full Chorin steps with the real PT convergence loop).
+
+    python tools/run_config.py --script multi --nx 255 --nt 3 [--mode strict|fast] [--compare-fast]
+
+Prints per-step PT iteration counts, seconds per step and the PT-loop throughput; with --compare-fast also runs FAST
+mode on the same case and reports the relative L2 difference of every field (BASELINE north_star: ≤1e-6) and whether the
+iteration counts agree.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from navierstokes3d_amd import kernels as K  # noqa: E402
+from navierstokes3d_amd.driver import run_navierstokes3D, runme  # noqa: E402
+
+
+def run(script, nx, nt, mode, temporal=True):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if script == "multi":
+        out = run_navierstokes3D(nx=nx, nt=nt, mode=mode, temporal=temporal, return_info=True)
+        info, fields = out[-1], dict(zip(("C", "Pr", "Vx", "Vy", "Vz"), out[:5]))
+    else:
+        f, info = runme(nx=nx, nt=nt, mode=mode)
+        fields = {n: K.to_numpy(getattr(f, n)) for n in ("C", "Pr", "Vx", "Vy", "Vz")}
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, info, fields
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--script", default="multi", choices=["multi", "gpu"])
+    ap.add_argument("--nx", type=int, default=255)
+    ap.add_argument("--nt", type=int, default=3)
+    ap.add_argument("--mode", default="strict")
+    ap.add_argument("--compare-fast", action="store_true")
+    a = ap.parse_args()
+    run(a.script, min(a.nx, 63), 1, a.mode)  # warm-up (library load, allocator)
+    wall, info, fields = run(a.script, a.nx, a.nt, a.mode)
+    p = info.params
+    cells = p.nx * p.ny * p.nz
+    its = sum(info.iters)
+    res = {"script": a.script, "grid": [p.nx, p.ny, p.nz], "nt": a.nt, "mode": a.mode, "pt_iters_per_step": info.iters,
+           "last_err_per_step": [e[-1] if e else None for e in info.errs], "wall_s": wall, "s_per_step": wall / a.nt,
+           "Mcells_iter_per_s_whole_run": cells * its / wall / 1e6,
+           "finite": bool(all(np.isfinite(v).all() for v in fields.values()))}
+    if a.compare_fast:
+        wall_f, info_f, fields_f = run(a.script, a.nx, a.nt, "fast")
+        vn = np.sqrt(sum(np.sum(fields[n].astype(np.float64) ** 2) for n in ("Vx", "Vy", "Vz")))
+        rel = {}
+        for n in fields:
+            den = vn if n.startswith("V") else np.sqrt(np.sum(fields[n].astype(np.float64) ** 2))
+            rel[n] = float(np.sqrt(np.sum((fields_f[n] - fields[n]) ** 2)) / den) if den > 0 else 0.0
+        res["fast"] = {"pt_iters_per_step": info_f.iters, "same_iteration_counts": info_f.iters == info.iters,
+                       "wall_s": wall_f, "rel_l2_vs_strict": rel}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
