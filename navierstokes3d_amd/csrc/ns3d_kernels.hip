@@ -1054,10 +1054,12 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
     const idx_t dsz = (idx_t)(nx - 2) * (ny - 2);
     const bool xlo_adj = (gi == 1), xhi_adj = (gi == nx - 2);
     const bool x_s1 = (gi <= nx - 2);
+    // does this tile touch an x or y face of the domain at all?  (scalar: same for the whole workgroup)
+    const bool tile_on_xy_face = (ox <= 1) || (ox + TX - 1 >= nx - 2) || (oy <= 1) || (oy + TY - 1 >= ny - 2);
     const bool x_out = x_s1 && (lx >= 1 || xlo_adj) && (lx <= TX - 2 || xhi_adj);
 
     int poff[CPT], roff[CPT], doff[CPT];
-    bool s1[CPT], outc[CPT], ylo_adj[CPT], yhi_adj[CPT];
+    bool outc[CPT];
 #pragma unroll
     for (int r = 0; r < CPT; ++r) {
         const int lr = wy * CPT + r, gj = oy + lr;
@@ -1065,9 +1067,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
         poff[r] = cj * nx + ci;
         roff[r] = cjj * nx + cii;
         doff[r] = (cjj - 1) * (nx - 2) + (cii - 1);
-        ylo_adj[r] = (gj == 1); yhi_adj[r] = (gj == ny - 2);
-        s1[r] = x_s1 && (gj <= ny - 2);
-        outc[r] = x_out && (gj <= ny - 2) && (lr >= 1 || ylo_adj[r]) && (lr <= TY - 2 || yhi_adj[r]);
+        outc[r] = x_out && (gj <= ny - 2) && (lr >= 1 || gj == 1) && (lr <= TY - 2 || gj == ny - 2);
     }
     // halo ring duties (P⁰ only): A = row below the tile, B = row above, C = the two columns beside it
     const bool hasA = (wy == 0), hasB = (wy == WY - 1), hasC = (tid < 2 * TY);
@@ -1120,7 +1120,6 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
         const T *__restrict__ l0 = L0[cur];
         const T *__restrict__ l1 = L1[cur];
         // ---------------- level 1 at plane k1 (interior planes only) ----------------
-        const bool k1_valid = (k1 >= 1) && (k1 <= nz - 2);
         T p1p[CPT], d1n[CPT];
 #pragma unroll
         for (int r = 0; r < CPT; ++r) {
@@ -1164,13 +1163,18 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
                 T w = l1[lr * TX + max(lx - 1, 0)], e = l1[lr * TX + min(lx + 1, TX - 1)];
                 T sv = r == 0 ? l1[max(lr - 1, 0) * TX + lx] : p1c[r - 1 < 0 ? 0 : r - 1];
                 T nv = r == CPT - 1 ? l1[min(lr + 1, TY - 1) * TX + lx] : p1c[r + 1 > CPT - 1 ? CPT - 1 : r + 1];
-                // boundary rule substituted where the stencil touches a face of P¹
-                if (xlo_adj) w = xface_val<T>(a, false, c, k2);
-                if (xhi_adj) e = xface_val<T>(a, true, c, k2);
-                if (ylo_adj[r]) sv = c;
-                if (yhi_adj[r]) nv = c;
-                const T bv = zlo ? c : p1m[r];
-                const T tv = zhi ? c : p1p[r];
+                // boundary rule substituted where the stencil touches a face of P¹ (workgroup-uniform test first:
+                // interior tiles skip the per-lane selects altogether)
+                T bv = p1m[r], tv = p1p[r];
+                if (tile_on_xy_face) {
+                    const int gjf = oy + lr;
+                    if (xlo_adj) w = xface_val<T>(a, false, c, k2);
+                    if (xhi_adj) e = xface_val<T>(a, true, c, k2);
+                    if (gjf == 1) sv = c;
+                    if (gjf == ny - 2) nv = c;
+                }
+                if (zlo) bv = c;
+                if (zhi) tv = c;
                 bool ok = true;
                 T res = poisson_rhs_ok<T>(c, w, e, sv, nv, bv, tv, r1c[r], a.rho_dt, g, ok);
                 if (NS3D_HAS_SLOW_PATH && __builtin_expect(!ok, 0)) res = poisson_rhs_slow<T>(c, w, e, sv, nv, bv, tv, r1c[r], a.rho_dt, g);
@@ -1179,7 +1183,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
                 if (outc[r]) {
                     st_stream<T, NT>(Dk + doff[r], dn);
                     const int gj = oy + lr;
-                    if (plain_k && !(xlo_adj | xhi_adj | ylo_adj[r] | yhi_adj[r]))
+                    if (plain_k && !tile_on_xy_face) // scalar test: interior tiles and planes store P² only
                         st_stream<T, NT>(a.Pout + (idx_t)k2 * sz + gj * nx + gi, pn);
                     else
                         store_with_bc<T, NT>(a, gi, gj, k2, pn);
@@ -1216,7 +1220,6 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
             d1c[r] = d1n[r];
         }
         hA = hAn; hB = hBn; hC = hCn;
-        (void)k1_valid; (void)s1;
         __syncthreads();
         cur ^= 1;
     }

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libns3d.so")
+LIB_PATH = os.environ.get("NS3D_LIB") or os.path.join(_HERE, "libns3d.so")   # NS3D_LIB: A/B-test another build
 
 NS3D_OK = 0
 NS3D_STRICT, NS3D_FAST, NS3D_ASYNC, NS3D_IEEE_DIV = 0x0, 0x1, 0x2, 0x4
