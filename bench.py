@@ -42,7 +42,14 @@ def cpu_baseline(n, nzs, iters, dtype):
     from oracle import oracle as O
     from navierstokes3d_amd.params import cavity_params
     cores = len(os.sched_getaffinity(0))
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    try:  # respect the cgroup CPU quota of the box (e.g. "1600000 100000" = 16 cores of a 256-thread host)
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
     p = cavity_params(n, nzs)
     npdt = np.float64 if dtype == "f64" else np.float32
     rng = np.random.Generator(np.random.MT19937(12345))

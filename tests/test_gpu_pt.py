@@ -218,3 +218,26 @@ def test_pt_iterate_and_solve_with_temporal_blocking(hip, oracle, grid):
         assert it == it_ref and errs == errs_ref
         assert np.array_equal(hip.to_numpy(dPr), Pr) and np.array_equal(hip.to_numpy(dd), d)
     ctx.close()
+
+
+@pytest.mark.parametrize("grid", [(256, 9, 7), (257, 10, 6), (258, 12, 5), (259, 34, 5), (66, 33, 6), (67, 35, 5),
+                                   (130, 17, 9), (9, 64, 6), (8, 66, 70), (320, 8, 8)])
+def test_pt_sweep2_tile_edge_sizes(hip, oracle, grid):
+    """Grid extents straddling the tile widths/heights (64·WX−2, 4·WY−2 outputs per tile) and the z-chunk length, every
+    tile shape: the two-column / two-row / two-plane overlaps must neither drop nor duplicate a cell."""
+    import torch
+    nx, ny, nz = grid
+    g = geometry(*grid)
+    Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 79)
+    Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
+    _oracle_iters(oracle, Pr, d, rhs, g, 2, 0, True, 0.5)
+    ctx = hip.Context(0, "strict")
+    for shape in (100, 200, 300, 500, 600, 104, 302, 0):
+        ctx.set_pt2_variant(shape)
+        dPr, dout, dd = hip.from_numpy(Pr0), hip.from_numpy(np.full_like(Pr0, 555.0)), hip.from_numpy(d0)
+        ddout = hip.from_numpy(np.full_like(d0, 444.0))
+        hip.pt_sweep2(dPr, dout, dd, ddout, hip.from_numpy(rhs), _params(hip, dPr, g, 0, True, 0.5), ctx=ctx)
+        torch.cuda.synchronize()
+        assert np.array_equal(hip.to_numpy(ddout), d), "dPrdτ differs: shape %d" % shape
+        assert np.array_equal(hip.to_numpy(dout), Pr), "Pr differs: shape %d" % shape
+    ctx.close()
