@@ -80,6 +80,9 @@ int ns3d_set_pt_variant(ns3d_ctx *ctx, int variant);
 /* Temporal blocking: ns3d_pt_iterate / ns3d_pt_solve advance TWO PT iterations per pass over memory where the
  * schedule allows it (same results).  variant < 0 disables, 0 = default tile shape, see DESIGN.md. */
 int ns3d_set_pt2_variant(ns3d_ctx *ctx, int variant);
+/* ns3d_pt_solve replays each residual-check block (nchk iterations) as one HIP graph: -1 = automatically on
+ * launch-bound grids (< 3 M cells), 0 = never, 1 = always.  Same results either way. */
+int ns3d_set_graph_mode(ns3d_ctx *ctx, int mode);
 
 /* Parameters of the fused pseudo-transient path (ns3d_pt_iterate / ns3d_pt_solve). */
 typedef struct ns3d_pt_params {

@@ -6,6 +6,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <vector>
 
 #include "ns3d_launch.h"
 
@@ -33,6 +35,22 @@ struct ns3d_ctx {
     size_t pingpong_d_bytes;
     int pt_variant;
     int pt2_variant; // tile shape of the two-iteration sweep; <0: temporal blocking off
+    int graph_mode;  // HIP-graph replay of residual-check blocks: -1 auto (launch-bound grids), 0 off, 1 on
+    hipEvent_t fence;
+    struct BlockGraph {
+        const void *src, *dst, *dsrc, *ddst, *rhs;
+        void *src_out, *dst_out, *dsrc_out, *ddst_out;
+        int n, mode, v1, v2, esize;
+        bool two;
+        ns3d_pt_params p;
+        hipGraphExec_t exec;
+    };
+    std::vector<BlockGraph> graphs;
+    void clear_graphs()
+    {
+        for (auto &g : graphs) (void)hipGraphExecDestroy(g.exec);
+        graphs.clear();
+    }
 };
 
 #define HIPCHK(ctx, expr)                                                                                   \
@@ -127,11 +145,14 @@ ns3d_ctx *ns3d_create(int device, int flags)
     c->pingpong_d_bytes = 0;
     c->pt_variant = 0;
     c->pt2_variant = 0; // temporal blocking on by default (ns3d_set_pt2_variant(ctx,-1) turns it off)
+    c->graph_mode = -1;
+    c->fence = nullptr;
     c->key_dev = nullptr;
     c->key_host = nullptr;
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc((void **)&c->key_dev, 64)) != hipSuccess ||
-        (e = hipHostMalloc((void **)&c->key_host, 64, hipHostMallocDefault)) != hipSuccess) {
+        (e = hipHostMalloc((void **)&c->key_host, 64, hipHostMallocDefault)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->fence, hipEventDisableTiming)) != hipSuccess) {
         fail(NS3D_ERR_HIP, "ns3d_create: %s", hipGetErrorString(e));
         delete c;
         return nullptr;
@@ -145,6 +166,9 @@ void ns3d_destroy(ns3d_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->own_stream);
+    c->clear_graphs();
+    if (c->fence) (void)hipEventDestroy(c->fence);
     if (c->pingpong) (void)hipFree(c->pingpong);
     if (c->pingpong_d) (void)hipFree(c->pingpong_d);
     if (c->key_dev) (void)hipFree(c->key_dev);
@@ -184,6 +208,13 @@ int ns3d_set_pt_variant(ns3d_ctx *c, int v)
     return NS3D_OK;
 }
 
+int ns3d_set_graph_mode(ns3d_ctx *c, int mode)
+{
+    if (!c) return fail(NS3D_ERR_ARG, "ns3d_set_graph_mode: null context");
+    c->graph_mode = mode < 0 ? -1 : (mode > 0 ? 1 : 0);
+    return NS3D_OK;
+}
+
 int ns3d_set_pt2_variant(ns3d_ctx *c, int v)
 {
     if (!c) return fail(NS3D_ERR_ARG, "ns3d_set_pt2_variant: null context");
@@ -195,10 +226,10 @@ int ns3d_set_pt2_variant(ns3d_ctx *c, int v)
 } // extern "C"
 
 // read back a reduction key: 8-byte D2H into pinned memory + stream sync (the only host round trip of the PT loop)
-static int fetch_key(ns3d_ctx *c, double *out)
+static int fetch_key(ns3d_ctx *c, hipStream_t s, double *out)
 {
-    HIPCHK(c, hipMemcpyAsync(c->key_host, c->key_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->key_host, c->key_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
     double v;
     std::memcpy(&v, c->key_host, sizeof v);
     *out = v;
@@ -233,6 +264,8 @@ static int ensure_pingpong(ns3d_ctx *c, const ns3d_pt_params *p, T **buf)
     if (c->pingpong_bytes < need) {
         if (c->pingpong) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->own_stream));
+            c->clear_graphs();
             HIPCHK(c, hipFree(c->pingpong));
             c->pingpong = nullptr;
             c->pingpong_bytes = 0;
@@ -251,6 +284,8 @@ static int ensure_pingpong_d(ns3d_ctx *c, const ns3d_pt_params *p, T **buf)
     if (c->pingpong_d_bytes < need) {
         if (c->pingpong_d) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->own_stream));
+            c->clear_graphs();
             HIPCHK(c, hipFree(c->pingpong_d));
             c->pingpong_d = nullptr;
             c->pingpong_d_bytes = 0;
@@ -301,6 +336,70 @@ static int pt_iterate_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_p
     return NS3D_OK;
 }
 
+// ---- the PT loop of multi.jl:458-471 ----------------------------------------------------------------------
+// enqueue exactly n iterations on stream s (two per pass where allowed) and leave the result pointers in src/dsrc
+template <class T>
+static hipError_t enqueue_iters(ns3d_ctx *c, hipStream_t s, int n, bool two, T *&src, T *&dst, T *&dsrc, T *&ddst,
+                                const T *divV, const ns3d_pt_params *p)
+{
+    hipError_t e = hipSuccess;
+    for (int it = 0; it < n && e == hipSuccess;) {
+        if (two && it + 2 <= n) {
+            e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_sweep2<T>(s, c->pt2_variant, src, dst, dsrc, ddst, divV, *p, 1, p->nz - 1));
+            T *t = dsrc; dsrc = ddst; ddst = t;
+            it += 2;
+        } else {
+            e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_sweep<T>(s, c->pt_variant, src, dst, dsrc, divV, *p, 1, p->nz - 1));
+            it += 1;
+        }
+        T *t = src; src = dst; dst = t;
+    }
+    return e;
+}
+
+// One residual-check block (nchk iterations) as a HIP graph: launch-bound grids (63×38×38: ≈2 µs of kernel per ≈5 µs
+// launch) replay the whole block with one host call.  Graphs are cached per buffer state in the context.
+template <class T>
+static int run_block_graph(ns3d_ctx *c, hipStream_t s, int n, bool two, T *&src, T *&dst, T *&dsrc, T *&ddst,
+                           const T *divV, const ns3d_pt_params *p)
+{
+    const int mode = mode_of(c, p->dx, p->dy, p->dz);
+    for (auto &g : c->graphs)
+        if (g.src == src && g.dst == dst && g.dsrc == dsrc && g.ddst == ddst && g.rhs == divV && g.n == n && g.two == two &&
+            g.mode == mode && g.v1 == c->pt_variant && g.v2 == c->pt2_variant && g.esize == (int)sizeof(T) &&
+            std::memcmp(&g.p, p, sizeof *p) == 0) {
+            HIPCHK(c, hipGraphLaunch(g.exec, s));
+            src = (T *)g.src_out; dst = (T *)g.dst_out; dsrc = (T *)g.dsrc_out; ddst = (T *)g.ddst_out;
+            return NS3D_OK;
+        }
+    if (c->graphs.size() >= 16) c->clear_graphs();
+    ns3d_ctx::BlockGraph g;
+    g.src = src; g.dst = dst; g.dsrc = dsrc; g.ddst = ddst; g.rhs = divV; g.n = n; g.two = two; g.mode = mode;
+    g.v1 = c->pt_variant; g.v2 = c->pt2_variant; g.esize = (int)sizeof(T); g.p = *p;
+    hipGraph_t graph = nullptr;
+    HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    hipError_t e = enqueue_iters<T>(c, s, n, two, src, dst, dsrc, ddst, divV, p);
+    hipError_t e2 = hipStreamEndCapture(s, &graph);
+    if (e != hipSuccess || e2 != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return fail(NS3D_ERR_HIP, "PT block graph capture: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    }
+    e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(NS3D_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    g.src_out = src; g.dst_out = dst; g.dsrc_out = dsrc; g.ddst_out = ddst;
+    c->graphs.push_back(g);
+    HIPCHK(c, hipGraphLaunch(g.exec, s));
+    return NS3D_OK;
+}
+
+static bool use_graphs(const ns3d_ctx *c, const ns3d_pt_params *p, int nchk)
+{
+    if (c->graph_mode == 0 || nchk < 4) return false;
+    if (c->graph_mode > 0) return true;
+    return (long long)p->nx * p->ny * p->nz < 3ll * 1000 * 1000;    // launch-bound regime
+}
+
 template <class T>
 static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_params *p, double eps, int niter,
                          int nchk, double err_mul, double err_div, int *iters_done, double *err_hist, int max_checks,
@@ -315,25 +414,30 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
     const bool two = use_two(c, p) && niter >= 2;
     T *dsrc = D, *ddst = nullptr;
     if (two && (rc = ensure_pingpong_d<T>(c, p, &ddst))) return rc;
+    // graphs cannot be captured on HIP's null stream: run the loop on the context's own stream, fenced by events
+    const bool graphs = use_graphs(c, p, nchk);
+    hipStream_t s = c->stream;
+    const bool fenced = graphs && (s == nullptr);
+    if (fenced) {
+        s = c->own_stream;
+        HIPCHK(c, hipEventRecord(c->fence, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(s, c->fence, 0));
+    }
     while (iter < niter) {
-        hipError_t e;
-        // two iterations per pass unless that would step over a residual check or the iteration budget
-        const int to_check = nchk > 0 ? nchk - iter % nchk : niter - iter;
-        if (two && to_check >= 2 && iter + 2 <= niter) {
-            e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_sweep2<T>(c->stream, c->pt2_variant, src, dst, dsrc, ddst, divV, *p, 1, p->nz - 1));
-            T *t = dsrc; dsrc = ddst; ddst = t;
-            iter += 2;
+        // iterations until the next residual check (multi.jl:464) or the end of the budget
+        const int n = nchk > 0 ? std::min(nchk - iter % nchk, niter - iter) : niter - iter;
+        if (graphs && n == nchk) {
+            if ((rc = run_block_graph<T>(c, s, n, two, src, dst, dsrc, ddst, divV, p))) return rc;
         } else {
-            e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_sweep<T>(c->stream, c->pt_variant, src, dst, dsrc, divV, *p, 1, p->nz - 1));
-            iter += 1;
+            hipError_t e = enqueue_iters<T>(c, s, n, two, src, dst, dsrc, ddst, divV, p);
+            if (e != hipSuccess) return fail(NS3D_ERR_HIP, "pt_sweep launch: %s", hipGetErrorString(e));
         }
-        if (e != hipSuccess) return fail(NS3D_ERR_HIP, "pt_sweep launch: %s", hipGetErrorString(e));
-        T *t = src; src = dst; dst = t;
+        iter += n;
         if (nchk > 0 && iter % nchk == 0) { // multi.jl:464-469
-            e = DISPATCHG(c, p->dx, p->dy, p->dz, residual_max_key<T>(c->stream, src, divV, *p, c->key_dev));
+            hipError_t e = DISPATCHG(c, p->dx, p->dy, p->dz, residual_max_key<T>(s, src, divV, *p, c->key_dev));
             if (e != hipSuccess) return fail(NS3D_ERR_HIP, "residual launch: %s", hipGetErrorString(e));
             double mx;
-            if ((rc = fetch_key(c, &mx))) return rc;
+            if ((rc = fetch_key(c, s, &mx))) return rc;
             const double err = mx * err_mul / err_div; // maximum(abs.(Rp))*ly^2/psc, multi.jl:466
             if (err_hist && checks < max_checks) err_hist[checks] = err;
             ++checks;
@@ -341,10 +445,14 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
         }
     }
     if (src != Pr)
-        HIPCHK(c, hipMemcpyAsync(Pr, src, plane * p->nz * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(Pr, src, plane * p->nz * sizeof(T), hipMemcpyDeviceToDevice, s));
     if (dsrc != D)
         HIPCHK(c, hipMemcpyAsync(D, dsrc, (size_t)(p->nx - 2) * (p->ny - 2) * (p->nz - 2) * sizeof(T),
-                                 hipMemcpyDeviceToDevice, c->stream));
+                                 hipMemcpyDeviceToDevice, s));
+    if (fenced) {
+        HIPCHK(c, hipEventRecord(c->fence, s));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->fence, 0));
+    }
     if (iters_done) *iters_done = done;
     if (n_checks) *n_checks = checks;
     return NS3D_OK;
@@ -424,7 +532,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
         if (n < 0) return fail(NS3D_ERR_ARG, "ns3d_max_abs: negative length");                               \
         hipError_t e = DISPATCH(c, max_abs_key<T>(c->stream, A, n, c->key_dev));                             \
         if (e != hipSuccess) return fail(NS3D_ERR_HIP, "max_abs launch: %s", hipGetErrorString(e));          \
-        return fetch_key(c, out_host);                                                                       \
+        return fetch_key(c, c->stream, out_host);                                                                       \
     }                                                                                                        \
     extern "C" int ns3d_correct_V_##S(ns3d_ctx *c, T *Vx, T *Vy, T *Vz, const T *Pr, double dt, double rho,  \
                                       double dx, double dy, double dz, int nx, int ny, int nz)               \
@@ -553,7 +661,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
         if (rc) return rc;                                                                                   \
         hipError_t e = DISPATCHG(c, p->dx, p->dy, p->dz, residual_max_key<T>(c->stream, Pr, divV, *p, c->key_dev));                \
         if (e != hipSuccess) return fail(NS3D_ERR_HIP, "residual launch: %s", hipGetErrorString(e));         \
-        return fetch_key(c, out_host);                                                                       \
+        return fetch_key(c, c->stream, out_host);                                                                       \
     }                                                                                                        \
     extern "C" int ns3d_selftest_exact_div_##S(ns3d_ctx *c, double d, long n, unsigned long long seed,        \
                                                long *mismatches)                                             \

@@ -935,8 +935,8 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep_pipe(SweepArgs<
     ylo = Pk[ylo_off];
     yhi = Pk[yhi_off];
     const int klast = ke - 1;
-#pragma unroll UNR
-    for (int k = kb; k < ke; ++k) {
+    for (int k = kb; k < ke; ++k) { // (hipcc cannot runtime-unroll a loop with cross-lane operations; UNR is unused)
+
         // plane k+1 (the auxiliary streams re-read plane klast on the last trip: in bounds, results unused)
         const T *__restrict__ Pn = Pk + sz;
         const idx_t adv = (k < klast) ? 1 : 0;

@@ -88,6 +88,10 @@ class Context:
     def set_pt_variant(self, v):
         L.check(self.lib.ns3d_set_pt_variant(self.handle, int(v)))
 
+    def set_graph_mode(self, mode):
+        """HIP-graph replay of residual-check blocks in pt_solve: -1 auto (launch-bound grids), 0 off, 1 on."""
+        L.check(self.lib.ns3d_set_graph_mode(self.handle, int(mode)))
+
     def set_pt2_variant(self, v):
         """Temporal blocking (two PT iterations per pass) in pt_iterate / pt_solve: v < 0 off, 0 default tile."""
         L.check(self.lib.ns3d_set_pt2_variant(self.handle, int(v)))

@@ -241,3 +241,31 @@ def test_pt_sweep2_tile_edge_sizes(hip, oracle, grid):
         assert np.array_equal(hip.to_numpy(ddout), d), "dPrdτ differs: shape %d" % shape
         assert np.array_equal(hip.to_numpy(dout), Pr), "Pr differs: shape %d" % shape
     ctx.close()
+
+
+@pytest.mark.parametrize("two", [False, True])
+def test_pt_solve_hip_graph_replay(hip, oracle, two):
+    """ns3d_pt_solve with every residual-check block replayed as a HIP graph (forced on; automatic below 3 M cells):
+    same counts, err history and fields as the eager loop and as the oracle — odd nchk, early exit, repeated calls that
+    reuse the cached graphs, with and without temporal blocking."""
+    import torch
+    nx, ny, nz = 40, 24, 24
+    g = geometry(nx, ny, nz)
+    Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 83)
+    rhs *= 1e-3
+    Rp = np.zeros((nx - 2, ny - 2, nz - 2), order="F")
+    ctx = hip.Context(0, "strict")
+    ctx.set_graph_mode(1)
+    ctx.set_pt2_variant(100 if two else -1)
+    for rep in range(2):   # second pass hits the graph cache
+        for eps, niter, nchk in ((-1.0, 75, 15), (5e4, 400, 23), (-1.0, 64, 8), (1e-30, 50, 7)):
+            Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
+            it_ref, errs_ref = oracle.pt_solve(Pr, d, rhs, Rp, g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"],
+                                               g["dz"], 0, True, 0.0, g["g"], eps, niter, nchk, 0.36, 1000.0)
+            dPr, dd = hip.from_numpy(Pr0), hip.from_numpy(d0)
+            it, errs = hip.pt_solve(dPr, dd, hip.from_numpy(rhs), _params(hip, dPr, g, 0, True, 0.0), eps, niter, nchk,
+                                    0.36, 1000.0, ctx=ctx)
+            torch.cuda.synchronize()
+            assert it == it_ref and errs == errs_ref, (rep, eps, niter, nchk)
+            assert np.array_equal(hip.to_numpy(dPr), Pr) and np.array_equal(hip.to_numpy(dd), d)
+    ctx.close()
