@@ -1029,7 +1029,7 @@ static hipError_t launch_pipe_auto(hipStream_t s, SweepArgs<T> &a, int kz)
 // outlet_val; gpu.jl x planes: hydrostatic value).  Faces of P² are stored by the producing thread as in the
 // single sweep.  z planes that are inter-slab halos are not supported here (the z-slab schedule uses single sweeps).
 // =========================================================================================================
-template <class T, int WX, int WY, int CPT, bool NT, int MINW = 1>
+template <class T, int WX, int WY, int CPT, bool NT, int MINW = 1, bool SEPF = false>
 __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a, int ntx, int nty)
 {
     constexpr int TX = 64 * WX, TY = CPT * WY, PX = TX + 2;
@@ -1183,7 +1183,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
                 if (outc[r]) {
                     st_stream<T, NT>(Dk + doff[r], dn);
                     const int gj = oy + lr;
-                    if (plain_k && !tile_on_xy_face) // scalar test: interior tiles and planes store P² only
+                    // SEPF: boundary cells of P² are written by k_pt_faces_* after this kernel (keeps the rare store
+                    // paths — and ≈70 VGPRs of their live state — out of the hot kernel)
+                    if (SEPF || (plain_k && !tile_on_xy_face)) // scalar test: interior tiles and planes store P² only
                         st_stream<T, NT>(a.Pout + (idx_t)k2 * sz + gj * nx + gi, pn);
                     else
                         store_with_bc<T, NT>(a, gi, gj, k2, pn);
@@ -1225,7 +1227,62 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
     }
 }
 
-template <class T, int WX, int WY, int CPT, bool NT, int MINW = 1>
+// ---- boundary cells of P² as separate launches (used with the SEPF form of k_pt_sweep2) ---------------------------
+// Same rule as store_with_bc, evaluated per boundary cell: nearest interior cell (bc_x!, bc_y!, bc_z! in that order ≡ index
+// clamp), outlet plane / hydrostatic x planes on top (multi.jl:176-181, gpu.jl:282-284).
+template <class T>
+__device__ __forceinline__ T face_value(const SweepArgs<T> &a, int i, int j, int k)
+{
+    const int nx = a.nx, ny = a.ny, nz = a.nz;
+    if (a.bc_kind == NS3D_BC_GPU) {
+        if (i == 0) return xface_val<T>(a, false, (T)0, k);
+        if (i == nx - 1) return xface_val<T>(a, true, (T)0, k);
+    } else if (i == nx - 1 && a.owns_outlet) return a.outlet_val;
+    const int ci = min(max(i, 1), nx - 2), cj = min(max(j, 1), ny - 2), ck = min(max(k, 1), nz - 2);
+    return a.Pout[IX3(ci, cj, ck, nx, ny)];
+}
+// x/y boundary ring of the interior planes [k0,k1): one thread per ring cell
+template <class T>
+__global__ __launch_bounds__(256) void k_pt_faces_ring(SweepArgs<T> a)
+{
+    const int nx = a.nx, ny = a.ny;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = a.k0 + blockIdx.y;
+    if (q >= 2 * nx + 2 * (ny - 2)) return;
+    int i, j;
+    if (q < nx) { i = q; j = 0; }
+    else if (q < 2 * nx) { i = q - nx; j = ny - 1; }
+    else { const int r = q - 2 * nx; j = 1 + (r >> 1); i = (r & 1) ? nx - 1 : 0; }
+    a.Pout[IX3(i, j, k, nx, ny)] = face_value<T>(a, i, j, k);
+}
+// whole z face planes (plane 0 when the launch contains plane 1, plane nz-1 when it contains plane nz-2)
+template <class T>
+__global__ __launch_bounds__(256) void k_pt_faces_z(SweepArgs<T> a, int lo, int hi)
+{
+    const int nx = a.nx, ny = a.ny;
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long)nx * ny) return;
+    const int i = (int)(q % nx), j = (int)(q / nx);
+    const int k = (blockIdx.y == 0 && lo) ? 0 : a.nz - 1;
+    (void)hi;
+    a.Pout[IX3(i, j, k, nx, ny)] = face_value<T>(a, i, j, k);
+}
+template <class T>
+static hipError_t launch_faces(hipStream_t s, const SweepArgs<T> &a)
+{
+    const int ring = 2 * a.nx + 2 * (a.ny - 2);
+    hipLaunchKernelGGL(k_pt_faces_ring<T>, dim3((unsigned)((ring + 255) / 256), (unsigned)(a.k1 - a.k0)), dim3(256), 0, s, a);
+    hipError_t e = hipGetLastError();
+    const int lo = (a.k0 == 1 && !a.zlo_halo) ? 1 : 0, hi = (a.k1 == a.nz - 1 && !a.zhi_halo) ? 1 : 0;
+    if (e == hipSuccess && (lo + hi) > 0) {
+        hipLaunchKernelGGL(k_pt_faces_z<T>, dim3((unsigned)(((long)a.nx * a.ny + 255) / 256), (unsigned)(lo + hi)), dim3(256), 0,
+                           s, a, lo, hi);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+template <class T, int WX, int WY, int CPT, bool NT, int MINW = 1, bool SEPF = false>
 static hipError_t launch_sweep2(hipStream_t s, SweepArgs<T> &a, int kz)
 {
     constexpr int TX = 64 * WX, TY = CPT * WY;
@@ -1233,9 +1290,11 @@ static hipError_t launch_sweep2(hipStream_t s, SweepArgs<T> &a, int kz)
     const int nk = a.k1 - a.k0;
     const int ntx = max(1, (a.nx - 4 + (TX - 2) - 1) / (TX - 2)), nty = max(1, (a.ny - 4 + (TY - 2) - 1) / (TY - 2));
     const int ntz = (nk + kz - 1) / kz;
-    hipLaunchKernelGGL((k_pt_sweep2<T, WX, WY, CPT, NT, MINW>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX, WY, 1), 0,
+    hipLaunchKernelGGL((k_pt_sweep2<T, WX, WY, CPT, NT, MINW, SEPF>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX, WY, 1), 0,
                        s, a, ntx, nty);
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (SEPF && e == hipSuccess) e = launch_faces<T>(s, a);
+    return e;
 }
 
 // Two fused PT iterations (Pin,Din) → (Pout,Dout) for the output planes [k0,k1) (k0 = 1, k1 = nz-1: the whole slab).
@@ -1256,12 +1315,16 @@ hipError_t pt_sweep2(hipStream_t s, int variant, const T *Pin, T *Pout, const T 
     int kz = variant % 100;
     const int nxi = p.nx - 2;
     if (variant == 0) {
-        // tile shape by grid size (measured: profiles/r1_sweep*_final.log): large grids → 64×32 columns per workgroup
-        // (least overlap), long z-chunks; cache-resident grids → wide 256×8 tiles, short chunks so that every CU gets
-        // work.  Explicit variants (shape·100 + kz) override.
+        // Tile shape by grid (measured: profiles/r1_sweep*_final.log).  Wide 256×8 tiles with the boundary cells written by
+        // separate launches are fastest whenever the rows fill them (two columns of overlap per 256: nx = 255, 512, …);
+        // otherwise 64×32 tiles (least overlap, 62-column granularity).  Long z-chunks on tall grids, short ones on
+        // cache-resident grids so that every CU gets work.  Explicit variants (shape·100 + kz) override.
         const long long cells = (long long)p.nx * p.ny * p.nz;
         const int nzi = p.nz - 2;
-        if (cells >= 32ll * 1000 * 1000) { shape = 3; kz = nzi >= 384 ? 64 : (nzi >= 192 ? 32 : 16); }
+        const int ntx256 = (p.nx - 4 + 253) / 254 > 0 ? (p.nx - 4 + 253) / 254 : 1;
+        const bool rows_fill_256 = nxi >= 200 && (double)nxi / (256.0 * ntx256) >= 0.95;
+        if (rows_fill_256) { shape = 11; kz = nzi >= 256 ? 32 : 16; }
+        else if (cells >= 32ll * 1000 * 1000) { shape = 3; kz = nzi >= 384 ? 64 : (nzi >= 192 ? 32 : 16); }
         else { shape = nxi > 128 ? 1 : (nxi > 64 ? 2 : 3); kz = nzi >= 64 ? 16 : 8; }
     }
     if (kz <= 0) kz = 32;
@@ -1272,6 +1335,15 @@ hipError_t pt_sweep2(hipStream_t s, int variant, const T *Pin, T *Pout, const T 
     case 4: return launch_sweep2<T, 4, 2, 4, false>(s, a, kz);  // 256 x 8, plain loads/stores
     case 5: return launch_sweep2<T, 4, 1, 4, true>(s, a, kz);   // 256 x 4 (256 threads)
     case 6: return launch_sweep2<T, 2, 2, 4, true>(s, a, kz);   // 128 x 8 (256 threads)
+    // boundary cells by separate launches (SEPF): leaner hot kernel, larger tiles / more workgroups per CU
+    case 7: return launch_sweep2<T, 1, 8, 2, true, 4, true>(s, a, kz);  //  64 x 16, ≤128 VGPRs: two workgroups per CU
+    case 8: return launch_sweep2<T, 2, 4, 2, true, 4, true>(s, a, kz);  // 128 x 8,  ≤128 VGPRs
+    case 9: return launch_sweep2<T, 1, 8, 4, true, 1, true>(s, a, kz);  //  64 x 32
+    case 10: return launch_sweep2<T, 1, 8, 6, true, 1, true>(s, a, kz); //  64 x 48
+    case 11: return launch_sweep2<T, 4, 2, 4, true, 1, true>(s, a, kz); // 256 x 8
+    case 12: return launch_sweep2<T, 2, 4, 6, true, 1, true>(s, a, kz); // 128 x 24
+    case 13: return launch_sweep2<T, 4, 2, 6, true, 1, true>(s, a, kz); // 256 x 12
+    case 14: return launch_sweep2<T, 2, 4, 4, true, 1, true>(s, a, kz); // 128 x 16
     default: // shape by row length: the widest tile whose overlap-2 tiling wastes the fewest lanes
         if (nxi > 128) return launch_sweep2<T, 4, 2, 4, true>(s, a, kz);
         if (nxi > 64) return launch_sweep2<T, 2, 4, 4, true>(s, a, kz);
