@@ -876,9 +876,10 @@ template <class T, bool NT> __device__ __forceinline__ void st_stream(T *p, T v)
 // is undone so that every XCD sweeps one contiguous range of tiles (y-neighbour tiles share an L2 and run together);
 // dPrdτ / ∇V / new Pr are streamed with nontemporal accesses.
 // Every load of the loop body is unconditional (clamped addresses instead of `if`s; the two x-halo lanes share one
-// instruction whose other lanes all read lane 0's address, i.e. one extra cache line), and the z loop is unrolled
-// UNR times so that the plane-ring rotation is pure register renaming: no v_mov of a freshly loaded value, hence no
-// `s_waitcnt vmcnt(0)` at the loop head — the loads of plane k+1 stay in flight while plane k is computed.
+// instruction whose other lanes all read lane 0's address, i.e. one extra cache line), which keeps the loop body one
+// basic block up to the stores so that the waitcnt pass can count outstanding loads instead of draining them.
+// (hipcc refuses to runtime-unroll a loop that contains cross-lane operations, so the plane-ring rotation costs a few
+// v_mov per step; the UNR parameter is kept for experiments only.)
 template <class T, int RY, int WX, int WY, bool NT, int UNR, int MINW>
 __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep_pipe(SweepArgs<T> a, int ntx, int nty)
 {
