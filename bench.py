@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--no-temporal-blocking", action="store_true")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: n x n x nz per GPU (the reference's model); strong: n x n x nz is the GLOBAL grid, split in z")
+    ap.add_argument("--no-autotune", action="store_true", help="built-in tile choice instead of timing the shapes once")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=12)
     a = ap.parse_args()
@@ -170,6 +171,13 @@ def main():
             return
         slab.iterate(n)      # seam planes first, 2-plane ghost exchange behind the interior sweep (slab.py)
 
+    # plan phase, untimed and outside the warmup count: the first two-iteration launch on a grid times the tile shapes
+    # of k_pt_sweep2 and the context keeps the winner (ns3d_set_autotune; every shape gives the same bits)
+    if a.no_autotune:
+        ctx.set_autotune(False)
+    if not a.no_temporal_blocking:
+        run(2)
+        torch.cuda.synchronize()
     run(a.warmup)
     if world > 1:
         dist.barrier()
@@ -220,7 +228,7 @@ def main():
             "config": {"workload": "lid-driven-cavity Poisson-only PT iteration (BASELINE configs[2])",
                        "local_grid": [nx, ny, nz], "global_grid": [nx, ny, grid.nz_g()],
                        "decomposition": "z-slabs x%d" % world, "arith_mode": a.mode, "variant": a.variant,
-                       "residual_after_run": err, "finite": finite},
+                       "pt2_variant": ctx.last_pt2_variant(), "residual_after_run": err, "finite": finite},
             "hbm_gbps_algorithmic": achieved * world,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

@@ -80,6 +80,13 @@ int ns3d_set_pt_variant(ns3d_ctx *ctx, int variant);
 /* Temporal blocking: ns3d_pt_iterate / ns3d_pt_solve advance TWO PT iterations per pass over memory where the
  * schedule allows it (same results).  variant < 0 disables, 0 = default tile shape, see DESIGN.md. */
 int ns3d_set_pt2_variant(ns3d_ctx *ctx, int variant);
+/* Tile shape of the two-iteration sweep when no explicit variant is set: with autotune on (the default) the first
+ * launch on a grid of >= 4 M cells times the candidate shapes on the caller's own arguments (the operation is idempotent,
+ * every shape gives the same bits) and the context remembers the winner; that first call therefore synchronises the
+ * stream.  Off: a built-in choice by grid size.  ns3d_last_pt2_variant: the variant of the latest two-iteration launch
+ * (0 = built-in choice). */
+int ns3d_set_autotune(ns3d_ctx *ctx, int on);
+int ns3d_last_pt2_variant(const ns3d_ctx *ctx);
 /* ns3d_pt_solve replays each residual-check block (nchk iterations) as one HIP graph: -1 = automatically on
  * launch-bound grids (< 3 M cells), 0 = never, 1 = always.  Same results either way. */
 int ns3d_set_graph_mode(ns3d_ctx *ctx, int mode);

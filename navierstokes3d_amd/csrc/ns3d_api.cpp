@@ -36,6 +36,11 @@ struct ns3d_ctx {
     int pt_variant;
     int pt2_variant; // tile shape of the two-iteration sweep; <0: temporal blocking off
     int graph_mode;  // HIP-graph replay of residual-check blocks: -1 auto (launch-bound grids), 0 off, 1 on
+    int autotune;    // time the tile shapes of the two-iteration sweep on first use of a grid (pt2_variant == 0 only)
+    int last_pt2;    // variant of the latest two-iteration launch (0: built-in choice by grid)
+    struct Tuned { int nx, ny, nz, nk, esize, mode, variant; };
+    std::vector<Tuned> tuned;
+    hipEvent_t tune_ev[2];
     hipEvent_t fence;
     struct BlockGraph {
         const void *src, *dst, *dsrc, *ddst, *rhs;
@@ -145,6 +150,9 @@ ns3d_ctx *ns3d_create(int device, int flags)
     c->pingpong_d_bytes = 0;
     c->pt_variant = 0;
     c->pt2_variant = 0; // temporal blocking on by default (ns3d_set_pt2_variant(ctx,-1) turns it off)
+    c->autotune = 1;
+    c->last_pt2 = 0;
+    c->tune_ev[0] = c->tune_ev[1] = nullptr;
     c->graph_mode = -1;
     c->fence = nullptr;
     c->key_dev = nullptr;
@@ -169,6 +177,8 @@ void ns3d_destroy(ns3d_ctx *c)
     (void)hipStreamSynchronize(c->own_stream);
     c->clear_graphs();
     if (c->fence) (void)hipEventDestroy(c->fence);
+    for (int q = 0; q < 2; ++q)
+        if (c->tune_ev[q]) (void)hipEventDestroy(c->tune_ev[q]);
     if (c->pingpong) (void)hipFree(c->pingpong);
     if (c->pingpong_d) (void)hipFree(c->pingpong_d);
     if (c->key_dev) (void)hipFree(c->key_dev);
@@ -214,6 +224,16 @@ int ns3d_set_graph_mode(ns3d_ctx *c, int mode)
     c->graph_mode = mode < 0 ? -1 : (mode > 0 ? 1 : 0);
     return NS3D_OK;
 }
+
+int ns3d_set_autotune(ns3d_ctx *c, int on)
+{
+    if (!c) return fail(NS3D_ERR_ARG, "ns3d_set_autotune: null context");
+    c->autotune = on ? 1 : 0;
+    if (!on) c->tuned.clear();
+    return NS3D_OK;
+}
+
+int ns3d_last_pt2_variant(const ns3d_ctx *c) { return c ? c->last_pt2 : -1; }
 
 int ns3d_set_pt2_variant(ns3d_ctx *c, int v)
 {
@@ -297,6 +317,60 @@ static int ensure_pingpong_d(ns3d_ctx *c, const ns3d_pt_params *p, T **buf)
     return NS3D_OK;
 }
 
+// ---- tile shape of the two-iteration sweep ------------------------------------------------------------------
+// Every shape gives the same bits (tests/test_gpu_pt.py), and which one is fastest depends on how the row length
+// divides into 64/128/256-wide tiles and on how many workgroups the grid yields (profiles/r1b_shapes.log: 128×8 with
+// two workgroups per CU wins at 255×153×153 and 384³, 256×8 at 512³ and 1024³).  So the first automatic launch on a
+// grid times the candidates on the caller's own arguments — the operation is idempotent: inputs and outputs are
+// distinct buffers — and remembers the winner in the context.  Skipped (built-in choice by grid instead) while the
+// stream is being captured, for launches under 4 M cells, after ns3d_set_autotune(ctx, 0), or with an explicit variant.
+template <class T>
+static int pick_pt2_variant(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV,
+                            const ns3d_pt_params *p, int k0, int k1)
+{
+    if (c->pt2_variant > 0) return c->pt2_variant;
+    const int nk = k1 - k0;
+    if (!c->autotune || (long long)p->nx * p->ny * nk < 4ll * 1000 * 1000) return 0;
+    for (const auto &t : c->tuned)
+        if (t.nx == p->nx && t.ny == p->ny && t.nz == p->nz && t.nk == nk && t.esize == (int)sizeof(T) && t.mode == mode)
+            return t.variant;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (cap != hipStreamCaptureStatusNone) return 0;
+    for (int q = 0; q < 2; ++q)
+        if (!c->tune_ev[q] && hipEventCreate(&c->tune_ev[q]) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    static const int shapes[] = {0, 11, 8, 3, 7, 13, 15, 12};   // 0 = the built-in choice (wins ties)
+    static const int chunks[] = {16, 32};
+    int best = 0;
+    float best_ms = 0.f;
+    for (int shape : shapes)
+        for (int kz : chunks) {
+            if (shape == 0 && kz != chunks[0]) continue;
+            const int v = shape ? shape * 100 + kz : 0;
+            bool ok = true;
+            float ms = 0.f;
+            for (int rep = 0; rep < 3 && ok; ++rep) {      // one untimed launch, two timed
+                if (rep == 1) ok = hipEventRecord(c->tune_ev[0], s) == hipSuccess;
+                ok = ok && DISPATCHM(mode, pt_sweep2<T>(s, v, src, dst, dsrc, ddst, divV, *p, k0, k1)) == hipSuccess;
+            }
+            ok = ok && hipEventRecord(c->tune_ev[1], s) == hipSuccess && hipEventSynchronize(c->tune_ev[1]) == hipSuccess &&
+                 hipEventElapsedTime(&ms, c->tune_ev[0], c->tune_ev[1]) == hipSuccess;
+            if (!ok) { (void)hipGetLastError(); return 0; }
+            if (best_ms == 0.f || ms < 0.99f * best_ms) { best_ms = ms; best = v; }
+        }
+    c->tuned.push_back({p->nx, p->ny, p->nz, nk, (int)sizeof(T), mode, best});
+    return best;
+}
+template <class T>
+static hipError_t launch_pt2(ns3d_ctx *c, hipStream_t s, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV,
+                             const ns3d_pt_params *p, int k0, int k1)
+{
+    const int mode = mode_of(c, p->dx, p->dy, p->dz);
+    const int v = pick_pt2_variant<T>(c, s, mode, src, dst, dsrc, ddst, divV, p, k0, k1);
+    c->last_pt2 = v;
+    return DISPATCHM(mode, pt_sweep2<T>(s, v, src, dst, dsrc, ddst, divV, *p, k0, k1));
+}
+
 // n_iters fused sweeps, result left in Pr (one D2D copy when n_iters is odd).  With z halos the scratch
 // buffer's halo planes are seeded from Pr first (a sweep never writes them).
 template <class T>
@@ -318,7 +392,7 @@ static int pt_iterate_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_p
     for (int it = 0; it < n_iters;) {
         hipError_t e;
         if (two && it + 2 <= n_iters) {
-            e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_sweep2<T>(c->stream, c->pt2_variant, src, dst, dsrc, ddst, divV, *p, 1, p->nz - 1));
+            e = launch_pt2<T>(c, c->stream, src, dst, dsrc, ddst, divV, p, 1, p->nz - 1);
             T *t = dsrc; dsrc = ddst; ddst = t;
             it += 2;
         } else {
@@ -345,7 +419,7 @@ static hipError_t enqueue_iters(ns3d_ctx *c, hipStream_t s, int n, bool two, T *
     hipError_t e = hipSuccess;
     for (int it = 0; it < n && e == hipSuccess;) {
         if (two && it + 2 <= n) {
-            e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_sweep2<T>(s, c->pt2_variant, src, dst, dsrc, ddst, divV, *p, 1, p->nz - 1));
+            e = launch_pt2<T>(c, s, src, dst, dsrc, ddst, divV, p, 1, p->nz - 1);
             T *t = dsrc; dsrc = ddst; ddst = t;
             it += 2;
         } else {
@@ -649,9 +723,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
             return fail(NS3D_ERR_ARG, "ns3d_pt_sweep2: z-slab ranks pass ghost-extended buffers, not halo flags"); \
         if (k0 < 1 || k1 > p->nz - 1 || k0 > k1)                                                             \
             return fail(NS3D_ERR_ARG, "ns3d_pt_sweep2: plane range [%d,%d) outside [1,%d)", k0, k1, p->nz - 1); \
-        return finish(c, DISPATCHG(c, p->dx, p->dy, p->dz, pt_sweep2<T>(c->stream, c->pt2_variant < 0 ? 0 : c->pt2_variant, Pr_in, \
-                                                  Pr_out, dPrdtau, dPrdtau_out, divV, *p, k0, k1)),          \
-                      "pt_sweep2");                                                                          \
+        return finish(c, launch_pt2<T>(c, c->stream, Pr_in, Pr_out, dPrdtau, dPrdtau_out, divV, p, k0, k1), "pt_sweep2"); \
     }                                                                                                        \
     extern "C" int ns3d_residual_max_##S(ns3d_ctx *c, const T *Pr, const T *divV, const ns3d_pt_params *p,   \
                                          double *out_host)                                                   \

@@ -250,7 +250,14 @@ __device__ __forceinline__ T poisson_rhs(T c, T w, T e, T s, T n, T b, T t, T dv
 #if defined(NS3D_EXACT_RECIP)
 template <class T> struct Div2Lim;
 template <> struct Div2Lim<double> { static constexpr double lo = 0x1p-700, hi = 0x1p700; };
-template <> struct Div2Lim<float> { static constexpr float lo = 0x1p-40f, hi = 0x1p40f; };
+template <> struct Div2Lim<float> { static constexpr float lo = 0x1p-60f, hi = 0x1p70f; };
+// Value-based form of the same guard (k_pt_sweep2): if every P in a stencil is zero or has 2^-640 < |P| < 2^690, every
+// second difference x = (e−c)−(c−w) is zero or lies in Div2Lim's range — |x| ≤ 4·2^690, and a non-zero x is a multiple
+// of the smallest ulp among its operands, ≥ 2^-640·2^-52.  One test per VALUE (as it is loaded or produced) replaces
+// three tests per stencil.  fp32: 2^-35 < |P| < 2^68 with 24-bit significands.
+template <class T> struct ValLim;
+template <> struct ValLim<double> { static constexpr double lo = 0x1p-640, hi = 0x1p690; };
+template <> struct ValLim<float> { static constexpr float lo = 0x1p-35f, hi = 0x1p68f; };
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double abs_(double a) { return __builtin_fabs(a); }
@@ -268,6 +275,37 @@ __device__ __forceinline__ T div2_known(T x, T d, T r, bool &ok)
     const bool z = (x == (T)0);
     ok = ok & (z | ((ax > Div2Lim<T>::lo) & (ax < Div2Lim<T>::hi)));   // bitwise on purpose: no short-circuit branches
     return z ? x : q2;
+}
+__device__ __forceinline__ double copysign_(double a, double b) { return __builtin_copysign(a, b); }
+__device__ __forceinline__ float copysign_(float a, float b) { return __builtin_copysignf(a, b); }
+template <class T>
+__device__ __forceinline__ bool val_ok(T v)
+{
+    const T av = abs_(v);
+    return (v == (T)0) | ((av > ValLim<T>::lo) & (av < ValLim<T>::hi));
+}
+// x/d/d for a dividend already known to be zero or inside Div2Lim's range; d > 0, so the quotient carries x's sign
+// (the copysign only matters for x = −0, where the FMA sequence would give +0)
+template <class T>
+__device__ __forceinline__ T div2_known_nochk(T x, T d, T r)
+{
+    T q = x * r;
+    T e = fma_(-q, d, x);
+    q = fma_(e, r, q);
+    T q2 = q * r;
+    e = fma_(-q2, d, q);
+    q2 = fma_(e, r, q2);
+    return copysign_(q2, x);
+}
+template <class T>
+__device__ __forceinline__ T poisson_rhs_nochk(T c, T w, T e, T s, T n, T b, T t, T dv, T rho_dt, const Geo<T> &g)
+{
+    const T d2x = (e - c) - (c - w);
+    const T d2y = (n - c) - (c - s);
+    const T d2z = (t - c) - (c - b);
+    const T lap = (div2_known_nochk<T>(d2x, g.dx, g.rdx) + div2_known_nochk<T>(d2y, g.dy, g.rdy)) +
+                  div2_known_nochk<T>(d2z, g.dz, g.rdz);
+    return lap - rho_dt * dv;
 }
 template <class T>
 __device__ __forceinline__ T poisson_rhs_ok(T c, T w, T e, T s, T n, T b, T t, T dv, T rho_dt, const Geo<T> &g, bool &ok)
@@ -300,6 +338,13 @@ __device__ __forceinline__ T poisson_rhs_slow(T c, T w, T e, T s, T n, T b, T t,
 {
     return poisson_rhs<T>(c, w, e, s, n, b, t, dv, rho_dt, g);
 }
+template <class T>
+__device__ __forceinline__ T poisson_rhs_nochk(T c, T w, T e, T s, T n, T b, T t, T dv, T rho_dt, const Geo<T> &g)
+{
+    return poisson_rhs<T>(c, w, e, s, n, b, t, dv, rho_dt, g);
+}
+template <class T>
+__device__ __forceinline__ bool val_ok(T) { return true; }
 #define NS3D_HAS_SLOW_PATH 0
 #endif
 
@@ -1034,8 +1079,17 @@ template <class T, int WX, int WY, int CPT, bool NT, int MINW = 1, bool SEPF = f
 __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a, int ntx, int nty)
 {
     constexpr int TX = 64 * WX, TY = CPT * WY, PX = TX + 2;
+    // measured on MI355X (512³, 384³; fp64 and fp32): only the fp64 256×8 separate-faces kernel gains from the early
+    // loads; fp32 would drop from two workgroups per CU to one (142 instead of 124 VGPRs)
+    constexpr bool EARLY = sizeof(T) == 8 && WX == 4 && WY == 2 && CPT == 4 && SEPF;
     __shared__ T L0[2][(TY + 2) * PX]; // P⁰ plane with halo ring: element (lx+1, lr+1)
     __shared__ T L1[2][TY * TX];       // P¹ plane
+#if NS3D_HAS_SLOW_PATH
+    // exact-reciprocal STRICT build: `Lbad` becomes (and stays) non-zero once any value that entered this tile's
+    // stencils fails val_ok; from then on the tile evaluates its stencils with plain IEEE divisions.  Values are tested
+    // once, by the thread that loads or produces them, and the flag travels through the same barrier as the value.
+    __shared__ int Lbad;
+#endif
     const int nx = a.nx, ny = a.ny, nz = a.nz;
     const Geo<T> &g = a.g;
     const int nb = gridDim.x, b = blockIdx.x;
@@ -1089,6 +1143,17 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
     T d1c[CPT], r1c[CPT];               // d¹[k2], ∇V[k2]
     T d0[CPT], r0[CPT];                 // d⁰[k1], ∇V[k1]
     T hA = (T)0, hB = (T)0, hC = (T)0;  // halo ring values of plane k1+1 (to be published at the end of the step)
+#if NS3D_HAS_SLOW_PATH
+    // boundary values substituted into level-2 stencils (outlet value, hydrostatic x planes) are launch constants
+    bool bad = false;
+    if (a.bc_kind == NS3D_BC_GPU) {
+        const T hmin = (a.rho_g * (T)1.5) * g.dz, hmax = (a.rho_g * ((T)(nz - 2) + (T)0.5)) * g.dz;
+        // |h| is monotone in k, and a non-zero h+100 is at least half an ulp of 100: the end values decide
+        bad = !(val_ok<T>(hmin) && val_ok<T>(hmax) && val_ok<T>(hmin + (T)100) && val_ok<T>(hmax + (T)100));
+    } else if (a.owns_outlet) bad = !val_ok<T>(a.outlet_val);
+    if (tid == 0) Lbad = 0;
+    __syncthreads();
+#endif
 
     // ---- prologue: planes kb-2 (clamped), kb-1, kb of P⁰; streams of plane kb-1; publish plane kb-1 ----
     {
@@ -1104,10 +1169,23 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
             r0[r] = ld_stream<T, NT>(RHS + (idx_t)ka * sz + roff[r]);
             p1m[r] = p1c[r] = d1c[r] = r1c[r] = (T)0;
             L0[0][(wy * CPT + r + 1) * PX + lx + 1] = p0c[r];
+#if NS3D_HAS_SLOW_PATH
+            bad |= !val_ok<T>(p0m[r]); bad |= !val_ok<T>(p0c[r]);       // p0p is tested when it is first used (step 0)
+#endif
         }
+#if NS3D_HAS_SLOW_PATH
+        { // halo ring of the first published plane
+            T v;
+            if (hasA) { v = Pc[offA]; L0[0][ldsA] = v; bad |= !val_ok<T>(v); }
+            if (hasB) { v = Pc[offB]; L0[0][ldsB] = v; bad |= !val_ok<T>(v); }
+            if (hasC) { v = Pc[offC]; L0[0][ldsC] = v; bad |= !val_ok<T>(v); }
+            if (bad) Lbad = 1;
+        }
+#else
         if (hasA) L0[0][ldsA] = Pc[offA];
         if (hasB) L0[0][ldsB] = Pc[offB];
         if (hasC) L0[0][ldsC] = Pc[offC];
+#endif
         if (hasA) hA = Pp[offA];
         if (hasB) hB = Pp[offB];
         if (hasC) hC = Pp[offC];
@@ -1120,8 +1198,39 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
         const int k1 = kb - 1 + s, k2 = k1 - 1;
         const T *__restrict__ l0 = L0[cur];
         const T *__restrict__ l1 = L1[cur];
+        // ---------------- the loads of the next step: plane k1+2 of P⁰ (+ halo ring), and with EARLY also d⁰/∇V of
+        // plane k1+1 into registers of their own.  EARLY issues them before level 1, so that when step s+1 waits for
+        // them the stores of this step (same in-order counter) are a whole level old; it costs 4·CPT VGPRs.  Otherwise
+        // P⁰ is fetched between the levels and d⁰/∇V after level 2, straight into d0/r0. ----------------
+        T p0n[CPT], d0n[EARLY ? CPT : 1], r0n[EARLY ? CPT : 1], hAn = (T)0, hBn = (T)0, hCn = (T)0;
+        auto issue_next = [&]() {
+            const int kp = min(k1 + 2, nz - 1);
+            const int ka = min(max(k1 + 1, 1), nz - 2);
+            const T *__restrict__ Pn = P + (idx_t)kp * sz;
+#pragma unroll
+            for (int r = 0; r < CPT; ++r) {
+                p0n[r] = Pn[poff[r]];
+                if constexpr (EARLY) {
+                    d0n[r] = ld_stream<T, NT>(Din + (idx_t)(ka - 1) * dsz + doff[r]);
+                    r0n[r] = ld_stream<T, NT>(RHS + (idx_t)ka * sz + roff[r]);
+                }
+            }
+            (void)ka;
+            if (hasA) hAn = Pn[offA];
+            if (hasB) hBn = Pn[offB];
+            if (hasC) hCn = Pn[offC];
+        };
+        if constexpr (EARLY) issue_next();
         // ---------------- level 1 at plane k1 (interior planes only) ----------------
         T p1p[CPT], d1n[CPT];
+#if NS3D_HAS_SLOW_PATH
+#pragma unroll
+        for (int r = 0; r < CPT; ++r) bad |= !val_ok<T>(p0p[r]);  // plane k1+1 of P⁰, first use
+        // wave-uniform: the tile's sticky flag (published with the values by the last barrier) or a lane's own finding
+        const bool slow1 = (__builtin_amdgcn_readfirstlane(Lbad) != 0) || (__builtin_amdgcn_ballot_w64(bad) != 0);
+#endif
+        // one (wave-uniform) branch per level, not per cell: the CPT independent cells stay interleavable
+        auto level1 = [&](auto slow_tag) {
 #pragma unroll
         for (int r = 0; r < CPT; ++r) {
             const int lr = wy * CPT + r;
@@ -1129,34 +1238,29 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
             const T w = l0[(lr + 1) * PX + lx], e = l0[(lr + 1) * PX + lx + 2];
             const T sv = r == 0 ? l0[lr * PX + lx + 1] : p0c[r - 1 < 0 ? 0 : r - 1];
             const T nv = r == CPT - 1 ? l0[(lr + 2) * PX + lx + 1] : p0c[r + 1 > CPT - 1 ? CPT - 1 : r + 1];
-            bool ok = true;
-            T res = poisson_rhs_ok<T>(c, w, e, sv, nv, p0m[r], p0p[r], r0[r], a.rho_dt, g, ok);
-            if (NS3D_HAS_SLOW_PATH && __builtin_expect(!ok, 0)) res = poisson_rhs_slow<T>(c, w, e, sv, nv, p0m[r], p0p[r], r0[r], a.rho_dt, g);
+            const T res = decltype(slow_tag)::value
+                              ? poisson_rhs_slow<T>(c, w, e, sv, nv, p0m[r], p0p[r], r0[r], a.rho_dt, g)
+                              : poisson_rhs_nochk<T>(c, w, e, sv, nv, p0m[r], p0p[r], r0[r], a.rho_dt, g);
             d1n[r] = d0[r] * a.one_m_damp + a.dtau * res;
             p1p[r] = c + a.dtau * d1n[r];
         }
-        // ---------------- issue the loads of the next step (hidden behind level 2) ----------------
-        T p0n[CPT], hAn = (T)0, hBn = (T)0, hCn = (T)0;
-        {
-            const int kp = min(k1 + 2, nz - 1);
-            const int ka = min(max(k1 + 1, 1), nz - 2);
-            const T *__restrict__ Pn = P + (idx_t)kp * sz;
+        };
+#if NS3D_HAS_SLOW_PATH
+        if (__builtin_expect(slow1, 0)) level1(std::true_type{});
+        else level1(std::false_type{});
 #pragma unroll
-            for (int r = 0; r < CPT; ++r) {
-                p0n[r] = Pn[poff[r]];
-                r1c[r] = r1c[r]; // (kept: ∇V[k2] is last step's r0)
-            }
-            if (hasA) hAn = Pn[offA];
-            if (hasB) hBn = Pn[offB];
-            if (hasC) hCn = Pn[offC];
-            // d⁰/∇V of plane k1+1 overwrite d0/r0 only after level 1 consumed them (below, after level 2's use of r1c)
-            (void)ka;
-        }
+        for (int r = 0; r < CPT; ++r) bad |= !val_ok<T>(p1p[r]);  // P¹ of plane k1: top neighbour of level 2 below
+        const bool slow2 = slow1 || (__builtin_amdgcn_ballot_w64(bad) != 0);
+#else
+        level1(std::false_type{});
+#endif
+        if constexpr (!EARLY) issue_next();
         // ---------------- level 2 at plane k2 ----------------
         if (s >= 2) {
             const bool zlo = (k2 == 1), zhi = (k2 == nz - 2);
             const bool plain_k = !(zlo || zhi);
             T *__restrict__ Dk = D + (idx_t)(k2 - 1) * dsz;
+            auto level2 = [&](auto slow_tag) {
 #pragma unroll
             for (int r = 0; r < CPT; ++r) {
                 const int lr = wy * CPT + r;
@@ -1176,9 +1280,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
                 }
                 if (zlo) bv = c;
                 if (zhi) tv = c;
-                bool ok = true;
-                T res = poisson_rhs_ok<T>(c, w, e, sv, nv, bv, tv, r1c[r], a.rho_dt, g, ok);
-                if (NS3D_HAS_SLOW_PATH && __builtin_expect(!ok, 0)) res = poisson_rhs_slow<T>(c, w, e, sv, nv, bv, tv, r1c[r], a.rho_dt, g);
+                const T res = decltype(slow_tag)::value
+                                  ? poisson_rhs_slow<T>(c, w, e, sv, nv, bv, tv, r1c[r], a.rho_dt, g)
+                                  : poisson_rhs_nochk<T>(c, w, e, sv, nv, bv, tv, r1c[r], a.rho_dt, g);
                 const T dn = d1c[r] * a.one_m_damp + a.dtau * res;
                 const T pn = c + a.dtau * dn;
                 if (outc[r]) {
@@ -1192,15 +1296,27 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
                         store_with_bc<T, NT>(a, gi, gj, k2, pn);
                 }
             }
+            };
+#if NS3D_HAS_SLOW_PATH
+            if (__builtin_expect(slow2, 0)) level2(std::true_type{});
+            else level2(std::false_type{});
+#else
+            level2(std::false_type{});
+#endif
         }
-        // ---------------- streams of plane k1+1 for the next level 1 ----------------
+        // ---------------- streams of plane k1+1 for the next level 1 (∇V[k1] becomes level 2's ∇V[k2]) ----------------
         {
             const int ka = min(max(k1 + 1, 1), nz - 2);
 #pragma unroll
             for (int r = 0; r < CPT; ++r) {
                 r1c[r] = r0[r];
-                d0[r] = ld_stream<T, NT>(Din + (idx_t)(ka - 1) * dsz + doff[r]);
-                r0[r] = ld_stream<T, NT>(RHS + (idx_t)ka * sz + roff[r]);
+                if constexpr (EARLY) {
+                    d0[r] = d0n[r];
+                    r0[r] = r0n[r];
+                } else {
+                    d0[r] = ld_stream<T, NT>(Din + (idx_t)(ka - 1) * dsz + doff[r]);
+                    r0[r] = ld_stream<T, NT>(RHS + (idx_t)ka * sz + roff[r]);
+                }
             }
         }
         // ---------------- publish plane k1+1 of P⁰ and plane k1 of P¹ into the other LDS buffers ----------------
@@ -1215,6 +1331,12 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
         if (hasA) n0[ldsA] = hA;
         if (hasB) n0[ldsB] = hB;
         if (hasC) n0[ldsC] = hC;
+#if NS3D_HAS_SLOW_PATH
+        if (hasA) bad |= !val_ok<T>(hA);
+        if (hasB) bad |= !val_ok<T>(hB);
+        if (hasC) bad |= !val_ok<T>(hC);
+        if (bad) Lbad = 1;
+#endif
         // ---------------- rotate the z rings ----------------
 #pragma unroll
         for (int r = 0; r < CPT; ++r) {
@@ -1341,10 +1463,15 @@ hipError_t pt_sweep2(hipStream_t s, int variant, const T *Pin, T *Pout, const T 
     case 8: return launch_sweep2<T, 2, 4, 2, true, 4, true>(s, a, kz);  // 128 x 8,  ≤128 VGPRs
     case 9: return launch_sweep2<T, 1, 8, 4, true, 1, true>(s, a, kz);  //  64 x 32
     case 10: return launch_sweep2<T, 1, 8, 6, true, 1, true>(s, a, kz); //  64 x 48
-    case 11: return launch_sweep2<T, 4, 2, 4, true, 1, true>(s, a, kz); // 256 x 8
+    case 11: return launch_sweep2<T, 4, 2, 4, true, (sizeof(T) == 4 ? 4 : 1), true>(s, a, kz); // 256 x 8 (fp32: four waves per SIMD = ≤128 VGPRs = two workgroups per CU)
     case 12: return launch_sweep2<T, 2, 4, 6, true, 1, true>(s, a, kz); // 128 x 24
     case 13: return launch_sweep2<T, 4, 2, 6, true, 1, true>(s, a, kz); // 256 x 12
     case 14: return launch_sweep2<T, 2, 4, 4, true, 1, true>(s, a, kz); // 128 x 16
+    // 256-thread workgroups, two or more per CU: independent barrier groups on one CU
+    case 15: return launch_sweep2<T, 2, 2, 4, true, 1, true>(s, a, kz); // 128 x 8
+    case 16: return launch_sweep2<T, 2, 2, 6, true, 1, true>(s, a, kz); // 128 x 12
+    case 17: return launch_sweep2<T, 1, 4, 6, true, 1, true>(s, a, kz); //  64 x 24
+    case 18: return launch_sweep2<T, 1, 4, 4, true, 1, true>(s, a, kz); //  64 x 16
     default: // shape by row length: the widest tile whose overlap-2 tiling wastes the fewest lanes
         if (nxi > 128) return launch_sweep2<T, 4, 2, 4, true>(s, a, kz);
         if (nxi > 64) return launch_sweep2<T, 2, 4, 4, true>(s, a, kz);
@@ -1432,7 +1559,8 @@ hipError_t residual_max_key(hipStream_t s, const T *Pr, const T *divV, const ns3
 
 // ---------------------------------------------------------------------------------------------------------
 // Self-test of div_by_known against the hardware's IEEE division: n pseudo-random dividends per launch (random
-// significands over 120 binades, plus quotients planted next to representable numbers and rounding midpoints).
+// significands over 120 binades — one in four over the whole guarded range and beyond it —, plus quotients planted next
+// to representable numbers and rounding midpoints).
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long splitmix(unsigned long long &st)
 {
@@ -1451,7 +1579,7 @@ __global__ __launch_bounds__(256) void k_divtest(T d, T r, long n, unsigned long
         T x;
         if (sizeof(T) == 8) {
             const unsigned long long mant = u & 0x000FFFFFFFFFFFFFull, sign = u & 0x8000000000000000ull;
-            const unsigned long long expo = 1023 - 60 + (v % 120);
+            const unsigned long long expo = ((v >> 32) & 3) ? 1023 - 60 + (v % 120) : 1023 - 720 + (v % 1440);  // 1 in 4 over the guard's whole range and beyond
             double xd = __longlong_as_double((long long)(sign | (expo << 52) | mant));
             if ((v >> 60) & 1) { // plant the quotient next to a representable number / midpoint: x ≈ qc·d
                 double qc = xd, prod = qc * (double)d;
@@ -1461,7 +1589,8 @@ __global__ __launch_bounds__(256) void k_divtest(T d, T r, long n, unsigned long
             x = (T)xd;
         } else {
             const unsigned int w = (unsigned int)u;
-            const unsigned int mant = w & 0x007FFFFFu, sign = w & 0x80000000u, expo = 127 - 20 + (unsigned int)(v % 40);
+            const unsigned int mant = w & 0x007FFFFFu, sign = w & 0x80000000u,
+                               expo = ((v >> 32) & 3) ? 127 - 20 + (unsigned int)(v % 40) : 127 - 80 + (unsigned int)(v % 160);
             float xf = __uint_as_float(sign | (expo << 23) | mant);
             if ((v >> 60) & 1) xf = __uint_as_float(__float_as_uint(xf * (float)d) + (unsigned int)((v >> 56) & 7) - 3u);
             x = (T)xf;
@@ -1476,6 +1605,9 @@ __global__ __launch_bounds__(256) void k_divtest(T d, T r, long n, unsigned long
         if (ok) {
             if (sizeof(T) == 8) same = same && (__double_as_longlong((double)a2) == __double_as_longlong((double)b2));
             else same = same && (__float_as_uint((float)a2) == __float_as_uint((float)b2));
+            const T a3 = div2_known_nochk<T>(x, d, r);   // k_pt_sweep2's form (guarded per value, same dividend range)
+            if (sizeof(T) == 8) same = same && (__double_as_longlong((double)a3) == __double_as_longlong((double)b2));
+            else same = same && (__float_as_uint((float)a3) == __float_as_uint((float)b2));
         }
 #endif
         nb += same ? 0 : 1;

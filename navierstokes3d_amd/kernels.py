@@ -92,6 +92,14 @@ class Context:
         """HIP-graph replay of residual-check blocks in pt_solve: -1 auto (launch-bound grids), 0 off, 1 on."""
         L.check(self.lib.ns3d_set_graph_mode(self.handle, int(mode)))
 
+    def set_autotune(self, on):
+        """Time the tile shapes of the two-iteration sweep on the first launch per grid (default on; same results)."""
+        L.check(self.lib.ns3d_set_autotune(self.handle, int(bool(on))))
+
+    def last_pt2_variant(self):
+        """Variant (shape·100 + z-chunk) of the latest two-iteration launch; 0 = built-in choice by grid."""
+        return int(self.lib.ns3d_last_pt2_variant(self.handle))
+
     def set_pt2_variant(self, v):
         """Temporal blocking (two PT iterations per pass) in pt_iterate / pt_solve: v < 0 off, 0 default tile."""
         L.check(self.lib.ns3d_set_pt2_variant(self.handle, int(v)))

@@ -61,7 +61,7 @@ SIGNATURES = {
 }
 CONTEXT_SYMBOLS = ["ns3d_version", "ns3d_last_error", "ns3d_create", "ns3d_destroy", "ns3d_flags",
                    "ns3d_set_stream", "ns3d_use_own_stream", "ns3d_get_stream", "ns3d_sync", "ns3d_set_pt_variant",
-                   "ns3d_set_pt2_variant", "ns3d_set_graph_mode"]
+                   "ns3d_set_pt2_variant", "ns3d_set_graph_mode", "ns3d_set_autotune", "ns3d_last_pt2_variant"]
 
 
 def exported_symbols():
@@ -100,6 +100,9 @@ def load():
     lib.ns3d_set_pt_variant.argtypes = [_P, _I]
     lib.ns3d_set_pt2_variant.argtypes = [_P, _I]
     lib.ns3d_set_graph_mode.argtypes = [_P, _I]
+    lib.ns3d_set_autotune.argtypes = [_P, _I]
+    lib.ns3d_last_pt2_variant.argtypes = [_P]
+    lib.ns3d_last_pt2_variant.restype = _I
     for name, args in SIGNATURES.items():
         for suf in ("f64", "f32"):
             fn = getattr(lib, "ns3d_%s_%s" % (name, suf))

@@ -158,7 +158,8 @@ def test_pt_f32(hip, oracle):
 
 
 # ---- temporal blocking: two PT iterations per pass over memory -------------------------------------------------
-SHAPES2 = [0, 100, 200, 300, 400, 500, 600, 103, 207, 101, 364, 316, 700, 800, 900, 1000, 1100, 1200, 703, 1002, 904]
+SHAPES2 = [0, 100, 200, 300, 400, 500, 600, 103, 207, 101, 364, 316, 700, 800, 900, 1000, 1100, 1200, 703, 1002, 904,
+           1300, 1400, 1500, 1600, 1700, 1800, 1503, 1605]
 GRIDS2 = GRIDS + [(260, 19, 9), (131, 40, 6), (66, 70, 5)]
 
 
@@ -232,7 +233,7 @@ def test_pt_sweep2_tile_edge_sizes(hip, oracle, grid):
     Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
     _oracle_iters(oracle, Pr, d, rhs, g, 2, 0, True, 0.5)
     ctx = hip.Context(0, "strict")
-    for shape in (100, 200, 300, 500, 600, 104, 302, 0, 700, 800, 900, 1000, 1100, 1200, 1003):
+    for shape in (100, 200, 300, 500, 600, 104, 302, 0, 700, 800, 900, 1000, 1100, 1200, 1003, 1500, 1600, 1700, 1800):
         ctx.set_pt2_variant(shape)
         dPr, dout, dd = hip.from_numpy(Pr0), hip.from_numpy(np.full_like(Pr0, 555.0)), hip.from_numpy(d0)
         ddout = hip.from_numpy(np.full_like(d0, 444.0))
@@ -268,4 +269,92 @@ def test_pt_solve_hip_graph_replay(hip, oracle, two):
             torch.cuda.synchronize()
             assert it == it_ref and errs == errs_ref, (rep, eps, niter, nchk)
             assert np.array_equal(hip.to_numpy(dPr), Pr) and np.array_equal(hip.to_numpy(dd), d)
+    ctx.close()
+
+
+# ---- the exact-division guard: values far outside the range in which the reciprocal sequence is proven exact -----------
+def _bits_equal(a, b):
+    """Bit-for-bit (signed zeros included); NaNs compare equal to NaNs whatever their payload."""
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    u = np.uint64 if a.dtype == np.float64 else np.uint32
+    nan = np.isnan(a) & np.isnan(b)
+    return bool(np.all((a.view(u) == b.view(u)) | nan))
+
+
+def _extreme_fields(nx, ny, nz, dtype, seed, mode):
+    """Pressure fields that exercise the guard of STRICT's division-by-known-divisor (the cases it must hand to the plain
+    IEEE division; an unguarded reciprocal sequence mis-rounds ≈30 % of the dividends near 1e-308 / 1e-38):
+      dense   — 30 % of the cells replaced by zeros, −0, subnormals, tiny and huge magnitudes
+      blocks  — contiguous regions scaled to the edge of the subnormal range, so that whole stencils are tiny
+      sparse0 — a zero field with a few scattered tiny values (every stencil that touches one is tiny, the rest exact
+                zeros; the neighbours across tile seams must notice)"""
+    Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], seed, dtype=dtype)
+    rng = np.random.Generator(np.random.MT19937(seed + 1000))
+    f64 = dtype == np.float64
+    edge = (1e-308, 1e-310) if f64 else (1e-38, 1e-40)
+    with np.errstate(all="ignore"):
+        if mode == "dense":
+            kind = rng.integers(0, 8, size=Pr0.shape)
+            pick = rng.uniform(size=Pr0.shape) < 0.3
+            scale = {2: 1e-320 if f64 else 1e-44, 3: 1e-305 if f64 else 1e-37, 4: 1e-250 if f64 else 1e-30,
+                     5: 1e-200 if f64 else 1e-12, 6: 1e250 if f64 else 1e22, 7: 1e300 if f64 else 1e30}
+            for k, sc in scale.items():
+                m = pick & (kind == k)
+                Pr0[m] = (Pr0[m].astype(np.float64) * sc).astype(dtype)
+            Pr0[pick & (kind == 0)] = 0.0
+            Pr0[pick & (kind == 1)] = -0.0
+        elif mode == "blocks":
+            big = Pr0.astype(np.float64)
+            big[nx // 3:2 * nx // 3] *= edge[0]
+            big[:nx // 3, ny // 2:] *= edge[1]
+            big[:, :, nz // 2:] *= 1e-3 if f64 else 1.0
+            big[2 * nx // 3:, :ny // 3] = 0.0
+            Pr0 = np.asfortranarray(big.astype(dtype))
+            d0 = np.asfortranarray((d0.astype(np.float64) * edge[0]).astype(dtype))   # nothing large to mask a mis-rounded ∇²P
+            rhs = np.zeros_like(rhs)
+        else:
+            pick = rng.uniform(size=Pr0.shape) < 0.004
+            pick[[1, nx // 2, 254 % nx, 255 % nx, 62, 63, 64], :, :] |= rng.uniform(size=(7, ny, nz)) < 0.05
+            big = np.where(pick, Pr0.astype(np.float64) * np.where(rng.uniform(size=Pr0.shape) < 0.5, edge[0], edge[1]), 0.0)
+            Pr0 = np.asfortranarray(big.astype(dtype))
+            d0 = np.asfortranarray((d0.astype(np.float64) * edge[0]).astype(dtype))
+            rhs = np.zeros_like(rhs)
+    return Pr0, d0, rhs
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("bc", [(0, True, 0.0), (0, True, 1e-310), (1, False, 0.0)])
+@pytest.mark.parametrize("mode", ["dense", "blocks", "sparse0"])
+def test_pt_exact_division_guard_extreme_values(hip, oracle, dtype, bc, mode):
+    """Zeros, −0, subnormals, 1e-320 … 1e300 in Pr: one and two iterations, every kernel family, stay bit-identical to
+    the oracle's IEEE divisions, signed zeros included."""
+    import torch
+    bc_kind, owns, val = bc
+    ctx = hip.Context(0, "strict")
+    with np.errstate(all="ignore"):
+        for grid in ((260, 19, 9), (70, 21, 13), (131, 40, 6)):
+            nx, ny, nz = grid
+            g = geometry(*grid)
+            Pr0, d0, rhs = _extreme_fields(nx, ny, nz, dtype, 97, mode)
+            ref = {}
+            Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
+            for n in (1, 2):
+                _oracle_iters(oracle, Pr, d, rhs, g, 1, bc_kind, owns, val)
+                ref[n] = (Pr.copy(order="F"), d.copy(order="F"))
+            p = _params(hip, hip.from_numpy(Pr0), g, bc_kind, owns, val)
+            for variant in (100, 200, 2200, 2700):
+                ctx.set_pt_variant(variant)
+                ctx.set_pt2_variant(-1)
+                dPr, dd = hip.from_numpy(Pr0), hip.from_numpy(d0)
+                hip.pt_iterate(dPr, dd, hip.from_numpy(rhs), p, 1, ctx=ctx)
+                torch.cuda.synchronize()
+                assert _bits_equal(hip.to_numpy(dPr), ref[1][0]) and _bits_equal(hip.to_numpy(dd), ref[1][1]), (grid, variant)
+            for shape in (100, 300, 600, 1100, 1200, 703, 1500, 1800):
+                ctx.set_pt2_variant(shape)
+                dPr, dout, dd = hip.from_numpy(Pr0), hip.from_numpy(np.full_like(Pr0, 555.0)), hip.from_numpy(d0)
+                ddout = hip.from_numpy(np.full_like(d0, 444.0))
+                hip.pt_sweep2(dPr, dout, dd, ddout, hip.from_numpy(rhs), p, ctx=ctx)
+                torch.cuda.synchronize()
+                assert _bits_equal(hip.to_numpy(ddout), ref[2][1]), (grid, shape)
+                assert _bits_equal(hip.to_numpy(dout), ref[2][0]), (grid, shape)
     ctx.close()
