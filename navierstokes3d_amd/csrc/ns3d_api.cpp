@@ -340,12 +340,13 @@ static int pick_pt2_variant(ns3d_ctx *c, hipStream_t s, int mode, const T *src, 
     for (int q = 0; q < 2; ++q)
         if (!c->tune_ev[q] && hipEventCreate(&c->tune_ev[q]) != hipSuccess) { (void)hipGetLastError(); return 0; }
     static const int shapes[] = {0, 11, 8, 3, 7, 13, 15, 12};   // 0 = the built-in choice (wins ties)
-    static const int chunks[] = {16, 32};
+    static const int chunks[] = {16, 32, 64};
     int best = 0;
     float best_ms = 0.f;
     for (int shape : shapes)
         for (int kz : chunks) {
             if (shape == 0 && kz != chunks[0]) continue;
+            if (kz == 64 && nk < 256) continue;
             const int v = shape ? shape * 100 + kz : 0;
             bool ok = true;
             float ms = 0.f;
