@@ -358,3 +358,40 @@ def test_pt_exact_division_guard_extreme_values(hip, oracle, dtype, bc, mode):
                 assert _bits_equal(hip.to_numpy(ddout), ref[2][1]), (grid, shape)
                 assert _bits_equal(hip.to_numpy(dout), ref[2][0]), (grid, shape)
     ctx.close()
+
+
+def test_pt2_first_use_tuning(hip, oracle):
+    """ns3d_set_autotune (default on): the first automatic two-iteration launch on a grid of >= 4 M cells times the tile
+    shapes on the caller's arguments; the result is the oracle's, the choice is remembered, and turning the tuner off
+    returns to the built-in choice."""
+    import torch
+    nx, ny, nz = 200, 164, 130
+    g = geometry(nx, ny, nz)
+    Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 101)
+    Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
+    _oracle_iters(oracle, Pr, d, rhs, g, 2, 0, True, 0.25)
+    ctx = hip.Context(0, "strict")
+    p = _params(hip, hip.from_numpy(Pr0), g, 0, True, 0.25)
+    seen = []
+    for rep in range(3):
+        dPr, dout, dd = hip.from_numpy(Pr0), hip.from_numpy(np.full_like(Pr0, 555.0)), hip.from_numpy(d0)
+        ddout = hip.from_numpy(np.full_like(d0, 444.0))
+        hip.pt_sweep2(dPr, dout, dd, ddout, hip.from_numpy(rhs), p, ctx=ctx)
+        torch.cuda.synchronize()
+        seen.append(ctx.last_pt2_variant())
+        assert np.array_equal(hip.to_numpy(dout), Pr) and np.array_equal(hip.to_numpy(ddout), d)
+        assert np.array_equal(hip.to_numpy(dPr), Pr0) and np.array_equal(hip.to_numpy(dd), d0)
+    assert seen[0] == seen[1] == seen[2]                       # tuned once, then remembered
+    # pt_iterate on the same grid reuses the choice (same plane range)
+    dPr, dd = hip.from_numpy(Pr0), hip.from_numpy(d0)
+    hip.pt_iterate(dPr, dd, hip.from_numpy(rhs), p, 2, ctx=ctx)
+    torch.cuda.synchronize()
+    assert ctx.last_pt2_variant() == seen[0]
+    assert np.array_equal(hip.to_numpy(dPr), Pr) and np.array_equal(hip.to_numpy(dd), d)
+    ctx.set_autotune(False)
+    dPr, dd = hip.from_numpy(Pr0), hip.from_numpy(d0)
+    hip.pt_iterate(dPr, dd, hip.from_numpy(rhs), p, 2, ctx=ctx)
+    torch.cuda.synchronize()
+    assert ctx.last_pt2_variant() == 0
+    assert np.array_equal(hip.to_numpy(dPr), Pr) and np.array_equal(hip.to_numpy(dd), d)
+    ctx.close()
