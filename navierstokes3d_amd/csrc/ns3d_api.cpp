@@ -339,7 +339,7 @@ static int pick_pt2_variant(ns3d_ctx *c, hipStream_t s, int mode, const T *src, 
     if (cap != hipStreamCaptureStatusNone) return 0;
     for (int q = 0; q < 2; ++q)
         if (!c->tune_ev[q] && hipEventCreate(&c->tune_ev[q]) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    static const int shapes[] = {0, 11, 8, 3, 7, 13, 15, 12};   // 0 = the built-in choice (wins ties)
+    static const int shapes[] = {0, 11, 8, 3, 7, 13, 19, 12};   // 0 = the built-in choice (wins ties)
     static const int chunks[] = {16, 32, 64};
     int best = 0;
     float best_ms = 0.f;

@@ -1472,6 +1472,7 @@ hipError_t pt_sweep2(hipStream_t s, int variant, const T *Pin, T *Pout, const T 
     case 16: return launch_sweep2<T, 2, 2, 6, true, 1, true>(s, a, kz); // 128 x 12
     case 17: return launch_sweep2<T, 1, 4, 6, true, 1, true>(s, a, kz); //  64 x 24
     case 18: return launch_sweep2<T, 1, 4, 4, true, 1, true>(s, a, kz); //  64 x 16
+    case 19: return launch_sweep2<T, 4, 4, 2, true, 4, true>(s, a, kz); // 256 x 8, 1024 threads with two rows each: four waves per SIMD
     default: // shape by row length: the widest tile whose overlap-2 tiling wastes the fewest lanes
         if (nxi > 128) return launch_sweep2<T, 4, 2, 4, true>(s, a, kz);
         if (nxi > 64) return launch_sweep2<T, 2, 4, 4, true>(s, a, kz);

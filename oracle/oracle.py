@@ -20,6 +20,8 @@ _LIB = None
 
 
 def build(force=False):
+    if os.environ.get("NS3D_ORACLE_LIB"):          # e.g. an ASan/UBSan build of ns3d_oracle.c (CPU sanitizer runs)
+        return os.environ["NS3D_ORACLE_LIB"]
     so = os.path.join(_HERE, "libns3d_oracle.so")
     src = os.path.join(_HERE, "ns3d_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
