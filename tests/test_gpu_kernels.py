@@ -253,3 +253,42 @@ def test_ieee_div_flag_gives_identical_results(hip, oracle):
         outs.append((hip.to_numpy(dPr), hip.to_numpy(dd)))
         ctx.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_c_abi_status_codes(hip):
+    """The boundary never aborts: bad arguments come back as NS3D_ERR_ARG with a message, straight from the C entry points
+    (raw ctypes, no Python-side checks in between)."""
+    import ctypes as C
+    import torch
+    from navierstokes3d_amd import lib as L
+    lib = L.load()
+    ctx = hip.Context(0, "strict")
+    h = ctx.handle
+    nx, ny, nz = 12, 9, 7
+    P, Q = hip.zeros((nx, ny, nz)), hip.zeros((nx, ny, nz))
+    D, E = hip.zeros((nx - 2, ny - 2, nz - 2)), hip.zeros((nx - 2, ny - 2, nz - 2))
+    R = hip.zeros((nx, ny, nz))
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    p = hip.pt_params(P, 1000.0, 0.01, 0.01, 0.1, 0.1, 0.1, 0.1, 0, True, 0.0, 0.0)
+    ERR = 1
+    assert lib.ns3d_update_Pr_f64(None, ptr(P), ptr(D), 0.1, nx, ny, nz) == ERR and b"null context" in lib.ns3d_last_error()
+    assert lib.ns3d_update_Pr_f64(h, None, ptr(D), 0.1, nx, ny, nz) == ERR and b"null field pointer" in lib.ns3d_last_error()
+    assert lib.ns3d_update_Pr_f64(h, ptr(P), ptr(D), 0.1, 2, ny, nz) == ERR and b"too small" in lib.ns3d_last_error()
+    assert lib.ns3d_pt_sweep2_f64(h, ptr(P), ptr(P), ptr(D), ptr(E), ptr(R), C.byref(p), 1, nz - 1) == ERR
+    assert b"must differ" in lib.ns3d_last_error()
+    assert lib.ns3d_pt_sweep2_f64(h, ptr(P), ptr(Q), ptr(D), ptr(D), ptr(R), C.byref(p), 1, nz - 1) == ERR
+    assert lib.ns3d_pt_sweep2_f64(h, ptr(P), ptr(Q), ptr(D), ptr(E), ptr(R), C.byref(p), 0, nz - 1) == ERR
+    assert b"plane range" in lib.ns3d_last_error()
+    assert lib.ns3d_pt_sweep_f64(h, ptr(P), ptr(Q), ptr(D), ptr(R), C.byref(p), 1, nz) == ERR
+    assert lib.ns3d_pt_iterate_f64(h, ptr(P), ptr(D), ptr(R), None, 3) == ERR and b"null params" in lib.ns3d_last_error()
+    bad = hip.pt_params(P, 1000.0, 0.01, 0.01, 0.1, 0.1, 0.1, 0.1, 0, True, 0.0, 0.0)
+    bad.bc_kind = 7
+    assert lib.ns3d_pt_iterate_f64(h, ptr(P), ptr(D), ptr(R), C.byref(bad), 3) == ERR and b"bc_kind" in lib.ns3d_last_error()
+    halo = hip.pt_params(P, 1000.0, 0.01, 0.01, 0.1, 0.1, 0.1, 0.1, 1, False, 0.0, 9.81, True, False)
+    assert lib.ns3d_pt_iterate_f64(h, ptr(P), ptr(D), ptr(R), C.byref(halo), 3) == ERR   # gpu.jl set has no z halos
+    assert lib.ns3d_set_pt_variant(h, -5) == ERR and lib.ns3d_set_pt2_variant(h, 123456) == ERR
+    assert lib.ns3d_set_autotune(None, 1) == ERR and lib.ns3d_last_pt2_variant(None) == -1
+    # … and a good call still works afterwards
+    assert lib.ns3d_pt_iterate_f64(h, ptr(P), ptr(D), ptr(R), C.byref(p), 3) == 0
+    torch.cuda.synchronize()
+    ctx.close()
