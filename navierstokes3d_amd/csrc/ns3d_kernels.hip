@@ -1405,13 +1405,58 @@ static hipError_t launch_faces(hipStream_t s, const SweepArgs<T> &a)
     return e;
 }
 
+// Workgroups of a kernel that one CU holds at a time (registers, LDS, wave slots), and the CUs of the current device.
+static int device_cus()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cus = n;
+        else { (void)hipGetLastError(); cus = 256; }
+    }
+    return cus;
+}
+static int workgroups_per_cu(const void *kernel, int threads)
+{
+    hipFuncAttributes at;
+    if (hipFuncGetAttributes(&at, kernel) != hipSuccess) { (void)hipGetLastError(); return 1; }
+    const int vg = ((at.numRegs > 0 ? at.numRegs : 128) + 7) / 8 * 8;          // VGPRs are allocated in blocks of 8
+    const int waves_per_simd = min(8, 512 / vg), wg_waves = (threads + 63) / 64;
+    const int by_waves = waves_per_simd * 4 / wg_waves;
+    const int by_lds = at.sharedSizeBytes > 0 ? (int)((160u * 1024u) / at.sharedSizeBytes) : 64;
+    return max(1, min(by_waves, by_lds));
+}
+
+// kz: planes per z-chunk.  1…89 literal.  0 and 91…99 choose the chunk length so that the launch fills whole "rounds" of
+// the chip: with S = CUs × workgroups per CU slots and t tiles per chunk, c = ⌊m·S/t⌋ chunks occupy the slots m times over
+// with no ragged last round (512³, 256×8 tiles: 2 720 workgroups of 32 planes = 10.6 rounds → 203 000 Mcells·iter/s;
+// 1 020 of 85 planes = 3.98 rounds → 217 000).  9m asks for m rounds, 0 for two; m grows until the fill reaches 95 %.
 template <class T, int WX, int WY, int CPT, bool NT, int MINW = 1, bool SEPF = false>
 static hipError_t launch_sweep2(hipStream_t s, SweepArgs<T> &a, int kz)
 {
     constexpr int TX = 64 * WX, TY = CPT * WY;
-    a.kz = kz;
     const int nk = a.k1 - a.k0;
     const int ntx = max(1, (a.nx - 4 + (TX - 2) - 1) / (TX - 2)), nty = max(1, (a.ny - 4 + (TY - 2) - 1) / (TY - 2));
+    if (kz <= 0 || kz > 90) {
+        static const int per_cu = workgroups_per_cu((const void *)k_pt_sweep2<T, WX, WY, CPT, NT, MINW, SEPF>, 64 * WX * WY);
+        const long slots = (long)device_cus() * per_cu, tiles = (long)ntx * nty;
+        const int want = kz > 90 ? kz - 90 : 2;
+        const int cmax = max(1, nk / 8);                     // chunks shorter than 8 planes are mostly pipeline fill
+        long best_c = 1;
+        double best_fill = 0.0;
+        for (int m = want; m <= want + 12; ++m) {
+            long c = m * slots / tiles;
+            c = c < 1 ? 1 : (c > cmax ? cmax : c);
+            const int kzc = (int)((nk + c - 1) / c);
+            const long wgs = tiles * ((nk + kzc - 1) / kzc);
+            const double fill = (double)wgs / (double)(((wgs + slots - 1) / slots) * slots);
+            if (fill > best_fill + 1e-9) { best_fill = fill; best_c = c; }
+            if (fill >= 0.95 || c == cmax) break;
+        }
+        kz = (int)((nk + best_c - 1) / best_c);
+    }
+    a.kz = kz;
     const int ntz = (nk + kz - 1) / kz;
     hipLaunchKernelGGL((k_pt_sweep2<T, WX, WY, CPT, NT, MINW, SEPF>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX, WY, 1), 0,
                        s, a, ntx, nty);
@@ -1439,18 +1484,18 @@ hipError_t pt_sweep2(hipStream_t s, int variant, const T *Pin, T *Pout, const T 
     const int nxi = p.nx - 2;
     if (variant == 0) {
         // Tile shape by grid (measured: profiles/r1_sweep*_final.log).  Wide 256×8 tiles with the boundary cells written by
-        // separate launches are fastest whenever the rows fill them (two columns of overlap per 256: nx = 255, 512, …);
-        // otherwise 64×32 tiles (least overlap, 62-column granularity).  Long z-chunks on tall grids, short ones on
-        // cache-resident grids so that every CU gets work.  Explicit variants (shape·100 + kz) override.
+        // separate launches are fastest on large grids whose rows fill them (two columns of overlap per 256: nx = 512, …);
+        // otherwise 128×8 tiles with two rows per thread.  Explicit variants (shape·100 + kz) override; the context's
+        // first-use tuning (ns3d_api.cpp) normally replaces this rule by a measurement.
         const long long cells = (long long)p.nx * p.ny * p.nz;
         const int nzi = p.nz - 2;
         const int ntx256 = (p.nx - 4 + 253) / 254 > 0 ? (p.nx - 4 + 253) / 254 : 1;
         const bool rows_fill_256 = nxi >= 200 && (double)nxi / (256.0 * ntx256) >= 0.95;
-        if (rows_fill_256) { shape = 11; kz = nzi >= 256 ? 32 : 16; }
-        else if (cells >= 32ll * 1000 * 1000) { shape = 3; kz = nzi >= 384 ? 64 : (nzi >= 192 ? 32 : 16); }
-        else { shape = nxi > 128 ? 1 : (nxi > 64 ? 2 : 3); kz = nzi >= 64 ? 16 : 8; }
+        (void)nzi;
+        if (rows_fill_256 && cells >= 64ll * 1000 * 1000) shape = 11;
+        else shape = nxi > 64 ? 8 : 7;          // 128×8 / 64×16 with two workgroups per CU (profiles/r1b_shapes.log)
+        kz = 0;                                 // z-chunks that fill whole rounds of the chip (launch_sweep2)
     }
-    if (kz <= 0) kz = 32;
     switch (shape) {
     case 1: return launch_sweep2<T, 4, 2, 4, true>(s, a, kz);   // 256 x 8
     case 2: return launch_sweep2<T, 2, 4, 4, true>(s, a, kz);   // 128 x 16
