@@ -744,6 +744,8 @@ __device__ __forceinline__ T xface_val(const SweepArgs<T> &a, bool hi, T copy, i
     return (hi && a.owns_outlet) ? a.outlet_val : copy; // multi.jl:109-110,148
 }
 
+template <class T, bool NT> __device__ __forceinline__ T ld_stream(const T *p);
+template <class T, bool NT> __device__ __forceinline__ void st_stream(T *p, T v);
 // store P⁺(i,j,k)=v and every boundary cell that maps onto it
 template <class T, bool NT = false>
 __device__ __forceinline__ void store_with_bc(const SweepArgs<T> &a, int i, int j, int k, T v)
@@ -753,8 +755,7 @@ __device__ __forceinline__ void store_with_bc(const SweepArgs<T> &a, int i, int 
     const bool ylo = (j == 1), yhi = (j == ny - 2);
     const bool zlo = (k == 1) && !a.zlo_halo, zhi = (k == nz - 2) && !a.zhi_halo;
     T *__restrict__ P = a.Pout;
-    if (NT) __builtin_nontemporal_store(v, &P[IX3(i, j, k, nx, ny)]);
-    else P[IX3(i, j, k, nx, ny)] = v;
+    st_stream<T, NT>(&P[IX3(i, j, k, nx, ny)], v);
     if (!(xlo | xhi | ylo | yhi | zlo | zhi)) return;
 #pragma unroll
     for (int zz = 0; zz < 3; ++zz) {
@@ -903,23 +904,30 @@ static hipError_t launch_zmarch(hipStream_t s, SweepArgs<T> &a, int kz)
     return hipGetLastError();
 }
 
-// streaming accessors: nontemporal loads/stores for data touched once per sweep (dPrdτ, ∇V, new Pr)
+// accessors of the data touched once per sweep (dPrdτ, ∇V, new Pr).  Nontemporal hints looked right on paper and cost
+// 6–11 % on MI355X (512³ strict 220 000 → 235 000 Mcells·iter/s, 255×153×153 177 000 → 197 000 with plain accesses; HBM
+// traffic 6.07 → 5.65 GB per pass): the rows that neighbouring tiles share are then re-fetched from HBM instead of hitting
+// the L2, and the next launch finds less of its input in the Infinity Cache.  -DNS3D_NONTEMPORAL restores the hints (A/B).
 template <class T, bool NT> __device__ __forceinline__ T ld_stream(const T *p)
 {
+#ifdef NS3D_NONTEMPORAL
     if (NT) return __builtin_nontemporal_load(p);
+#endif
     return *p;
 }
 template <class T, bool NT> __device__ __forceinline__ void st_stream(T *p, T v)
 {
-    if (NT) __builtin_nontemporal_store(v, p);
-    else *p = v;
+#ifdef NS3D_NONTEMPORAL
+    if (NT) { __builtin_nontemporal_store(v, p); return; }
+#endif
+    *p = v;
 }
 
 // ---- variant P: z-marching register pipeline, whole-row workgroups, XCD-aware tile order -----------------
 // Same arithmetic as variant Z.  A workgroup is WX waves wide in x (for nx ≤ 64·WX+2 it owns whole rows, so the x-halo
 // lines are hits in its own CU); the grid is 1-D and the hardware's round-robin block→XCD dealing (block b → XCD b mod 8)
 // is undone so that every XCD sweeps one contiguous range of tiles (y-neighbour tiles share an L2 and run together);
-// dPrdτ / ∇V / new Pr are streamed with nontemporal accesses.
+// dPrdτ / ∇V / new Pr go through ld_stream / st_stream (plain accesses unless built with -DNS3D_NONTEMPORAL).
 // Every load of the loop body is unconditional (clamped addresses instead of `if`s; the two x-halo lanes share one
 // instruction whose other lanes all read lane 0's address, i.e. one extra cache line), which keeps the loop body one
 // basic block up to the stores so that the waitcnt pass can count outstanding loads instead of draining them.
