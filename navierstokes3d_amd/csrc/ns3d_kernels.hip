@@ -1119,6 +1119,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
     const bool x_s1 = (gi <= nx - 2);
     // does this tile touch an x or y face of the domain at all?  (scalar: same for the whole workgroup)
     const bool tile_on_xy_face = (ox <= 1) || (ox + TX - 1 >= nx - 2) || (oy <= 1) || (oy + TY - 1 >= ny - 2);
+    const bool tile_on_x_face = (ox <= 1) || (ox + TX - 1 >= nx - 2);
     const bool x_out = x_s1 && (lx >= 1 || xlo_adj) && (lx <= TX - 2 || xhi_adj);
 
     int poff[CPT], roff[CPT], doff[CPT];
@@ -1298,9 +1299,14 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
                     const int gj = oy + lr;
                     // SEPF: boundary cells of P² are written by k_pt_faces_* after this kernel (keeps the rare store
                     // paths — and ≈70 VGPRs of their live state — out of the hot kernel)
-                    if (SEPF || (plain_k && !tile_on_xy_face)) // scalar test: interior tiles and planes store P² only
-                        st_stream<T, NT>(a.Pout + (idx_t)k2 * sz + gj * nx + gi, pn);
-                    else
+                    if (SEPF || (plain_k && !tile_on_xy_face)) { // scalar test: interior tiles and planes store P² only
+                        T *__restrict__ po = a.Pout + (idx_t)k2 * sz + gj * nx + gi;
+                        st_stream<T, NT>(po, pn);
+                        if (SEPF && tile_on_x_face) {   // the x-face cell beside it shares its cache line: one more store
+                            if (xlo_adj) po[-1] = xface_val<T>(a, false, pn, k2);
+                            if (xhi_adj) po[1] = xface_val<T>(a, true, pn, k2);
+                        }
+                    } else
                         store_with_bc<T, NT>(a, gi, gj, k2, pn);
                 }
             }
@@ -1358,7 +1364,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
     }
 }
 
-// ---- boundary cells of P² as separate launches (used with the SEPF form of k_pt_sweep2) ---------------------------
+// ---- y- and z-face cells of P² as separate launches (used with the SEPF form of k_pt_sweep2) ----------------------
 // Same rule as store_with_bc, evaluated per boundary cell: nearest interior cell (bc_x!, bc_y!, bc_z! in that order ≡ index
 // clamp), outlet plane / hydrostatic x planes on top (multi.jl:176-181, gpu.jl:282-284).
 template <class T>
@@ -1372,18 +1378,16 @@ __device__ __forceinline__ T face_value(const SweepArgs<T> &a, int i, int j, int
     const int ci = min(max(i, 1), nx - 2), cj = min(max(j, 1), ny - 2), ck = min(max(k, 1), nz - 2);
     return a.Pout[IX3(ci, cj, ck, nx, ny)];
 }
-// x/y boundary ring of the interior planes [k0,k1): one thread per ring cell
+// y-face rows (j = 0 and j = ny-1, corners included) of the interior planes [k0,k1): one thread per cell.  The x-face
+// cells of rows 1…ny-2 are stored by k_pt_sweep2 itself, next to the interior cell they copy.
 template <class T>
 __global__ __launch_bounds__(256) void k_pt_faces_ring(SweepArgs<T> a)
 {
     const int nx = a.nx, ny = a.ny;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     const int k = a.k0 + blockIdx.y;
-    if (q >= 2 * nx + 2 * (ny - 2)) return;
-    int i, j;
-    if (q < nx) { i = q; j = 0; }
-    else if (q < 2 * nx) { i = q - nx; j = ny - 1; }
-    else { const int r = q - 2 * nx; j = 1 + (r >> 1); i = (r & 1) ? nx - 1 : 0; }
+    if (q >= 2 * nx) return;
+    const int i = q < nx ? q : q - nx, j = q < nx ? 0 : ny - 1;
     a.Pout[IX3(i, j, k, nx, ny)] = face_value<T>(a, i, j, k);
 }
 // whole z face planes (plane 0 when the launch contains plane 1, plane nz-1 when it contains plane nz-2)
@@ -1401,7 +1405,7 @@ __global__ __launch_bounds__(256) void k_pt_faces_z(SweepArgs<T> a, int lo, int 
 template <class T>
 static hipError_t launch_faces(hipStream_t s, const SweepArgs<T> &a)
 {
-    const int ring = 2 * a.nx + 2 * (a.ny - 2);
+    const int ring = 2 * a.nx;
     hipLaunchKernelGGL(k_pt_faces_ring<T>, dim3((unsigned)((ring + 255) / 256), (unsigned)(a.k1 - a.k0)), dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
     const int lo = (a.k0 == 1 && !a.zlo_halo) ? 1 : 0, hi = (a.k1 == a.nz - 1 && !a.zhi_halo) ? 1 : 0;
