@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""SQ counters of the k_pt_sweep2 launches of one bench run (one rocprofv3 --pmc pass, kernel-trace only).
+
+    python tools/collect_sq.py --out gpurun_out/sq.json [--variant2 1392] [--modes strict,fast]
+
+WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ≈ WAVE_CYCLES (MI355X_MICROARCH.md, counter table).
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COUNTERS = ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS",
+            "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--variant2", default="1392")
+    ap.add_argument("--modes", default="strict,fast")
+    ap.add_argument("--dtype", default="f64")
+    a = ap.parse_args()
+    res = {}
+    for mode in a.modes.split(","):
+        wd = "/tmp/ns3d_sq"
+        shutil.rmtree(wd, ignore_errors=True)
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + COUNTERS + ["-f", "csv", "-d", wd, "-o", "p", "--", sys.executable,
+               os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "2", "--no-cpu-baseline", "--mode", mode,
+               "--dtype", a.dtype, "--variant2", a.variant2]
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
+        acc = {}
+        for f in glob.glob(os.path.join(wd, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if "k_pt_sweep2" not in row["Kernel_Name"]:
+                    continue
+                s, n = acc.get(row["Counter_Name"], (0.0, 0))
+                acc[row["Counter_Name"]] = (s + float(row["Counter_Value"]), n + 1)
+        m = {k: s / n for k, (s, n) in acc.items()}
+        wc = m.get("SQ_WAVE_CYCLES", 0.0) or 1.0
+        m["fractions_of_wave_cycles"] = {k: round(v / wc, 4) for k, v in m.items() if k.startswith("SQ_") and k != "SQ_WAVE_CYCLES"}
+        res["%s_v%s_%s" % (mode, a.variant2, a.dtype)] = m
+        print(mode, m["fractions_of_wave_cycles"], flush=True)
+    json.dump(res, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
