@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "ns3d_launch.h"
@@ -21,6 +22,12 @@ static int fail(int code, const char *fmt, ...)
     va_end(ap);
     return code;
 }
+
+// tile choices measured so far in this process (per device and grid): contexts come and go (one per driver call), the
+// measurement should not be repeated
+struct Tuned { int device, nx, ny, nz, nk, esize, mode, variant; };
+static std::vector<Tuned> g_tuned;
+static std::mutex g_tuned_mutex;
 
 struct ns3d_ctx {
     int device;
@@ -38,8 +45,6 @@ struct ns3d_ctx {
     int graph_mode;  // HIP-graph replay of residual-check blocks: -1 auto (launch-bound grids), 0 off, 1 on
     int autotune;    // time the tile shapes of the two-iteration sweep on first use of a grid (pt2_variant == 0 only)
     int last_pt2;    // variant of the latest two-iteration launch (0: built-in choice by grid)
-    struct Tuned { int nx, ny, nz, nk, esize, mode, variant; };
-    std::vector<Tuned> tuned;
     hipEvent_t tune_ev[2];
     hipEvent_t fence;
     struct BlockGraph {
@@ -229,7 +234,6 @@ int ns3d_set_autotune(ns3d_ctx *c, int on)
 {
     if (!c) return fail(NS3D_ERR_ARG, "ns3d_set_autotune: null context");
     c->autotune = on ? 1 : 0;
-    if (!on) c->tuned.clear();
     return NS3D_OK;
 }
 
@@ -331,9 +335,13 @@ static int pick_pt2_variant(ns3d_ctx *c, hipStream_t s, int mode, const T *src, 
     if (c->pt2_variant > 0) return c->pt2_variant;
     const int nk = k1 - k0;
     if (!c->autotune || (long long)p->nx * p->ny * nk < 4ll * 1000 * 1000) return 0;
-    for (const auto &t : c->tuned)
-        if (t.nx == p->nx && t.ny == p->ny && t.nz == p->nz && t.nk == nk && t.esize == (int)sizeof(T) && t.mode == mode)
-            return t.variant;
+    {
+        std::lock_guard<std::mutex> lock(g_tuned_mutex);
+        for (const auto &t : g_tuned)
+            if (t.device == c->device && t.nx == p->nx && t.ny == p->ny && t.nz == p->nz && t.nk == nk &&
+                t.esize == (int)sizeof(T) && t.mode == mode)
+                return t.variant;
+    }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return 0; }
     if (cap != hipStreamCaptureStatusNone) return 0;
@@ -384,7 +392,10 @@ static int pick_pt2_variant(ns3d_ctx *c, hipStream_t s, int mode, const T *src, 
         if (!time_variant(0, ms0, 6) || !time_variant(best, ms1, 6)) { (void)hipGetLastError(); return 0; }
         if (!(ms1 < 0.97f * ms0)) best = 0;              // run-to-run noise is a few per cent: change only for a clear gain
     }
-    c->tuned.push_back({p->nx, p->ny, p->nz, nk, (int)sizeof(T), mode, best});
+    {
+        std::lock_guard<std::mutex> lock(g_tuned_mutex);
+        g_tuned.push_back({c->device, p->nx, p->ny, p->nz, nk, (int)sizeof(T), mode, best});
+    }
     return best;
 }
 template <class T>

@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--mode", default="strict")
     ap.add_argument("--compare-fast", action="store_true")
     a = ap.parse_args()
-    run(a.script, min(a.nx, 63), 1, a.mode)  # warm-up (library load, allocator)
+    run(a.script, a.nx, 1, a.mode)           # warm-up on the same grid (library load, allocator, one-time tile tuning)
     wall, info, fields = run(a.script, a.nx, a.nt, a.mode)
     p = info.params
     cells = p.nx * p.ny * p.nz
