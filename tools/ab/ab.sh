@@ -1,3 +1,8 @@
+#!/bin/bash
+# A/B of library builds on ONE GPU box (box-to-box spread is larger than most kernel changes):
+#   cp navierstokes3d_amd/libns3d.so tools/ab/libns3d_old.so;  …edit, rebuild…;  cp navierstokes3d_amd/libns3d.so tools/ab/libns3d_new.so
+#   gpurun -- 'BENCH_ARGS="--variant2 1392" bash tools/ab/ab.sh'
+# Every tools/ab/libns3d_*.so is benchmarked twice, interleaved, through the NS3D_LIB override of navierstokes3d_amd/lib.py.
 set -e
 cd $GRAFT_REPO_ROOT
 if [ -z "$SKIP_TESTS" ]; then
