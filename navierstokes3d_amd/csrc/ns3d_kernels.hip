@@ -1495,14 +1495,14 @@ hipError_t pt_sweep2(hipStream_t s, int variant, const T *Pin, T *Pout, const T 
     int kz = variant % 100;
     const int nxi = p.nx - 2;
     if (variant == 0) {
-        // Tile shape by grid (measured: profiles/r1_sweep*_final.log).  Wide 256×8 tiles with the boundary cells written by
-        // separate launches are fastest on large grids whose rows fill them (two columns of overlap per 256: nx = 512, …);
+        // Tile shape by grid (measured: profiles/r1b_shapes.log and later sweeps).  256-wide tiles (12 rows in fp64, 8 in fp32)
+        // are fastest on large grids whose rows fill them (two columns of overlap per 256: nx = 512, …);
         // otherwise 128×8 tiles with two rows per thread.  Explicit variants (shape·100 + kz) override; the context's
         // first-use tuning (ns3d_api.cpp) normally replaces this rule by a measurement.
         const long long cells = (long long)p.nx * p.ny * (k1 - k0);      // of this launch (z-slab ranks sweep thin seam ranges)
         const int ntx256 = (p.nx - 4 + 253) / 254 > 0 ? (p.nx - 4 + 253) / 254 : 1;
         const bool rows_fill_256 = nxi >= 200 && (double)nxi / (256.0 * ntx256) >= 0.95;
-        if (rows_fill_256 && cells >= 64ll * 1000 * 1000) shape = 11;
+        if (rows_fill_256 && cells >= 64ll * 1000 * 1000) shape = sizeof(T) == 8 ? 13 : 11;   // 256×12 (fp64) / 256×8 (fp32)
         else shape = nxi > 64 ? 8 : 7;          // 128×8 / 64×16 with two workgroups per CU (profiles/r1b_shapes.log)
         kz = 0;                                 // z-chunks that fill whole rounds of the chip (launch_sweep2)
     }
