@@ -350,7 +350,7 @@ static int pick_pt2_variant(ns3d_ctx *c, hipStream_t s, int mode, const T *src, 
     // candidates: variant = shape*100 + kz (ns3d.h).  Stage 1: every shape with round-filling chunks (92) and with short
     // 16-plane chunks (which keep neighbouring tiles close in time: their overlaps then hit the L2); stage 2: the other
     // chunk lengths for the three best shapes.  0 = the built-in choice; it wins ties.
-    static const int shapes[] = {11, 8, 3, 7, 13, 19, 12};
+    static const int shapes[] = {11, 8, 9, 7, 13, 19, 12};
     static const int stage1[] = {92, 16}, stage2[] = {94, 91, 98, 32};
     constexpr int NS = (int)(sizeof shapes / sizeof shapes[0]);
     auto time_variant = [&](int v, float &ms, int timed = 3) -> bool {
