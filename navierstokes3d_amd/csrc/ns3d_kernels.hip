@@ -606,8 +606,10 @@ hipError_t set_cylinder(hipStream_t s, T *C, T *Vx, T *Vy, T *Vz, double a2, dou
 // ---------------------------------------------------------------------------------------------------------
 template <class T> __device__ __forceinline__ T lerp_(T a, T b, T t) { return b * t + a * ((T)1 - t); }
 __device__ __forceinline__ int clampi(long long v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : (int)v); }
-__device__ __forceinline__ double fmod1(double a) { return fmod(a, 1.0); }
-__device__ __forceinline__ float fmod1(float a) { return fmodf(a, 1.0f); }
+// δ%1 (multi.jl:196; Julia `%` = rem = C fmod): the remainder of a division by one is exact, a − trunc(a), for every finite a (±Inf and
+// NaN give NaN either way); only the sign of a zero result can differ from fmod's, and the callers subtract it from 0 or 1.
+__device__ __forceinline__ double fmod1(double a) { return a - __builtin_trunc(a); }
+__device__ __forceinline__ float fmod1(float a) { return a - __builtin_truncf(a); }
 __device__ __forceinline__ double floor_(double a) { return floor(a); }
 __device__ __forceinline__ float floor_(float a) { return floorf(a); }
 
@@ -618,7 +620,7 @@ __device__ __forceinline__ void backtrack(T *__restrict__ A, const T *__restrict
 #if NS3D_FASTMATH
     const T ddx = dt * vxc * g.rdx, ddy = dt * vyc * g.rdy, ddz = dt * vzc * g.rdz;
 #else
-    const T ddx = dt * vxc / g.dx, ddy = dt * vyc / g.dy, ddz = dt * vzc / g.dz;
+    const T ddx = DIV_X(dt * vxc), ddy = DIV_Y(dt * vyc), ddz = DIV_Z(dt * vzc);
 #endif
     const int ix1 = clampi((long long)floor_((T)ix - ddx), 1, sx);
     const int iy1 = clampi((long long)floor_((T)iy - ddy), 1, sy);
