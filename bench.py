@@ -7,10 +7,12 @@
 
 Metric (BASELINE.json): Mcells·PT-iter/s (+ achieved HBM GB/s) on the 512³ lid-driven-cavity Poisson-only
 configuration (BASELINE.json configs[2]; synthetic, SURVEY.md §8d Config 3).  One "step" = one PT iteration
-{update_dPrdτ!; update_Pr!; set_bc_Pr!} (multi.jl:459-463) over the whole grid = one launch of the fused sweep
-kernel; fields are resident in HBM before the timed region.  For N>1 every rank owns one 512×512×512 z-slab of an
-implicit global grid 512×512×(N·510+2) (weak scaling, the reference's own model: local size fixed,
-multi.jl:325,338), with the two seam planes exchanged over RCCL/xGMI each iteration behind the interior sweep.
+{update_dPrdτ!; update_Pr!; set_bc_Pr!} (multi.jl:459-463) over the whole grid; the K timed steps are issued as K/2
+launches of the two-iteration kernel k_pt_sweep2 (one single-iteration launch more when K is odd).  Fields are resident
+in HBM before the timed region; an untimed plan phase before the warm-up lets the library time its tile shapes once.
+For N>1 every rank owns one 512×512×512 z-slab of an implicit global grid 512×512×(N·510+2) (weak scaling, the
+reference's own model: local size fixed, multi.jl:325,338); per two iterations two planes of Pr and one of dPrdτ travel
+to each z neighbour over RCCL/xGMI behind the interior sweep (navierstokes3d_amd/slab.py).
 
 Prints ONE JSON line on rank 0.
 """
