@@ -83,7 +83,7 @@ int ns3d_set_pt_variant(ns3d_ctx *ctx, int variant);
  * kz-90 whole rounds of workgroups on the chip). */
 int ns3d_set_pt2_variant(ns3d_ctx *ctx, int variant);
 /* Tile shape of the two-iteration sweep when no explicit variant is set: with autotune on (the default) the first
- * launch on a grid of >= 4 M cells times the candidate shapes on the caller's own arguments (the operation is idempotent,
+ * launch on a grid of >= 1.5 M cells times the candidate shapes on the caller's own arguments (the operation is idempotent,
  * every shape gives the same bits) and the process remembers the winner per device and grid; that first call therefore
  * synchronises the stream.  Off: a built-in choice by grid size.  ns3d_last_pt2_variant: the variant of the latest two-iteration launch
  * (0 = built-in choice). */

@@ -272,13 +272,15 @@ static int check_pt_params(const ns3d_pt_params *p, const char *fn)
     return NS3D_OK;
 }
 
-// Temporal blocking pays once the grid no longer lives in the caches (≈4 M cells: profiles/r1_sweep*_final.log);
+// Temporal blocking pays from ≈1.5 M cells on (128³: 137 000 against 113 000 Mcells·iter/s, 160³: 169 000 against 124 000;
+// 127×76×76 = 0.7 M cells: 55 000 against 70 000 — there the one-thread-per-cell sweep has more parallelism);
 // an explicit ns3d_set_pt2_variant(ctx, v>0) forces it, v<0 disables it.
+static const long long NS3D_TWO_MIN_CELLS = 1500ll * 1000;
 static bool use_two(const ns3d_ctx *c, const ns3d_pt_params *p)
 {
     if (c->pt2_variant < 0) return false;
     if (c->pt2_variant > 0) return true;
-    return (long long)p->nx * p->ny * p->nz >= 4ll * 1000 * 1000;
+    return (long long)p->nx * p->ny * p->nz >= NS3D_TWO_MIN_CELLS;
 }
 
 template <class T>
@@ -327,14 +329,14 @@ static int ensure_pingpong_d(ns3d_ctx *c, const ns3d_pt_params *p, T **buf)
 // two workgroups per CU wins at 255×153×153 and 384³, 256×8 at 512³ and 1024³).  So the first automatic launch on a
 // grid times the candidates on the caller's own arguments — the operation is idempotent: inputs and outputs are
 // distinct buffers — and remembers the winner in the context.  Skipped (built-in choice by grid instead) while the
-// stream is being captured, for launches under 4 M cells, after ns3d_set_autotune(ctx, 0), or with an explicit variant.
+// stream is being captured, for launches under 1.5 M cells, after ns3d_set_autotune(ctx, 0), or with an explicit variant.
 template <class T>
 static int pick_pt2_variant(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV,
                             const ns3d_pt_params *p, int k0, int k1)
 {
     if (c->pt2_variant > 0) return c->pt2_variant;
     const int nk = k1 - k0;
-    if (!c->autotune || (long long)p->nx * p->ny * nk < 4ll * 1000 * 1000) return 0;
+    if (!c->autotune || (long long)p->nx * p->ny * nk < NS3D_TWO_MIN_CELLS) return 0;
     {
         std::lock_guard<std::mutex> lock(g_tuned_mutex);
         for (const auto &t : g_tuned)
@@ -534,6 +536,9 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
         HIPCHK(c, hipEventRecord(c->fence, c->stream));
         HIPCHK(c, hipStreamWaitEvent(s, c->fence, 0));
     }
+    // settle the tile choice of the two-iteration sweep now (eagerly, into the scratch buffers): inside a stream capture
+    // it could only be looked up
+    if (two) (void)pick_pt2_variant<T>(c, s, mode_of(c, p->dx, p->dy, p->dz), src, dst, dsrc, ddst, divV, p, 1, p->nz - 1);
     while (iter < niter) {
         // iterations until the next residual check (multi.jl:464) or the end of the budget
         const int n = nchk > 0 ? std::min(nchk - iter % nchk, niter - iter) : niter - iter;

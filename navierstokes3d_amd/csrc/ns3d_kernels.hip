@@ -1505,7 +1505,8 @@ hipError_t pt_sweep2(hipStream_t s, int variant, const T *Pin, T *Pout, const T 
         const int ntx256 = (p.nx - 4 + 253) / 254 > 0 ? (p.nx - 4 + 253) / 254 : 1;
         const bool rows_fill_256 = nxi >= 200 && (double)nxi / (256.0 * ntx256) >= 0.95;
         if (rows_fill_256 && cells >= 64ll * 1000 * 1000) shape = sizeof(T) == 8 ? 13 : 11;   // 256×12 (fp64) / 256×8 (fp32)
-        else shape = nxi > 64 ? 8 : 7;          // 128×8 / 64×16 with two workgroups per CU (profiles/r1b_shapes.log)
+        else shape = (nxi > 64 && cells >= 8ll * 1000 * 1000) ? 8 : 7;   // 128×8 / 64×16 with two workgroups per CU; small
+                                                                         // grids want the many workgroups of the narrow tile
         kz = 0;                                 // z-chunks that fill whole rounds of the chip (launch_sweep2)
     }
     switch (shape) {

@@ -361,7 +361,7 @@ def test_pt_exact_division_guard_extreme_values(hip, oracle, dtype, bc, mode):
 
 
 def test_pt2_first_use_tuning(hip, oracle):
-    """ns3d_set_autotune (default on): the first automatic two-iteration launch on a grid of >= 4 M cells times the tile
+    """ns3d_set_autotune (default on): the first automatic two-iteration launch on a grid of >= 1.5 M cells times the tile
     shapes on the caller's arguments; the result is the oracle's, the choice is remembered, and turning the tuner off
     returns to the built-in choice."""
     import torch
