@@ -80,7 +80,7 @@ int ns3d_set_pt_variant(ns3d_ctx *ctx, int variant);
 /* Temporal blocking: ns3d_pt_iterate / ns3d_pt_solve advance TWO PT iterations per pass over memory where the
  * schedule allows it (same results).  variant < 0 disables, 0 = automatic; otherwise shape*100 + kz with the tile
  * shapes of DESIGN.md §4.2 and kz = planes per z-chunk (1..89 literal; 0 or 91..99: as many chunks as fill two /
- * kz-90 whole rounds of workgroups on the chip). */
+ * kz-90 whole rounds of workgroups on the chip).  The environment variable NS3D_PT2_VARIANT presets it at ns3d_create. */
 int ns3d_set_pt2_variant(ns3d_ctx *ctx, int variant);
 /* Tile shape of the two-iteration sweep when no explicit variant is set: with autotune on (the default) the first
  * launch on a grid of >= 1.5 M cells times the candidate shapes on the caller's own arguments (the operation is idempotent,

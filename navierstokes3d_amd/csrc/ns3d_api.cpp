@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <mutex>
@@ -155,6 +156,7 @@ ns3d_ctx *ns3d_create(int device, int flags)
     c->pingpong_d_bytes = 0;
     c->pt_variant = 0;
     c->pt2_variant = 0; // temporal blocking on by default (ns3d_set_pt2_variant(ctx,-1) turns it off)
+    if (const char *ev = std::getenv("NS3D_PT2_VARIANT")) c->pt2_variant = std::atoi(ev);   // experiments without an API call
     c->autotune = 1;
     c->last_pt2 = 0;
     c->tune_ev[0] = c->tune_ev[1] = nullptr;
