@@ -104,12 +104,30 @@ def main():
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
     backend = os.environ.get("NS3D_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N>1 path on a single-GPU box
-    local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+    shared_gpu = backend != "nccl" or os.environ.get("NS3D_BENCH_SHARED_GPU") == "1"   # ranks may share a device (tests)
+    local_rank = local_rank % max(torch.cuda.device_count(), 1) if shared_gpu else local_rank
     torch.cuda.set_device(local_rank)
+    transport_note = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # RCCL over xGMI is the transport.  Its communicators come up lazily, so exchange one tiny plane with the z
+            # neighbours now: that warms them up, and if RCCL cannot run here (it raises, e.g. two ranks on one device)
+            # the bench falls back to the host-staged transport over gloo and says so in its JSON line.
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                from navierstokes3d_amd.halo import ZSlabGrid as _G
+                probe = torch.zeros((6, 4, 4), dtype=torch.float64, device="cuda").permute(2, 1, 0)
+                _G(4, 4, 6).update_halo(probe)
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001  (any RCCL / HIP error means: no device transport on this box)
+                transport_note = "host-staged over gloo (RCCL unavailable: %s)" % (str(e).splitlines()[0][:160],)
+                try:
+                    dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                backend = "gloo"
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group(backend)
 
@@ -231,7 +249,9 @@ def main():
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "lid-driven-cavity Poisson-only PT iteration (BASELINE configs[2])",
                        "local_grid": [nx, ny, nz], "global_grid": [nx, ny, grid.nz_g()],
-                       "decomposition": "z-slabs x%d" % world, "arith_mode": a.mode, "variant": a.variant,
+                       "decomposition": "z-slabs x%d" % world,
+                       "transport": None if world == 1 else (transport_note or ("RCCL (device planes)" if backend == "nccl" else "host-staged over " + backend)),
+                       "arith_mode": a.mode, "variant": a.variant,
                        "pt2_variant": ctx.last_pt2_variant(), "residual_after_run": err, "finite": finite},
             "hbm_gbps_algorithmic": achieved * world,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
