@@ -395,3 +395,53 @@ def test_pt2_first_use_tuning(hip, oracle):
     assert ctx.last_pt2_variant() == 0
     assert np.array_equal(hip.to_numpy(dPr), Pr) and np.array_equal(hip.to_numpy(dd), d)
     ctx.close()
+
+
+def test_full_size_512_cubed_properties(hip, oracle):
+    """BASELINE.json configs[2] at its full size (512³, 134 M cells), where the oracle cannot sweep the whole grid in test
+    time: (a) the automatically chosen two-iteration kernel, two launches of the one-thread-per-cell sweep and two of the
+    z-marching sweep give the same bits on the whole grid (three independent kernels; compared on the device);
+    (b) locality — two iterations on planes [a+2, b-2) depend only on planes [a, b) — lets the oracle check a 30-plane
+    sub-slab cut out of the middle, x/y faces and outlet plane included, bit for bit."""
+    import torch
+    n = 512
+    g = geometry(n, n, n)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(20240512)
+
+    def rnd_dev(*shape):
+        t = hip.zeros(shape)
+        t.permute(2, 1, 0).uniform_(-1.0, 1.0, generator=gen)
+        return t
+
+    P0, D0, R = rnd_dev(n, n, n), rnd_dev(n - 2, n - 2, n - 2), rnd_dev(n, n, n)
+    ctx = hip.Context(0, "strict")
+    p = _params(hip, P0, g, 0, True, 0.75)
+    # (a1) the two-iteration kernel, automatic choice (first use: the tile shapes are timed on these very arguments)
+    Pa, Da = hip.zeros((n, n, n)), hip.zeros((n - 2, n - 2, n - 2))
+    hip.pt_sweep2(P0, Pa, D0, Da, R, p, ctx=ctx)
+    # (a2/a3) two single sweeps, two different kernel families
+    results = []
+    for variant in (100, 2200):
+        ctx.set_pt_variant(variant)
+        Pb, Pc, Db = hip.zeros((n, n, n)), hip.zeros((n, n, n)), hip.clone(D0)
+        hip.pt_sweep(P0, Pb, Db, R, p, 1, n - 1, ctx=ctx)
+        hip.pt_sweep(Pb, Pc, Db, R, p, 1, n - 1, ctx=ctx)
+        results.append((Pc, Db))
+        del Pb
+    torch.cuda.synchronize()
+    for Pc, Db in results:
+        assert torch.equal(Pa.view(torch.int64), Pc.view(torch.int64)), "Pr differs between kernels at 512^3"
+        assert torch.equal(Da.view(torch.int64), Db.view(torch.int64)), "dPrdτ differs between kernels at 512^3"
+    del results
+    # (b) oracle on the sub-slab of planes [a, b)
+    a, b = 240, 270
+    Ps = np.asfortranarray(hip.to_numpy(P0)[:, :, a:b])
+    Ds = np.asfortranarray(hip.to_numpy(D0)[:, :, a:b - 2])
+    Rs = np.asfortranarray(hip.to_numpy(R)[:, :, a:b])
+    gs = dict(g)
+    _oracle_iters(oracle, Ps, Ds, Rs, gs, 2, 0, True, 0.75)
+    got_P = hip.to_numpy(Pa)[:, :, a + 2:b - 2]
+    got_D = hip.to_numpy(Da)[:, :, a + 1:b - 3]          # dPrdτ index = plane − 1
+    assert np.array_equal(got_P, Ps[:, :, 2:-2])
+    assert np.array_equal(got_D, Ds[:, :, 1:-1])
+    ctx.close()
