@@ -292,3 +292,52 @@ def test_c_abi_status_codes(hip):
     assert lib.ns3d_pt_iterate_f64(h, ptr(P), ptr(D), ptr(R), C.byref(p), 3) == 0
     torch.cuda.synchronize()
     ctx.close()
+
+
+# ---- the once-per-step kernels at BASELINE's full size -----------------------------------------------------------
+def test_full_size_512_cubed_substeps_against_oracle_subslab(hip, oracle):
+    """512³ (BASELINE configs[2]): every once-per-step stencil kernel runs on the full grid; all of them are local in z
+    (radius ≤ 1 cell, advect! with |δ| < 1), so the oracle can check a 16-cell-thick sub-slab cut out of the middle —
+    all x/y faces included — bit for bit, two planes in from each cut."""
+    import torch
+    from util import SHAPES
+    n, a, b, m = 512, 250, 266, 2
+    g = geometry(n, n, n)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(512512)
+    ctx = hip.Context(0, "strict")
+
+    def rnd_dev(kind, scale=1.0):
+        t = hip.zeros(SHAPES[kind](n, n, n))
+        t.permute(2, 1, 0).uniform_(-scale, scale, generator=gen)
+        return t
+
+    def zlen(kind):                       # z extent of the sub-slab's array of that kind
+        return SHAPES[kind](n, n, b - a)[2]
+
+    def cut(t, kind):                     # host copy of the sub-slab part of a full-size device array
+        return np.asfortranarray(hip.to_numpy(t[:, :, a:a + zlen(kind)]))
+
+    def check(name, kinds, scalars, out_idx, scales=None, kwargs=None):
+        kwargs = kwargs or {}
+        dev = [rnd_dev(k, (scales or {}).get(q, 1.0)) for q, k in enumerate(kinds)]
+        ref = [cut(t, k) for t, k in zip(dev, kinds)]
+        getattr(oracle, name)(*ref, *scalars, **kwargs)
+        getattr(hip, name)(*dev, *scalars, ctx=ctx, **kwargs)
+        torch.cuda.synchronize()
+        for q in out_idx:
+            got = cut(dev[q], kinds[q])
+            assert np.array_equal(got[:, :, m:-m], ref[q][:, :, m:-m]), "%s output %d differs at 512^3" % (name, q)
+        del dev
+
+    check("update_tau", ["c", "c", "c", "s", "s", "s", "vx", "vy", "vz"], (g["mu"], g["dx"], g["dy"], g["dz"]), range(6))
+    check("predict_V", ["vx", "vy", "vz", "c", "c", "c", "s", "s", "s"],
+          (g["rho"], g["g"], g["dt"], g["dx"], g["dy"], g["dz"]), range(3))
+    check("update_divV", ["c", "vx", "vy", "vz"], (g["dx"], g["dy"], g["dz"]), [0])
+    check("correct_V", ["vx", "vy", "vz", "c"], (g["dt"], g["rho"], g["dx"], g["dy"], g["dz"]), range(3))
+    check("update_dPrdtau", ["c", "i", "c"], (g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"]), [1])
+    check("compute_res", ["i", "c", "c"], (g["rho"], g["dt"], g["dx"], g["dy"], g["dz"]), [0])
+    # advect!(Vx,Vx_o,Vy,Vy_o,Vz,Vz_o,C,C_o,…): old velocities scaled so that |δ| = |v·dt/dx| < 0.4 cells
+    vs = 0.4 * g["dx"] / g["dt"]
+    check("advect", ["vx", "vx", "vy", "vy", "vz", "vz", "c", "c"], (g["dt"], g["dx"], g["dy"], g["dz"], True),
+          [0, 2, 4, 6], scales={1: vs, 3: vs, 5: vs})
+    ctx.close()
