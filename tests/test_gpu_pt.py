@@ -397,7 +397,8 @@ def test_pt2_first_use_tuning(hip, oracle):
     ctx.close()
 
 
-def test_full_size_512_cubed_properties(hip, oracle):
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_full_size_512_cubed_properties(hip, oracle, dtype):
     """BASELINE.json configs[2] at its full size (512³, 134 M cells), where the oracle cannot sweep the whole grid in test
     time: (a) the automatically chosen two-iteration kernel, two launches of the one-thread-per-cell sweep and two of the
     z-marching sweep give the same bits on the whole grid (three independent kernels; compared on the device);
@@ -407,9 +408,11 @@ def test_full_size_512_cubed_properties(hip, oracle):
     n = 512
     g = geometry(n, n, n)
     gen = torch.Generator(device="cuda"); gen.manual_seed(20240512)
+    tdt, bits = (torch.float64, torch.int64) if dtype == "f64" else (torch.float32, torch.int32)
+    zeros = lambda shape: hip.zeros(shape, tdt)
 
     def rnd_dev(*shape):
-        t = hip.zeros(shape)
+        t = zeros(shape)
         t.permute(2, 1, 0).uniform_(-1.0, 1.0, generator=gen)
         return t
 
@@ -417,21 +420,21 @@ def test_full_size_512_cubed_properties(hip, oracle):
     ctx = hip.Context(0, "strict")
     p = _params(hip, P0, g, 0, True, 0.75)
     # (a1) the two-iteration kernel, automatic choice (first use: the tile shapes are timed on these very arguments)
-    Pa, Da = hip.zeros((n, n, n)), hip.zeros((n - 2, n - 2, n - 2))
+    Pa, Da = zeros((n, n, n)), zeros((n - 2, n - 2, n - 2))
     hip.pt_sweep2(P0, Pa, D0, Da, R, p, ctx=ctx)
     # (a2/a3) two single sweeps, two different kernel families
     results = []
     for variant in (100, 2200):
         ctx.set_pt_variant(variant)
-        Pb, Pc, Db = hip.zeros((n, n, n)), hip.zeros((n, n, n)), hip.clone(D0)
+        Pb, Pc, Db = zeros((n, n, n)), zeros((n, n, n)), hip.clone(D0)
         hip.pt_sweep(P0, Pb, Db, R, p, 1, n - 1, ctx=ctx)
         hip.pt_sweep(Pb, Pc, Db, R, p, 1, n - 1, ctx=ctx)
         results.append((Pc, Db))
         del Pb
     torch.cuda.synchronize()
     for Pc, Db in results:
-        assert torch.equal(Pa.view(torch.int64), Pc.view(torch.int64)), "Pr differs between kernels at 512^3"
-        assert torch.equal(Da.view(torch.int64), Db.view(torch.int64)), "dPrdτ differs between kernels at 512^3"
+        assert torch.equal(Pa.view(bits), Pc.view(bits)), "Pr differs between kernels at 512^3"
+        assert torch.equal(Da.view(bits), Db.view(bits)), "dPrdτ differs between kernels at 512^3"
     del results
     # (b) oracle on the sub-slab of planes [a, b)
     a, b = 240, 270
