@@ -72,3 +72,78 @@ def test_zslab_ranks_one_gpu(hip, world, fused, temporal):
             assert np.array_equal(a, ref[-1].ranks[r][n], equal_nan=True), (r, n)
     for n, a, b in zip(("C", "Pr", "Vx", "Vy", "Vz"), results[0][3], ref[:5]):
         assert np.array_equal(a, b, equal_nan=True), n
+
+
+def _slab_worker(rank, world, port, shape, n_iters, q):
+    try:
+        import faulthandler
+        faulthandler.dump_traceback_later(120, exit=True)       # a hung rank reports where it hangs instead of stalling the suite
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from navierstokes3d_amd import kernels as K, lib as L
+        from navierstokes3d_amd.halo import ZSlabGrid
+        from navierstokes3d_amd.slab import SlabPTSolver
+        from util import fields, geometry
+        nx, ny, nz = shape
+        nz_g = world * (nz - 2) + 2
+        g = geometry(nx, ny, nz_g)
+        Pg, Dg, Rg = fields(nx, ny, nz_g, ["c", "i", "c"], 211)          # the same global fields on every rank
+        lo = rank * (nz - 2)
+        Pr, R = K.from_numpy(Pg[:, :, lo:lo + nz]), K.from_numpy(Rg[:, :, lo:lo + nz])
+        D = K.from_numpy(Dg[:, :, lo:lo + nz - 2])
+        grid = ZSlabGrid(nx, ny, nz)
+        ctx = K.Context(0, "strict")
+        sol = SlabPTSolver(ctx, grid, Pr, g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"],
+                           L.NS3D_BC_MULTI, True, 0.25, 0.0)
+        sol.load(Pr, D, R)
+        sol.iterate(n_iters)
+        sol.store(Pr, D)
+        torch.cuda.synchronize()
+        q.put((rank, "OK", K.to_numpy(Pr), K.to_numpy(D)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, "ERROR", traceback.format_exc(), None))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_solver_equals_global_solve_large(hip, world):
+    """Decomposition independence at a size where the tuned two-iteration kernels run (≈2 M cells per interior launch):
+    seven PT iterations on `world` z-slab ranks (deep-ghost schedule, seam planes first) leave exactly the planes of the
+    single-device solve of the global grid — every local plane, halo planes included."""
+    import torch
+    from util import fields, geometry
+    shape, n_iters = (200, 160, 66), 7
+    nx, ny, nz = shape
+    nz_g = world * (nz - 2) + 2
+    g = geometry(nx, ny, nz_g)
+    Pg, Dg, Rg = fields(nx, ny, nz_g, ["c", "i", "c"], 211)
+    ctx = hip.Context(0, "strict")
+    dP, dD = hip.from_numpy(Pg), hip.from_numpy(Dg)
+    p = hip.pt_params(dP, g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, True, 0.25, 0.0)
+    hip.pt_iterate(dP, dD, hip.from_numpy(Rg), p, n_iters, ctx=ctx)
+    torch.cuda.synchronize()
+    Pref, Dref = hip.to_numpy(dP), hip.to_numpy(dD)
+    ctx.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_slab_worker, args=(r, world, port, shape, n_iters, q), daemon=True) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = {}
+    for _ in range(world):
+        r = q.get(timeout=240)
+        assert r[1] == "OK", r[2]
+        got[r[0]] = r
+    for pr in procs:
+        pr.join(timeout=60)
+    for r in range(world):
+        lo = r * (nz - 2)
+        assert np.array_equal(got[r][2], Pref[:, :, lo:lo + nz]), "Pr of rank %d" % r
+        assert np.array_equal(got[r][3], Dref[:, :, lo:lo + nz - 2]), "dPrdτ of rank %d" % r
