@@ -1513,23 +1513,14 @@ hipError_t pt_sweep2(hipStream_t s, int variant, const T *Pin, T *Pout, const T 
     case 1: return launch_sweep2<T, 4, 2, 4, true>(s, a, kz);   // 256 x 8
     case 2: return launch_sweep2<T, 2, 4, 4, true>(s, a, kz);   // 128 x 16
     case 3: return launch_sweep2<T, 1, 8, 4, true>(s, a, kz);   //  64 x 32
-    case 4: return launch_sweep2<T, 4, 2, 4, false>(s, a, kz);  // 256 x 8, plain loads/stores
-    case 5: return launch_sweep2<T, 4, 1, 4, true>(s, a, kz);   // 256 x 4 (256 threads)
     case 6: return launch_sweep2<T, 2, 2, 4, true>(s, a, kz);   // 128 x 8 (256 threads)
     // boundary cells by separate launches (SEPF): leaner hot kernel, larger tiles / more workgroups per CU
     case 7: return launch_sweep2<T, 1, 8, 2, true, 4, true>(s, a, kz);  //  64 x 16, ≤128 VGPRs: two workgroups per CU
     case 8: return launch_sweep2<T, 2, 4, 2, true, 4, true>(s, a, kz);  // 128 x 8,  ≤128 VGPRs
     case 9: return launch_sweep2<T, 1, 8, 4, true, 1, true>(s, a, kz);  //  64 x 32
-    case 10: return launch_sweep2<T, 1, 8, 6, true, 1, true>(s, a, kz); //  64 x 48
     case 11: return launch_sweep2<T, 4, 2, 4, true, (sizeof(T) == 4 ? 4 : 1), true>(s, a, kz); // 256 x 8 (fp32: four waves per SIMD = ≤128 VGPRs = two workgroups per CU)
     case 12: return launch_sweep2<T, 2, 4, 6, true, 1, true>(s, a, kz); // 128 x 24
     case 13: return launch_sweep2<T, 4, 2, 6, true, 1, true>(s, a, kz); // 256 x 12
-    case 14: return launch_sweep2<T, 2, 4, 4, true, 1, true>(s, a, kz); // 128 x 16
-    // 256-thread workgroups, two or more per CU: independent barrier groups on one CU
-    case 15: return launch_sweep2<T, 2, 2, 4, true, 1, true>(s, a, kz); // 128 x 8
-    case 16: return launch_sweep2<T, 2, 2, 6, true, 1, true>(s, a, kz); // 128 x 12
-    case 17: return launch_sweep2<T, 1, 4, 6, true, 1, true>(s, a, kz); //  64 x 24
-    case 18: return launch_sweep2<T, 1, 4, 4, true, 1, true>(s, a, kz); //  64 x 16
     case 19: return launch_sweep2<T, 4, 4, 2, true, 4, true>(s, a, kz); // 256 x 8, 1024 threads with two rows each: four waves per SIMD
     default: // shape by row length: the widest tile whose overlap-2 tiling wastes the fewest lanes
         if (nxi > 128) return launch_sweep2<T, 4, 2, 4, true>(s, a, kz);

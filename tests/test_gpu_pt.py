@@ -158,8 +158,8 @@ def test_pt_f32(hip, oracle):
 
 
 # ---- temporal blocking: two PT iterations per pass over memory -------------------------------------------------
-SHAPES2 = [0, 100, 200, 300, 400, 500, 600, 103, 207, 101, 364, 316, 700, 800, 900, 1000, 1100, 1200, 703, 1002, 904,
-           1300, 1400, 1500, 1600, 1700, 1800, 1503, 1605, 1900, 1905, 1392, 891]
+SHAPES2 = [0, 100, 200, 300, 600, 103, 207, 101, 364, 316, 700, 800, 900, 1100, 1200, 703, 904,
+           1300, 1900, 1905, 1392, 891]
 GRIDS2 = GRIDS + [(260, 19, 9), (131, 40, 6), (66, 70, 5)]
 
 
@@ -233,7 +233,7 @@ def test_pt_sweep2_tile_edge_sizes(hip, oracle, grid):
     Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
     _oracle_iters(oracle, Pr, d, rhs, g, 2, 0, True, 0.5)
     ctx = hip.Context(0, "strict")
-    for shape in (100, 200, 300, 500, 600, 104, 302, 0, 700, 800, 900, 1000, 1100, 1200, 1003, 1500, 1600, 1700, 1800, 1900, 1392, 894):
+    for shape in (100, 200, 300, 600, 104, 302, 0, 700, 800, 900, 1100, 1200, 1103, 1300, 1900, 1392, 894):
         ctx.set_pt2_variant(shape)
         dPr, dout, dd = hip.from_numpy(Pr0), hip.from_numpy(np.full_like(Pr0, 555.0)), hip.from_numpy(d0)
         ddout = hip.from_numpy(np.full_like(d0, 444.0))
@@ -349,7 +349,7 @@ def test_pt_exact_division_guard_extreme_values(hip, oracle, dtype, bc, mode):
                 hip.pt_iterate(dPr, dd, hip.from_numpy(rhs), p, 1, ctx=ctx)
                 torch.cuda.synchronize()
                 assert _bits_equal(hip.to_numpy(dPr), ref[1][0]) and _bits_equal(hip.to_numpy(dd), ref[1][1]), (grid, variant)
-            for shape in (100, 300, 600, 1100, 1200, 703, 1500, 1800, 1900):
+            for shape in (100, 300, 600, 1100, 1200, 703, 1300, 1900):
                 ctx.set_pt2_variant(shape)
                 dPr, dout, dd = hip.from_numpy(Pr0), hip.from_numpy(np.full_like(Pr0, 555.0)), hip.from_numpy(d0)
                 ddout = hip.from_numpy(np.full_like(d0, 444.0))
