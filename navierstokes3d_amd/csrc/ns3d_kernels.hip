@@ -1070,20 +1070,21 @@ static hipError_t launch_pipe_auto(hipStream_t s, SweepArgs<T> &a, int kz)
 // ≈(24·overlap + 16) B per cell per TWO iterations.  Every value is computed with exactly the arithmetic of the
 // single sweep (same expression tree per cell), so the result is bit-identical to two k_pt_sweep launches.
 //
-// Workgroup = 512 threads = WX×WY waves; tile = TX×TY columns (TX = 64·WX in x, TY = CPT·WY in y, CPT consecutive
+// Workgroup = WX×WY waves (512 or 1024 threads); tile = TX×TY columns (TX = 64·WX in x, TY = CPT·WY in y, CPT consecutive
 // rows per thread), marched in z.  Per z-step s the workgroup produces level 1 of plane k1 and level 2 of plane
 // k2 = k1−1:
 //   registers (per column): P⁰[k1−1], P⁰[k1], P⁰[k1+1]; P¹[k2−1], P¹[k2]; d¹[k2], ∇V[k2]           (own-column z rings)
 //   LDS (double-buffered):  plane k1 of P⁰ incl. a one-cell halo ring (x/y neighbours for level 1),
 //                           plane k2 of P¹                              (x/y neighbours for level 2)
-//   one __syncthreads() per step; the loads of step s+1 (P⁰[k1+2], d⁰[k1+1], ∇V[k1+1], halo ring of plane k1+2) are
-//   issued between the two levels so that level 2's arithmetic hides their latency.
+//   one __syncthreads() per step; the loads of step s+1 (P⁰[k1+2] and the halo ring of plane k1+2 between the two
+//   levels, d⁰[k1+1] and ∇V[k1+1] after level 2 — or all of them before level 1, see EARLY) are in flight behind arithmetic.
 // Level 1 is evaluated on every interior column of the tile (its x/y neighbours outside the tile come from the
 // halo ring, loaded straight from P⁰), level 2 on the columns whose four neighbours are in the tile or are domain
 // faces; tiles therefore overlap by two columns/rows, z-chunks by two planes.  Faces of P¹ are never materialised:
 // where a level-2 stencil touches a face the boundary rule is substituted (Neumann: the cell's own P¹; outlet:
-// outlet_val; gpu.jl x planes: hydrostatic value).  Faces of P² are stored by the producing thread as in the
-// single sweep.  z planes that are inter-slab halos are not supported here (the z-slab schedule uses single sweeps).
+// outlet_val; gpu.jl x planes: hydrostatic value).  Faces of P² are stored by the producing thread as in the single
+// sweep, or (SEPF) only the x-face cell beside an interior cell, the y/z faces following in k_pt_faces_*.  z planes that
+// are inter-slab halos are not supported here: z-slab ranks pass buffers extended by a second ghost plane (slab.py).
 // =========================================================================================================
 template <class T, int WX, int WY, int CPT, bool NT, int MINW = 1, bool SEPF = false>
 __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a, int ntx, int nty)
