@@ -12,13 +12,25 @@ launches of the two-iteration kernel k_pt_sweep2 (one single-iteration launch mo
 in HBM before the timed region; an untimed plan phase before the warm-up lets the library time its tile shapes once.
 For N>1 every rank owns one 512×512×512 z-slab of an implicit global grid 512×512×(N·510+2) (weak scaling, the
 reference's own model: local size fixed, multi.jl:325,338); per two iterations two planes of Pr and one of dPrdτ travel
-to each z neighbour over RCCL/xGMI behind the interior sweep (navierstokes3d_amd/slab.py).
+to each z neighbour behind the interior sweep — by RCCL send/recv over xGMI inside libns3d.so (ns3d_mgpu_create_rank,
+ns3d_slab_iterate).  `python bench.py --gpus N` without a launcher starts its N ranks itself (torch.distributed.run as a
+child process, before this process touches the GPU).  The ranks agree COLLECTIVELY on the transport: a gloo group comes up
+first (control plane: unique id, barriers, timing), RCCL is brought up and probed with a verified plane exchange, and only
+if every rank succeeded is it used; otherwise all ranks together take the host-staged transport over gloo and the line says so.
+
+roofline.frac is a physical fraction (SURVEY.md §8d "Roofline fraction = achieved / 8000 GB/s" with the bytes one launch
+MUST move: one pass over Pr, ∇V, dPrdτ in and dPrdτ, Pr out = itemsize·(N + 4·N_inner), however many PT iterations the
+launch advances) and is ≤ 1; the metric's "achieved HBM GB/s = algorithmic_bytes · iters / wall" (40 B per cell and
+ITERATION, §8d) is reported next to it as hbm_gbps_algorithmic / roofline.effective_frac and exceeds the physical number by
+the temporal-blocking factor.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -79,6 +91,76 @@ def cpu_baseline(n, nzs, iters, dtype):
     }
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` typed as is: start the N ranks as children (one process per GPU) and relay rank 0's line.
+    Runs before this process has made any GPU call (device_count() does not initialise the GPU on this image)."""
+    ndev = torch.cuda.device_count()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if ndev < a.gpus:           # rehearsal on a smaller box: ranks share devices, RCCL cannot run, the line says so
+        env["NS3D_BENCH_SHARED_GPU"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1])
+    else:
+        sys.stderr.write(r.stdout)
+    return r.returncode if (r.returncode or lines) else 1
+
+
+def agree(ok):
+    """every rank takes the same branch: MIN of the ranks' ok flags over the gloo control group"""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
+def bring_up_rccl(world, rank, device, nx, ny, nz, mode, tdt):
+    """libns3d's own RCCL communicator (ns3d_mgpu_create_rank), probed with a verified plane exchange.  Every stage ends
+    with a collective agreement, so either all ranks return a MultiGpu or all return (None, reason)."""
+    from navierstokes3d_amd import kernels as K
+    from navierstokes3d_amd import lib as L
+    from navierstokes3d_amd.mgpu import MultiGpu
+    why, uid = "", None
+    try:                                            # stage 1: RCCL loads everywhere (dlopen) and makes an id
+        uid = MultiGpu.unique_id()
+    except L.Ns3dError as e:
+        why = str(e)
+    if not agree(uid is not None):
+        return None, "RCCL not loadable on every rank" + (": " + why if why else "")
+    box = [uid]
+    dist.broadcast_object_list(box, src=0)
+    mg = None
+    try:                                            # stage 2: communicator
+        mg = MultiGpu.create_rank(world, rank, device, box[0], nx, ny, nz, mode)
+    except L.Ns3dError as e:
+        why = str(e)
+    if not agree(mg is not None):
+        if mg is not None:
+            mg.close()
+        return None, "ncclCommInitRank failed on a rank" + (": " + why if why else "")
+    ok = True
+    try:                                            # stage 3: one plane to each z neighbour and back, contents checked
+        probe = K.zeros((8, 8, nz), tdt, torch.device("cuda", device))      # nz planes: overlap 2 like a cell-centred field
+        probe.fill_(float(rank + 1))
+        mg.update_halo(probe)
+        mg.sync()
+        lo, hi = probe[0, 0, 0].item(), probe[7, 7, nz - 1].item()
+        ok = (lo == (rank if rank > 0 else rank + 1)) and (hi == (rank + 2 if rank < world - 1 else rank + 1))
+        ok = ok and mg.rccl_ranks() == world
+        if not ok:
+            why = "probe exchange returned wrong planes (%r, %r)" % (lo, hi)
+    except L.Ns3dError as e:
+        ok, why = False, str(e)
+    if not agree(ok):
+        mg.close()
+        return None, "RCCL probe exchange failed on a rank" + (": " + why if why else "")
+    return mg, ""
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,40 +178,25 @@ def main():
     ap.add_argument("--no-autotune", action="store_true", help="built-in tile choice instead of timing the shapes once")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=12)
+    ap.add_argument("--transport", default=os.environ.get("NS3D_BENCH_TRANSPORT", "auto"), choices=["auto", "rccl", "host"],
+                    help="N>1: rccl = libns3d's RCCL communicator (fails loudly if it cannot come up), host = host-staged "
+                         "over gloo, auto = rccl with a collective fall-back to host")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
-    backend = os.environ.get("NS3D_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N>1 path on a single-GPU box
-    shared_gpu = backend != "nccl" or os.environ.get("NS3D_BENCH_SHARED_GPU") == "1"   # ranks may share a device (tests)
-    local_rank = local_rank % max(torch.cuda.device_count(), 1) if shared_gpu else local_rank
-    torch.cuda.set_device(local_rank)
-    transport_note = None
+    if world != a.gpus:
+        raise SystemExit("bench.py --gpus %d runs under a launcher with WORLD_SIZE=%d" % (a.gpus, world))
+    ndev = max(torch.cuda.device_count(), 1)
+    shared_gpu = os.environ.get("NS3D_BENCH_SHARED_GPU") == "1" or os.environ.get("NS3D_BENCH_BACKEND") == "gloo" or ndev < world
+    device = local_rank % ndev
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            # RCCL over xGMI is the transport.  Its communicators come up lazily, so exchange one tiny plane with the z
-            # neighbours now: that warms them up, and if RCCL cannot run here (it raises, e.g. two ranks on one device)
-            # the bench falls back to the host-staged transport over gloo and says so in its JSON line.
-            try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-                from navierstokes3d_amd.halo import ZSlabGrid as _G
-                probe = torch.zeros((6, 4, 4), dtype=torch.float64, device="cuda").permute(2, 1, 0)
-                _G(4, 4, 6).update_halo(probe)
-                torch.cuda.synchronize()
-            except Exception as e:  # noqa: BLE001  (any RCCL / HIP error means: no device transport on this box)
-                transport_note = "host-staged over gloo (RCCL unavailable: %s)" % (str(e).splitlines()[0][:160],)
-                try:
-                    dist.destroy_process_group()
-                except Exception:  # noqa: BLE001
-                    pass
-                backend = "gloo"
-                dist.init_process_group("gloo")
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group("gloo")             # control plane; the data plane is libns3d's RCCL communicator
 
     from navierstokes3d_amd import build
     if rank == 0:
@@ -149,10 +216,33 @@ def main():
         p.dz = p.dx
     nx, ny, nz = p.nx, p.ny, p.nz
     tdt = torch.float64 if a.dtype == "f64" else torch.float32
-    dev = torch.device("cuda", local_rank)
-    ctx = K.Context(local_rank, a.mode, async_=True)
+    dev = torch.device("cuda", device)
+
+    # ---- transport of the z-slab ranks, agreed collectively ---------------------------------------------------
+    mg, transport, rccl_ranks = None, None, 0
+    if world > 1:
+        want = "host" if (shared_gpu and a.transport == "auto") else a.transport
+        reason = "%d ranks share %d device(s)" % (world, ndev) if shared_gpu else "requested"
+        if want in ("auto", "rccl"):
+            mg, why = bring_up_rccl(world, rank, device, nx, ny, nz, a.mode, tdt)
+            if mg is None:
+                if want == "rccl":
+                    raise SystemExit("bench.py --transport rccl: " + why)
+                reason = why
+        if mg is not None:
+            transport, rccl_ranks = "RCCL send/recv over xGMI inside libns3d (ns3d_mgpu_create_rank)", mg.rccl_ranks()
+        else:
+            transport = "host-staged over gloo (%s)" % reason[:200]
+    if mg is not None:
+        ctx = mg.contexts[0]
+    else:
+        ctx = K.Context(device, a.mode, async_=True)
     ctx.set_pt_variant(a.variant)
-    grid = ZSlabGrid(nx, ny, nz)
+    if a.variant2 is not None:
+        ctx.set_pt2_variant(a.variant2)
+    if a.no_autotune:
+        ctx.set_autotune(False)
+    grid = ZSlabGrid(nx, ny, nz, transport="host") if world > 1 else ZSlabGrid(nx, ny, nz)
 
     # synthetic right-hand side ∇V = U(-1e-3,1e-3), seeded per rank; Pr = dPrdτ = 0 (SURVEY §8d Config 3)
     gen = torch.Generator(device=dev); gen.manual_seed(12345 + rank)
@@ -164,41 +254,51 @@ def main():
     pt = K.pt_params(Pr, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, L.NS3D_BC_MULTI, False, 0.0, 0.0,
                      grid.z_lo_is_halo(), grid.z_hi_is_halo())
 
-    use2 = (world == 1) and not a.no_temporal_blocking
+    depth = 1 if a.no_temporal_blocking else 2      # PT iterations per pass over memory
+    use2 = (world == 1) and depth == 2
     slab = None
-    if world > 1:
+    if mg is not None:                              # the whole schedule inside libns3d: ns3d_slab_load / _plan / _iterate
+        mg.set_temporal(depth)
+        mg.update_halo(rhs)                         # update_halo!(∇V), multi.jl:455: the seam planes of the RHS agree
+        mg.slab_load(Pr, D, rhs, pt)
+        if not a.no_autotune:
+            mg.slab_plan()                          # plan phase, untimed: tile shape of the interior sweeps
+    elif world > 1:
         from navierstokes3d_amd.slab import SlabPTSolver
+        grid.update_halo(rhs)
         slab = SlabPTSolver(ctx, grid, Pr, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, L.NS3D_BC_MULTI, False, 0.0, 0.0)
-        slab.set_temporal_blocking(not a.no_temporal_blocking)
+        slab.set_temporal_blocking(depth == 2)
         slab.load(Pr, D, rhs)
-    if a.variant2 is not None:
-        ctx.set_pt2_variant(a.variant2)
     D2 = K.zeros((nx - 2, ny - 2, nz - 2), tdt, dev) if use2 else None
 
     def run(n):
-        """n PT iterations {update_dPrdτ!; update_Pr!; set_bc_Pr!}.  One GPU: ns3d_pt_iterate (two iterations per
-        pass over memory where n allows).  z-slab ranks: seam planes first, their exchange behind the interior sweep."""
+        """n PT iterations {update_dPrdτ!; update_Pr!; set_bc_Pr!}.  One GPU: what ns3d_pt_iterate does, with the buffer
+        swaps visible (two iterations per pass over memory where n allows).  z-slab ranks: seam planes first, their
+        exchange behind the interior sweep."""
         nonlocal Pr, Pb, D, D2
-        if world == 1 and use2:
-            for _ in range(n // 2):                      # what ns3d_pt_iterate does, with the buffer swaps visible
+        if mg is not None:
+            mg.slab_iterate(n)
+            return
+        if slab is not None:
+            slab.iterate(n)
+            return
+        if use2:
+            for _ in range(n // 2):
                 K.pt_sweep2(Pr, Pb, D, D2, rhs, pt, ctx=ctx)
                 Pr, Pb, D, D2 = Pb, Pr, D2, D
             n = n % 2
-        if world == 1:
-            for _ in range(n):
-                K.pt_sweep(Pr, Pb, D, rhs, pt, 1, nz - 1, ctx=ctx)
-                Pr, Pb = Pb, Pr
-            return
-        slab.iterate(n)      # seam planes first, 2-plane ghost exchange behind the interior sweep (slab.py)
+        for _ in range(n):
+            K.pt_sweep(Pr, Pb, D, rhs, pt, 1, nz - 1, ctx=ctx)
+            Pr, Pb = Pb, Pr
 
-    # plan phase, untimed and outside the warmup count: the first two-iteration launch on a grid times the tile shapes
-    # of k_pt_sweep2 and the context keeps the winner (ns3d_set_autotune; every shape gives the same bits)
-    if a.no_autotune:
-        ctx.set_autotune(False)
-    if not a.no_temporal_blocking:
-        run(2)
+    # plan phase, untimed and outside the warmup count: ns3d_plan_pt times the tile shapes of k_pt_sweep2 on these
+    # arguments and the process keeps the winner (every shape gives the same bits)
+    if use2 and not a.no_autotune:
+        K.plan_pt(Pr, Pb, D, D2, rhs, pt, ctx=ctx)
+        Pb.zero_(); D2.zero_()
         torch.cuda.synchronize()
     run(a.warmup)
+    torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -213,21 +313,28 @@ def main():
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        t = torch.tensor([wall, dev_ms], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, dev_ms = t[0].item(), t[1].item()
-    err = (slab.residual() if slab is not None else K.residual_max(Pr, rhs, pt, ctx=ctx)) * (p.ly * p.ly) / p.psc
+    if mg is not None:
+        err = mg.slab_residual()
+    elif slab is not None:
+        err = slab.residual()
+    else:
+        err = K.residual_max(Pr, rhs, pt, ctx=ctx)
+    err = err * (p.ly * p.ly) / p.psc
     finite = bool(np.isfinite(err))
 
     if rank == 0:
         cells_g = nx * ny * grid.nz_g()
         itemsize = 8 if a.dtype == "f64" else 4
         # the dominant kernel: k_pt_sweep2 advances TWO iterations per launch (k_pt_sweep: one)
-        its_per_launch = 2 if (not a.no_temporal_blocking) and a.steps >= 2 else 1
+        its_per_launch = 2 if depth == 2 and a.steps >= 2 else 1
         launches = a.steps // 2 + a.steps % 2 if its_per_launch == 2 else a.steps
         kern_ms = dev_ms / launches                  # HIP events around the timed launches on the launch stream
-        abytes = its_per_launch * algorithmic_bytes(nx, ny, nz, itemsize)
-        achieved = a.steps * algorithmic_bytes(nx, ny, nz, itemsize) / (dev_ms * 1e-3) / 1e9
+        must_move = algorithmic_bytes(nx, ny, nz, itemsize)          # bytes ONE pass has to move, per launch
+        physical = must_move / (kern_ms * 1e-3) / 1e9
+        effective = a.steps * algorithmic_bytes(nx, ny, nz, itemsize) / (dev_ms * 1e-3) / 1e9   # 40 B per cell and iteration
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "pt_sweep_traffic.json")
         if world == 1 and os.path.exists(tfile):
@@ -250,15 +357,20 @@ def main():
             "config": {"workload": "lid-driven-cavity Poisson-only PT iteration (BASELINE configs[2])",
                        "local_grid": [nx, ny, nz], "global_grid": [nx, ny, grid.nz_g()],
                        "decomposition": "z-slabs x%d" % world,
-                       "transport": None if world == 1 else (transport_note or ("RCCL (device planes)" if backend == "nccl" else "host-staged over " + backend)),
+                       "transport": transport, "rccl_ranks": rccl_ranks,
                        "arith_mode": a.mode, "variant": a.variant,
                        "pt2_variant": ctx.last_pt2_variant(), "residual_after_run": err, "finite": finite},
-            "hbm_gbps_algorithmic": achieved * world,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+            "hbm_gbps_algorithmic": effective * world,
+            "roofline": {"bound": "hbm", "achieved": physical, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": physical / HBM_PEAK_GBPS,
+                         "definition": "bytes one launch must move (one pass: itemsize*(N+4*N_inner)) / launch time / peak",
+                         "traffic": traffic, "traffic_source": "profiles lookup" if traffic is not None else "none",
                          "kernel": "k_pt_sweep2" if its_per_launch == 2 else "k_pt_sweep",
-                         "kernel_ms": kern_ms if world == 1 else None,
-                         "pt_iterations_per_launch": its_per_launch, "algorithmic_bytes_per_launch": abytes},
+                         "kernel_ms": kern_ms,
+                         "pt_iterations_per_launch": its_per_launch, "bytes_per_launch": must_move,
+                         "effective_gbps": effective, "effective_frac": effective / HBM_PEAK_GBPS,
+                         "effective_definition": "SURVEY 8d: 40 B per cell and PT ITERATION (itemsize*(N+4*N_inner) per "
+                                                 "iteration) / time / peak; exceeds frac by the temporal-blocking factor"},
         }
         if world == 1 and not a.no_cpu_baseline:
             try:
@@ -268,7 +380,10 @@ def main():
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(out))
     ctx.sync()
+    if mg is not None:
+        mg.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

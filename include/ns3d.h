@@ -45,7 +45,8 @@ enum {
     NS3D_OK = 0,
     NS3D_ERR_ARG = 1,   /* bad argument (null pointer, extent too small, …) */
     NS3D_ERR_HIP = 2,   /* a HIP runtime call or kernel launch failed */
-    NS3D_ERR_STATE = 3  /* context misuse */
+    NS3D_ERR_STATE = 3, /* context misuse */
+    NS3D_ERR_RCCL = 4   /* RCCL could not be loaded, or an RCCL call failed */
 };
 
 enum {
@@ -185,6 +186,13 @@ typedef struct ns3d_pt_params {
      * z-slab ranks run it on buffers extended by a second ghost plane per seam. */              \
     int ns3d_pt_sweep2_##S(ns3d_ctx *, const T *Pr_in, T *Pr_out, const T *dPrdtau_in, T *dPrdtau_out,       \
                            const T *divV, const ns3d_pt_params *p, int k0, int k1);                          \
+    /* Plan phase of the two-iteration sweep (ns3d_set_autotune): times the tile shapes NOW on these very arguments  \
+     * (idempotent: inputs and outputs are distinct buffers; every shape gives the same bits) and remembers the       \
+     * winner per device, grid and plane range for the rest of the process.  Blocks.  ns3d_pt_iterate / ns3d_pt_solve \
+     * plan on first use by themselves; ns3d_pt_sweep2 never measures — it looks the choice up (built-in shape when   \
+     * nothing was planned).  Pr_out / dPrdtau_out hold the result of one two-iteration pass afterwards. */           \
+    int ns3d_plan_pt_##S(ns3d_ctx *, const T *Pr_in, T *Pr_out, const T *dPrdtau_in, T *dPrdtau_out,         \
+                         const T *divV, const ns3d_pt_params *p, int k0, int k1);                            \
     /* max|∇²Pr − ρ/dt ∇V| over the interior = maximum(abs.(Rp)) after compute_res!, without writing Rp.   \
      * NaN-propagating.  (multi.jl:465-466) */                                                               \
     int ns3d_residual_max_##S(ns3d_ctx *, const T *Pr, const T *divV, const ns3d_pt_params *p,               \
@@ -203,6 +211,69 @@ typedef struct ns3d_pt_params {
 NS3D_DECL(double, f64)
 NS3D_DECL(float, f32)
 #undef NS3D_DECL
+
+/* =====================================================================================================================
+ * Multi-GPU: z-slab implicit global grid.  Replaces what multi.jl gets from ImplicitGlobalGrid.jl + MPI.jl:
+ *     init_global_grid(nx,ny,nz)   multi.jl:325      →  ns3d_mgpu_create / ns3d_mgpu_create_rank   (dims = (1,1,P))
+ *     update_halo!(A…)             multi.jl:371,373,450,453,455,460,462,182,167,477  →  ns3d_update_halo
+ *     max_g(A)                     multi.jl:21,466   →  ns3d_max_g
+ *     gather!(A_inn, A_v)          multi.jl:399-403,528-532  →  ns3d_gather
+ *     nz_g()                       multi.jl:328,338  →  ns3d_mgpu_nz_g            finalize_global_grid() :534 → ns3d_mgpu_destroy
+ * ImplicitGlobalGrid's indexing is kept: overlap 2, halo width 1, nz_g = P·(nz−2)+2; an array with nz+s planes has overlap
+ * 2+s (sends plane 2+s / size−(1+s), receives into 1 / size, 1-based); arrays with overlap < 2 have no halo; physical ends
+ * are left untouched.  Column-major xy-planes are contiguous, so every message is one block (no packing).
+ *
+ * An ns3d_mgpu holds `nlocal` of the P ranks: all P in the one-process form (ns3d_mgpu_create; planes move by
+ * hipMemcpyPeerAsync over xGMI; a device may appear several times — virtual ranks), exactly one in the one-process-per-GPU
+ * form (ns3d_mgpu_create_rank; planes move by RCCL send/recv on a dedicated stream, the residual by ncclAllReduce).
+ * Every per-rank argument is an array of nlocal entries in local-rank order; field lists are field-major:
+ * fields[f*nlocal + l].  Kernels for local rank l run on ns3d_mgpu_ctx(m, l).  Calls are ordered with the work already
+ * enqueued on those contexts' streams and block unless `flags` had NS3D_ASYNC.
+ * ===================================================================================================================== */
+typedef struct ns3d_mgpu ns3d_mgpu;
+#define NS3D_UNIQUE_ID_BYTES 128
+
+ns3d_mgpu *ns3d_mgpu_create(int P, const int *devices, int nx, int ny, int nz_local, int flags);
+/* One process per GPU: rank 0 calls ns3d_mgpu_unique_id and distributes the NS3D_UNIQUE_ID_BYTES bytes (MPI.Bcast in the
+ * reference's setting), then every rank calls ns3d_mgpu_create_rank (collective).  RCCL is loaded at run time. */
+int ns3d_mgpu_unique_id(void *id_out);
+ns3d_mgpu *ns3d_mgpu_create_rank(int P, int rank, int device, const void *unique_id, int nx, int ny, int nz_local, int flags);
+void ns3d_mgpu_destroy(ns3d_mgpu *m);
+int ns3d_mgpu_world(const ns3d_mgpu *m);               /* P */
+int ns3d_mgpu_nlocal(const ns3d_mgpu *m);
+int ns3d_mgpu_rank(const ns3d_mgpu *m, int local);     /* z coordinate ("me") of a local rank */
+ns3d_ctx *ns3d_mgpu_ctx(ns3d_mgpu *m, int local);
+int ns3d_mgpu_nz_g(const ns3d_mgpu *m);
+const char *ns3d_mgpu_transport(const ns3d_mgpu *m);   /* "peer" | "rccl" */
+int ns3d_mgpu_rccl_ranks(const ns3d_mgpu *m);          /* ncclCommCount of the communicator (0 in the one-process form) */
+int ns3d_mgpu_sync(ns3d_mgpu *m);
+int ns3d_max_g(ns3d_mgpu *m, const double *local_max, double *out);    /* NaN-propagating */
+/* PT iterations per pass over memory in ns3d_slab_* / ns3d_pt_solve_slab: 2 (default; two ghost planes per seam) or 1 */
+int ns3d_mgpu_set_temporal(ns3d_mgpu *m, int depth);
+/* The pseudo-transient state of a z-slab rank lives in library-owned buffers extended by the ghost planes temporal
+ * blocking needs: load → iterate / residual → store; ns3d_pt_solve_slab is the whole inner loop multi.jl:458-471
+ * (load, plan, iterate with a global residual check every nchk iterations, store).  Iterates are bit-identical to the
+ * single-device solve of the global grid.  divV's halo planes must be current (update_halo!(∇V), multi.jl:455). */
+int ns3d_slab_iterate(ns3d_mgpu *m, int n_iters);
+int ns3d_slab_plan(ns3d_mgpu *m);
+int ns3d_slab_residual(ns3d_mgpu *m, double *out);
+
+#define NS3D_MGPU_DECL(T, S)                                                                                \
+    /* extents: 3 ints (sx,sy,sz) per field */                                                              \
+    int ns3d_update_halo_##S(ns3d_mgpu *m, T *const *fields, const int *extents, int nfields);              \
+    /* halo-stripped blocks A[2:end-1,2:end-1,2:end-1] of every rank, concatenated along z, into out_host   \
+     * ((sx-2)·(sy-2)·P·(sz-2) elements; rank 0's process only in the one-process-per-GPU form) */           \
+    int ns3d_gather_##S(ns3d_mgpu *m, const T *const *A, int sx, int sy, int sz, T *out_host);              \
+    int ns3d_slab_load_##S(ns3d_mgpu *m, const T *const *Pr, const T *const *dPrdtau, const T *const *divV, \
+                           const ns3d_pt_params *p);                                                        \
+    int ns3d_slab_store_##S(ns3d_mgpu *m, T *const *Pr, T *const *dPrdtau);                                 \
+    int ns3d_pt_solve_slab_##S(ns3d_mgpu *m, T *const *Pr, T *const *dPrdtau, const T *const *divV,         \
+                               const ns3d_pt_params *p, double eps, int niter, int nchk, double err_mul,    \
+                               double err_div, int *iters_done, double *err_hist, int max_checks,           \
+                               int *n_checks);
+NS3D_MGPU_DECL(double, f64)
+NS3D_MGPU_DECL(float, f32)
+#undef NS3D_MGPU_DECL
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,7 @@ UNITS = [
     ("ns3d_kernels.hip", "ns3d_kernels_strictx.o", ["-DNS3D_MODE_STRICT", "-DNS3D_EXACT_RECIP", "-ffp-contract=off"]),
     ("ns3d_kernels.hip", "ns3d_kernels_fast.o", ["-DNS3D_MODE_FAST", "-ffp-contract=fast"]),
     ("ns3d_api.cpp", "ns3d_api.o", ["-x", "hip"]),
+    ("ns3d_mgpu.cpp", "ns3d_mgpu.o", ["-x", "hip"]),
 ]
 
 
@@ -69,7 +70,7 @@ def build(force=False, verbose=False, extra_flags=()):
             raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), out.decode(errors="replace")))
         if verbose and out:
             print(out.decode(errors="replace"))
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

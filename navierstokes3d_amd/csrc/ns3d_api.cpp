@@ -11,11 +11,11 @@
 #include <mutex>
 #include <vector>
 
-#include "ns3d_launch.h"
+#include "ns3d_internal.h"
 
 static thread_local char g_err[512] = "";
 
-static int fail(int code, const char *fmt, ...)
+int ns3d_fail(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -29,67 +29,6 @@ static int fail(int code, const char *fmt, ...)
 struct Tuned { int device, nx, ny, nz, nk, esize, mode, variant; };
 static std::vector<Tuned> g_tuned;
 static std::mutex g_tuned_mutex;
-
-struct ns3d_ctx {
-    int device;
-    int flags;
-    hipStream_t own_stream;
-    hipStream_t stream;
-    unsigned long long *key_dev;  // device scratch for max reductions
-    unsigned long long *key_host; // pinned host mirror
-    void *pingpong;               // second Pr buffer of the fused PT path (lazily sized)
-    size_t pingpong_bytes;
-    void *pingpong_d;             // second dPrdτ buffer (temporal blocking only)
-    size_t pingpong_d_bytes;
-    int pt_variant;
-    int pt2_variant; // tile shape of the two-iteration sweep; <0: temporal blocking off
-    int graph_mode;  // HIP-graph replay of residual-check blocks: -1 auto (launch-bound grids), 0 off, 1 on
-    int autotune;    // time the tile shapes of the two-iteration sweep on first use of a grid (pt2_variant == 0 only)
-    int last_pt2;    // variant of the latest two-iteration launch (0: built-in choice by grid)
-    hipEvent_t tune_ev[2];
-    hipEvent_t fence;
-    struct BlockGraph {
-        const void *src, *dst, *dsrc, *ddst, *rhs;
-        void *src_out, *dst_out, *dsrc_out, *ddst_out;
-        int n, mode, v1, v2, esize;
-        bool two;
-        ns3d_pt_params p;
-        hipGraphExec_t exec;
-    };
-    std::vector<BlockGraph> graphs;
-    void clear_graphs()
-    {
-        for (auto &g : graphs) (void)hipGraphExecDestroy(g.exec);
-        graphs.clear();
-    }
-};
-
-#define HIPCHK(ctx, expr)                                                                                   \
-    do {                                                                                                    \
-        hipError_t e_ = (expr);                                                                             \
-        if (e_ != hipSuccess) return fail(NS3D_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));            \
-    } while (0)
-
-#define CHECK_CTX(ctx)                                                                                      \
-    do {                                                                                                    \
-        if (!(ctx)) return fail(NS3D_ERR_ARG, "%s: null context", __func__);                                \
-        hipError_t e_ = hipSetDevice((ctx)->device);                                                        \
-        if (e_ != hipSuccess) return fail(NS3D_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e_));         \
-    } while (0)
-
-#define CHECK_PTRS(...)                                                                                     \
-    do {                                                                                                    \
-        const void *ps_[] = {__VA_ARGS__};                                                                  \
-        for (size_t q_ = 0; q_ < sizeof ps_ / sizeof ps_[0]; ++q_)                                          \
-            if (!ps_[q_]) return fail(NS3D_ERR_ARG, "%s: null field pointer (argument %zu)", __func__, q_); \
-    } while (0)
-
-#define CHECK_GRID(nx, ny, nz, m)                                                                           \
-    do {                                                                                                    \
-        if ((nx) < (m) || (ny) < (m) || (nz) < (m))                                                         \
-            return fail(NS3D_ERR_ARG, "%s: grid %dx%dx%d too small (need >= %d per direction)", __func__,   \
-                        (nx), (ny), (nz), (m));                                                             \
-    } while (0)
 
 // launch + (unless NS3D_ASYNC) block like `@parallel` does
 static int finish(ns3d_ctx *ctx, hipError_t e, const char *what)
@@ -143,13 +82,16 @@ ns3d_ctx *ns3d_create(int device, int flags)
         fail(NS3D_ERR_ARG, "ns3d_create: device %d out of range [0,%d)", device, ndev);
         return nullptr;
     }
-    if ((e = hipSetDevice(device)) != hipSuccess) {
-        fail(NS3D_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    ns3d_device_guard guard(device);        // the caller's current device is put back on return
+    if (guard.err != hipSuccess) {
+        fail(NS3D_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(guard.err));
         return nullptr;
     }
     ns3d_ctx *c = new ns3d_ctx();
     c->device = device;
     c->flags = flags;
+    c->own_stream = nullptr;
+    c->stream = nullptr;
     c->pingpong = nullptr;
     c->pingpong_bytes = 0;
     c->pingpong_d = nullptr;
@@ -169,7 +111,7 @@ ns3d_ctx *ns3d_create(int device, int flags)
         (e = hipHostMalloc((void **)&c->key_host, 64, hipHostMallocDefault)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->fence, hipEventDisableTiming)) != hipSuccess) {
         fail(NS3D_ERR_HIP, "ns3d_create: %s", hipGetErrorString(e));
-        delete c;
+        ns3d_destroy(c);                    // releases whatever was created so far
         return nullptr;
     }
     c->stream = c->own_stream;
@@ -179,9 +121,9 @@ ns3d_ctx *ns3d_create(int device, int flags)
 void ns3d_destroy(ns3d_ctx *c)
 {
     if (!c) return;
-    (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipStreamSynchronize(c->own_stream);
+    ns3d_device_guard guard(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     c->clear_graphs();
     if (c->fence) (void)hipEventDestroy(c->fence);
     for (int q = 0; q < 2; ++q)
@@ -190,7 +132,7 @@ void ns3d_destroy(ns3d_ctx *c)
     if (c->pingpong_d) (void)hipFree(c->pingpong_d);
     if (c->key_dev) (void)hipFree(c->key_dev);
     if (c->key_host) (void)hipHostFree(c->key_host);
-    (void)hipStreamDestroy(c->own_stream);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
 
@@ -262,7 +204,7 @@ static int fetch_key(ns3d_ctx *c, hipStream_t s, double *out)
     return NS3D_OK;
 }
 
-static int check_pt_params(const ns3d_pt_params *p, const char *fn)
+int ns3d_check_pt_params(const ns3d_pt_params *p, const char *fn)
 {
     if (!p) return fail(NS3D_ERR_ARG, "%s: null params", fn);
     if (p->nx < 3 || p->ny < 3 || p->nz < 3)
@@ -332,20 +274,28 @@ static int ensure_pingpong_d(ns3d_ctx *c, const ns3d_pt_params *p, T **buf)
 // grid times the candidates on the caller's own arguments — the operation is idempotent: inputs and outputs are
 // distinct buffers — and remembers the winner in the context.  Skipped (built-in choice by grid instead) while the
 // stream is being captured, for launches under 1.5 M cells, after ns3d_set_autotune(ctx, 0), or with an explicit variant.
+// explicit variant / tuning off / launch too small → that answer; a choice measured earlier in this process → it; -1: unknown
 template <class T>
-static int pick_pt2_variant(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV,
-                            const ns3d_pt_params *p, int k0, int k1)
+static int lookup_pt2_variant(const ns3d_ctx *c, int mode, const ns3d_pt_params *p, int k0, int k1)
 {
     if (c->pt2_variant > 0) return c->pt2_variant;
     const int nk = k1 - k0;
     if (!c->autotune || (long long)p->nx * p->ny * nk < NS3D_TWO_MIN_CELLS) return 0;
-    {
-        std::lock_guard<std::mutex> lock(g_tuned_mutex);
-        for (const auto &t : g_tuned)
-            if (t.device == c->device && t.nx == p->nx && t.ny == p->ny && t.nz == p->nz && t.nk == nk &&
-                t.esize == (int)sizeof(T) && t.mode == mode)
-                return t.variant;
-    }
+    std::lock_guard<std::mutex> lock(g_tuned_mutex);
+    for (const auto &t : g_tuned)
+        if (t.device == c->device && t.nx == p->nx && t.ny == p->ny && t.nz == p->nz && t.nk == nk &&
+            t.esize == (int)sizeof(T) && t.mode == mode)
+            return t.variant;
+    return -1;
+}
+// the measurement: runs on the caller's own arguments (idempotent: inputs and outputs are distinct buffers), blocks on
+// its events.  Called from ns3d_plan_pt, ns3d_pt_iterate and ns3d_pt_solve only — never from ns3d_pt_sweep2, whose callers
+// (z-slab schedules with an exchange in flight) must not be stalled by ≈100 extra launches.
+template <class T>
+static int tune_pt2_variant(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV,
+                            const ns3d_pt_params *p, int k0, int k1)
+{
+    const int nk = k1 - k0;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return 0; }
     if (cap != hipStreamCaptureStatusNone) return 0;
@@ -403,14 +353,67 @@ static int pick_pt2_variant(ns3d_ctx *c, hipStream_t s, int mode, const T *src, 
     return best;
 }
 template <class T>
+static int pick_pt2_variant(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV,
+                            const ns3d_pt_params *p, int k0, int k1, bool may_tune)
+{
+    int v = lookup_pt2_variant<T>(c, mode, p, k0, k1);
+    if (v < 0) v = may_tune ? tune_pt2_variant<T>(c, s, mode, src, dst, dsrc, ddst, divV, p, k0, k1) : 0;
+    return v;
+}
+template <class T>
 static hipError_t launch_pt2(ns3d_ctx *c, hipStream_t s, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV,
-                             const ns3d_pt_params *p, int k0, int k1)
+                             const ns3d_pt_params *p, int k0, int k1, bool may_tune)
 {
     const int mode = mode_of(c, p->dx, p->dy, p->dz);
-    const int v = pick_pt2_variant<T>(c, s, mode, src, dst, dsrc, ddst, divV, p, k0, k1);
+    const int v = pick_pt2_variant<T>(c, s, mode, src, dst, dsrc, ddst, divV, p, k0, k1, may_tune);
     c->last_pt2 = v;
     return DISPATCHM(mode, pt_sweep2<T>(s, v, src, dst, dsrc, ddst, divV, *p, k0, k1));
 }
+
+// ---- what the multi-GPU layer enqueues on its ranks' contexts (ns3d_internal.h) ----------------------------------
+template <class T>
+hipError_t ns3d_enqueue_pt2(ns3d_ctx *c, hipStream_t s, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV,
+                            const ns3d_pt_params *p, int k0, int k1)
+{
+    return launch_pt2<T>(c, s, src, dst, dsrc, ddst, divV, p, k0, k1, false);
+}
+template <class T>
+int ns3d_plan_pt_internal(ns3d_ctx *c, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV, const ns3d_pt_params *p,
+                          int k0, int k1)
+{
+    (void)pick_pt2_variant<T>(c, c->stream, mode_of(c, p->dx, p->dy, p->dz), src, dst, dsrc, ddst, divV, p, k0, k1, true);
+    return NS3D_OK;
+}
+template <class T>
+hipError_t ns3d_enqueue_pt1(ns3d_ctx *c, hipStream_t s, const T *src, T *dst, T *d, const T *divV, const ns3d_pt_params *p,
+                            int k0, int k1)
+{
+    return DISPATCHG(c, p->dx, p->dy, p->dz, pt_sweep<T>(s, c->pt_variant, src, dst, d, divV, *p, k0, k1));
+}
+template <class T>
+hipError_t ns3d_enqueue_residual_key(ns3d_ctx *c, hipStream_t s, const T *Pr, const T *divV, const ns3d_pt_params *p,
+                                     unsigned long long *key_dev)
+{
+    return DISPATCHG(c, p->dx, p->dy, p->dz, residual_max_key<T>(s, Pr, divV, *p, key_dev));
+}
+template <class T>
+hipError_t ns3d_enqueue_strip_inner(ns3d_ctx *c, hipStream_t s, const T *A, T *out, int sx, int sy, int sz)
+{
+    return DISPATCH(c, strip_inner<T>(s, A, out, sx, sy, sz));
+}
+#define NS3D_INST_INTERNAL(T)                                                                                       \
+    template hipError_t ns3d_enqueue_pt2<T>(ns3d_ctx *, hipStream_t, const T *, T *, const T *, T *, const T *,      \
+                                            const ns3d_pt_params *, int, int);                                      \
+    template int ns3d_plan_pt_internal<T>(ns3d_ctx *, const T *, T *, const T *, T *, const T *,                     \
+                                          const ns3d_pt_params *, int, int);                                        \
+    template hipError_t ns3d_enqueue_pt1<T>(ns3d_ctx *, hipStream_t, const T *, T *, T *, const T *,                 \
+                                            const ns3d_pt_params *, int, int);                                      \
+    template hipError_t ns3d_enqueue_residual_key<T>(ns3d_ctx *, hipStream_t, const T *, const T *,                  \
+                                                     const ns3d_pt_params *, unsigned long long *);                 \
+    template hipError_t ns3d_enqueue_strip_inner<T>(ns3d_ctx *, hipStream_t, const T *, T *, int, int, int);
+NS3D_INST_INTERNAL(double)
+NS3D_INST_INTERNAL(float)
+#undef NS3D_INST_INTERNAL
 
 // n_iters fused sweeps, result left in Pr (one D2D copy when n_iters is odd).  With z halos the scratch
 // buffer's halo planes are seeded from Pr first (a sweep never writes them).
@@ -433,7 +436,7 @@ static int pt_iterate_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_p
     for (int it = 0; it < n_iters;) {
         hipError_t e;
         if (two && it + 2 <= n_iters) {
-            e = launch_pt2<T>(c, c->stream, src, dst, dsrc, ddst, divV, p, 1, p->nz - 1);
+            e = launch_pt2<T>(c, c->stream, src, dst, dsrc, ddst, divV, p, 1, p->nz - 1, true);
             T *t = dsrc; dsrc = ddst; ddst = t;
             it += 2;
         } else {
@@ -460,7 +463,7 @@ static hipError_t enqueue_iters(ns3d_ctx *c, hipStream_t s, int n, bool two, T *
     hipError_t e = hipSuccess;
     for (int it = 0; it < n && e == hipSuccess;) {
         if (two && it + 2 <= n) {
-            e = launch_pt2<T>(c, s, src, dst, dsrc, ddst, divV, p, 1, p->nz - 1);
+            e = launch_pt2<T>(c, s, src, dst, dsrc, ddst, divV, p, 1, p->nz - 1, true);
             T *t = dsrc; dsrc = ddst; ddst = t;
             it += 2;
         } else {
@@ -540,7 +543,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
     }
     // settle the tile choice of the two-iteration sweep now (eagerly, into the scratch buffers): inside a stream capture
     // it could only be looked up
-    if (two) (void)pick_pt2_variant<T>(c, s, mode_of(c, p->dx, p->dy, p->dz), src, dst, dsrc, ddst, divV, p, 1, p->nz - 1);
+    if (two) (void)pick_pt2_variant<T>(c, s, mode_of(c, p->dx, p->dy, p->dz), src, dst, dsrc, ddst, divV, p, 1, p->nz - 1, true);
     while (iter < niter) {
         // iterations until the next residual check (multi.jl:464) or the end of the budget
         const int n = nchk > 0 ? std::min(nchk - iter % nchk, niter - iter) : niter - iter;
@@ -738,7 +741,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
                                        const ns3d_pt_params *p, int n_iters)                                 \
     {                                                                                                        \
         CHECK_CTX(c); CHECK_PTRS(Pr, dPrdtau, divV);                                                         \
-        int rc = check_pt_params(p, "ns3d_pt_iterate");                                                      \
+        int rc = ns3d_check_pt_params(p, "ns3d_pt_iterate");                                                      \
         if (rc) return rc;                                                                                   \
         if ((rc = pt_iterate_impl<T>(c, Pr, dPrdtau, divV, p, n_iters))) return rc;                          \
         return finish(c, hipSuccess, "pt_iterate");                                                          \
@@ -747,7 +750,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
                                      const ns3d_pt_params *p, int k0, int k1)                                \
     {                                                                                                        \
         CHECK_CTX(c); CHECK_PTRS(Pr_in, Pr_out, dPrdtau, divV);                                              \
-        int rc = check_pt_params(p, "ns3d_pt_sweep");                                                        \
+        int rc = ns3d_check_pt_params(p, "ns3d_pt_sweep");                                                        \
         if (rc) return rc;                                                                                   \
         if (Pr_in == Pr_out) return fail(NS3D_ERR_ARG, "ns3d_pt_sweep: Pr_in and Pr_out must differ");       \
         if (k0 < 1 || k1 > p->nz - 1 || k0 > k1)                                                             \
@@ -760,20 +763,34 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
     {                                                                                                        \
         CHECK_CTX(c); CHECK_PTRS(Pr_in, Pr_out, dPrdtau, dPrdtau_out, divV);                                 \
         if (dPrdtau == dPrdtau_out) return fail(NS3D_ERR_ARG, "ns3d_pt_sweep2: dPrdtau_in and dPrdtau_out must differ"); \
-        int rc = check_pt_params(p, "ns3d_pt_sweep2");                                                       \
+        int rc = ns3d_check_pt_params(p, "ns3d_pt_sweep2");                                                       \
         if (rc) return rc;                                                                                   \
         if (Pr_in == Pr_out) return fail(NS3D_ERR_ARG, "ns3d_pt_sweep2: Pr_in and Pr_out must differ");      \
         if (p->z_lo_is_halo || p->z_hi_is_halo)                                                              \
             return fail(NS3D_ERR_ARG, "ns3d_pt_sweep2: z-slab ranks pass ghost-extended buffers, not halo flags"); \
         if (k0 < 1 || k1 > p->nz - 1 || k0 > k1)                                                             \
             return fail(NS3D_ERR_ARG, "ns3d_pt_sweep2: plane range [%d,%d) outside [1,%d)", k0, k1, p->nz - 1); \
-        return finish(c, launch_pt2<T>(c, c->stream, Pr_in, Pr_out, dPrdtau, dPrdtau_out, divV, p, k0, k1), "pt_sweep2"); \
+        return finish(c, launch_pt2<T>(c, c->stream, Pr_in, Pr_out, dPrdtau, dPrdtau_out, divV, p, k0, k1, false), "pt_sweep2"); \
+    }                                                                                                        \
+    extern "C" int ns3d_plan_pt_##S(ns3d_ctx *c, const T *Pr_in, T *Pr_out, const T *dPrdtau, T *dPrdtau_out, \
+                                    const T *divV, const ns3d_pt_params *p, int k0, int k1)                  \
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(Pr_in, Pr_out, dPrdtau, dPrdtau_out, divV);                                 \
+        int rc = ns3d_check_pt_params(p, "ns3d_plan_pt");                                                    \
+        if (rc) return rc;                                                                                   \
+        if (Pr_in == Pr_out || dPrdtau == dPrdtau_out)                                                       \
+            return fail(NS3D_ERR_ARG, "ns3d_plan_pt: input and output buffers must differ");                 \
+        if (k0 < 1 || k1 > p->nz - 1 || k0 > k1)                                                             \
+            return fail(NS3D_ERR_ARG, "ns3d_plan_pt: plane range [%d,%d) outside [1,%d)", k0, k1, p->nz - 1);\
+        (void)pick_pt2_variant<T>(c, c->stream, mode_of(c, p->dx, p->dy, p->dz), Pr_in, Pr_out, dPrdtau,     \
+                                  dPrdtau_out, divV, p, k0, k1, true);                                       \
+        return finish(c, hipSuccess, "plan_pt");                                                             \
     }                                                                                                        \
     extern "C" int ns3d_residual_max_##S(ns3d_ctx *c, const T *Pr, const T *divV, const ns3d_pt_params *p,   \
                                          double *out_host)                                                   \
     {                                                                                                        \
         CHECK_CTX(c); CHECK_PTRS(Pr, divV, out_host);                                                        \
-        int rc = check_pt_params(p, "ns3d_residual_max");                                                    \
+        int rc = ns3d_check_pt_params(p, "ns3d_residual_max");                                                    \
         if (rc) return rc;                                                                                   \
         hipError_t e = DISPATCHG(c, p->dx, p->dy, p->dz, residual_max_key<T>(c->stream, Pr, divV, *p, c->key_dev));                \
         if (e != hipSuccess) return fail(NS3D_ERR_HIP, "residual launch: %s", hipGetErrorString(e));         \
@@ -797,7 +814,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
                                      int *iters_done, double *err_hist, int max_checks, int *n_checks)       \
     {                                                                                                        \
         CHECK_CTX(c); CHECK_PTRS(Pr, dPrdtau, divV);                                                         \
-        int rc = check_pt_params(p, "ns3d_pt_solve");                                                        \
+        int rc = ns3d_check_pt_params(p, "ns3d_pt_solve");                                                        \
         if (rc) return rc;                                                                                   \
         if (p->z_lo_is_halo || p->z_hi_is_halo)                                                              \
             return fail(NS3D_ERR_ARG, "ns3d_pt_solve: single-rank loop; drive z-slab ranks with ns3d_pt_sweep + halo exchange"); \

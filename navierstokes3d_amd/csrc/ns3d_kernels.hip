@@ -695,6 +695,24 @@ hipError_t advect(hipStream_t s, T *Vx, const T *Vx_o, T *Vy, const T *Vy_o, T *
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// A[2:end-1,2:end-1,2:end-1] packed (what gather! receives per rank, multi.jl:399-403): one thread per inner cell
+// ---------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_strip_inner(const T *__restrict__ A, T *__restrict__ out, int sx, int sy, int sz)
+{
+    TID3
+    if (i >= sx - 2 || j >= sy - 2 || k >= sz - 2) return;
+    out[IX3(i, j, k, sx - 2, sy - 2)] = A[IX3(i + 1, j + 1, k + 1, sx, sy)];
+}
+template <class T>
+hipError_t strip_inner(hipStream_t s, const T *A, T *out, int sx, int sy, int sz)
+{
+    if (sx <= 2 || sy <= 2 || sz <= 2) return hipSuccess;
+    hipLaunchKernelGGL(k_strip_inner<T>, grid3(sx - 2, sy - 2, sz - 2, BLK3), BLK3, 0, s, A, out, sx, sy, sz);
+    return hipGetLastError();
+}
+
 // =========================================================================================================
 // The fused pseudo-transient sweep  —  THE hot kernel (≥98 % of all bytes moved).
 //
@@ -1704,7 +1722,8 @@ hipError_t divtest(hipStream_t s, double d, long n, unsigned long long seed, uns
                                      const ns3d_pt_params &, int, int);                                      \
     template hipError_t residual_max_key<T>(hipStream_t, const T *, const T *, const ns3d_pt_params &,       \
                                             unsigned long long *);                                           \
-    template hipError_t divtest<T>(hipStream_t, double, long, unsigned long long, unsigned long long *);
+    template hipError_t divtest<T>(hipStream_t, double, long, unsigned long long, unsigned long long *);   \
+    template hipError_t strip_inner<T>(hipStream_t, const T *, T *, int, int, int);
 INST(double)
 INST(float)
 #undef INST

@@ -49,6 +49,8 @@
                                 unsigned long long *key_dev);                                                \
     template <class T>                                                                                       \
     hipError_t divtest(hipStream_t, double d, long n, unsigned long long seed, unsigned long long *bad_dev); \
+    template <class T>                                                                                       \
+    hipError_t strip_inner(hipStream_t, const T *A, T *out, int sx, int sy, int sz);                         \
     }
 
 NS3D_LAUNCHER_DECLS(ns3d_strict)

@@ -1,0 +1,822 @@
+// ns3d_mgpu.cpp — the z-slab multi-GPU half of the boundary (include/ns3d.h, "multi-GPU" section): what the reference
+// gets from ImplicitGlobalGrid.jl + MPI.jl — init_global_grid (multi.jl:325), update_halo! (:371,373,450,453,455,460,462,
+// 182,167,477), max_g (:21), gather! (:399-403,528-532), finalize_global_grid (:534) — plus the pseudo-transient loop of
+// a z-slab rank (multi.jl:458-471) with its halo traffic hidden behind the interior sweep.
+//
+// Decomposition: 1-D slabs along z, ImplicitGlobalGrid's indexing (overlap 2, halo width 1, nz_g = P·(nz−2)+2, an array
+// with nz+s planes has overlap 2+s, physical ends untouched).  Arrays are packed column-major, so every xy-plane — every
+// halo message — is ONE contiguous block: no pack/unpack kernels anywhere.
+//
+// Two forms, one schedule:
+//   * ns3d_mgpu_create      — ONE process drives P devices (a device may repeat: P virtual ranks on one GPU, which is how the
+//                             one-GPU test box runs the whole layer).  Planes move by hipMemcpyPeerAsync over xGMI, receiver
+//                             pulls, ordered by events between the ranks' streams.
+//   * ns3d_mgpu_create_rank — one process per GPU (the reference's model, one MPI rank per GPU): an RCCL communicator over
+//                             the P ranks; planes move by ncclSend/ncclRecv in one group per exchange on a dedicated
+//                             high-priority stream; the residual is reduced by ncclAllReduce(max) on the unsigned bit
+//                             pattern of the non-negative double (NaN sorts on top: NaN-propagating like Julia's maximum).
+//                             RCCL is resolved with dlopen at the first use, so libns3d.so has no link-time dependency on it
+//                             and binds to the librccl already in the process (PyTorch's) when there is one.
+// xGMI is point-to-point: a slab chain uses 2 of a GPU's 7 links and moves a few MB per exchange, so the cost is latency
+// and ordering, not bandwidth — hence one group / one burst of peer copies per exchange and no per-plane handshakes.
+//
+// Pseudo-transient loop of a slab rank (ns3d_slab_*, ns3d_pt_solve_slab): the single-GPU fast path advances `depth` PT
+// iterations per pass over memory.  Level 2 of a rank's first own plane needs level 1 of the seam halo plane, which needs
+// the previous iterate one plane further out: the solve state therefore lives in library-owned buffers EXTENDED by
+// G = depth−1 ghost planes per seam.  Every pass recomputes the lower levels on the ghost planes (bit-identical on both
+// ranks: same inputs, same arithmetic), afterwards the depth outermost own planes of Pr and the G outermost own planes of
+// dPrdτ travel to the neighbour (depth=2: 3 planes per two iterations instead of the reference's ≥2 exchanges per single
+// iteration, multi.jl:460-463,182).  The seam-adjacent output planes are swept first, their exchange is posted on the
+// communication stream, the interior sweep runs behind it.  Jacobi sweeps are decomposition independent:
+// the iterates are bit-identical to the single-device solve of the global grid.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include <rccl/rccl.h>   // types and prototypes only; every symbol is resolved by dlopen below
+
+#include "ns3d_internal.h"
+
+namespace {
+
+// ---- RCCL through dlopen ---------------------------------------------------------------------------------------
+struct RcclApi {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string path;
+};
+RcclApi g_rccl;
+
+int load_rccl()
+{
+    if (g_rccl.handle) return NS3D_OK;
+    const char *cands[] = {std::getenv("NS3D_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    std::string tried;
+    for (const char *c : cands) {
+        if (!c || !*c) continue;
+        h = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
+        if (h) { g_rccl.path = c; break; }
+        tried += std::string(tried.empty() ? "" : ", ") + c;
+    }
+    if (!h) return fail(NS3D_ERR_RCCL, "RCCL not found (tried %s): %s", tried.c_str(), dlerror());
+#define SYM(name)                                                                                           \
+    if (!(g_rccl.name = (decltype(g_rccl.name))dlsym(h, "nccl" #name))) {                                   \
+        dlclose(h);                                                                                         \
+        return fail(NS3D_ERR_RCCL, "%s lacks nccl" #name, g_rccl.path.c_str());                             \
+    }
+    SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(CommCount) SYM(Send) SYM(Recv) SYM(AllReduce)
+    SYM(GroupStart) SYM(GroupEnd) SYM(GetErrorString)
+#undef SYM
+    g_rccl.handle = h;
+    return NS3D_OK;
+}
+
+#define NCCLCHK(expr)                                                                                       \
+    do {                                                                                                    \
+        ncclResult_t r_ = (expr);                                                                           \
+        if (r_ != ncclSuccess) return fail(NS3D_ERR_RCCL, "%s: %s", #expr, g_rccl.GetErrorString(r_));      \
+    } while (0)
+
+static_assert(sizeof(ncclUniqueId) == NS3D_UNIQUE_ID_BYTES, "NS3D_UNIQUE_ID_BYTES must equal sizeof(ncclUniqueId)");
+
+// ---- one z-slab rank driven by this process ----------------------------------------------------------------------
+struct SlabState {                // deep-ghost pseudo-transient state (library-owned)
+    void *P[2] = {nullptr, nullptr}, *D[2] = {nullptr, nullptr}, *R = nullptr;
+    size_t bytes_P = 0, bytes_D = 0;
+    int ip = 0, id = 0;           // current Pr / dPrdτ buffer
+    int glo = 0, ghi = 0, nze = 0;
+};
+struct MRank {
+    int rank = 0, device = 0;
+    ns3d_ctx *ctx = nullptr;
+    hipStream_t comm = nullptr;                    // halo traffic (high priority)
+    hipEvent_t ev_ready = nullptr, ev_landed = nullptr;
+    SlabState st;
+    void *gbuf = nullptr;                          // gather!: packed halo-stripped block
+    size_t gbuf_bytes = 0;
+};
+struct Block {                    // one contiguous piece that travels to both neighbours (pointers on the owning rank)
+    void *send_lo, *recv_lo, *send_hi, *recv_hi;
+    size_t bytes;
+};
+
+} // namespace
+
+struct ns3d_mgpu {
+    int P = 1, nx = 0, ny = 0, nz = 0, flags = 0;
+    std::vector<MRank> loc;
+    bool rccl = false;
+    ncclComm_t comm = nullptr;
+    int rccl_ranks = 0;
+    int depth = 2;                // PT iterations per pass over memory (1: single sweeps, plain one-plane halo)
+    // loaded solve
+    bool loaded = false;
+    int esize = 0, G = 0;
+    ns3d_pt_params p;             // the caller's (local grid)
+    void *stage = nullptr;        // rank 0, RCCL gather: the global halo-stripped array on the device
+    size_t stage_bytes = 0;
+};
+
+namespace {
+
+bool has_lower(const ns3d_mgpu *m, const MRank &r) { (void)m; return r.rank > 0; }
+bool has_upper(const ns3d_mgpu *m, const MRank &r) { return r.rank < m->P - 1; }
+hipStream_t compute(const MRank &r) { return r.ctx->stream; }
+
+// Post the exchange of `blocks[l]` (same count and sizes on every rank): everything up to "the ghosts have landed" is
+// enqueued on the communication streams, ordered after what the compute streams hold NOW.
+int exchange_begin(ns3d_mgpu *m, const std::vector<std::vector<Block>> &blocks)
+{
+    const int n = (int)m->loc.size();
+    if (m->P == 1) return NS3D_OK;
+    for (int l = 0; l < n; ++l) {
+        MRank &r = m->loc[l];
+        ns3d_device_guard g(r.device);
+        HIPCHK(0, hipEventRecord(r.ev_ready, compute(r)));
+    }
+    if (m->rccl) {
+        MRank &r = m->loc[0];
+        ns3d_device_guard g(r.device);
+        HIPCHK(0, hipStreamWaitEvent(r.comm, r.ev_ready, 0));
+        NCCLCHK(g_rccl.GroupStart());
+        for (const Block &b : blocks[0]) {
+            if (has_lower(m, r)) {
+                NCCLCHK(g_rccl.Send(b.send_lo, b.bytes, ncclUint8, r.rank - 1, m->comm, r.comm));
+                NCCLCHK(g_rccl.Recv(b.recv_lo, b.bytes, ncclUint8, r.rank - 1, m->comm, r.comm));
+            }
+            if (has_upper(m, r)) {
+                NCCLCHK(g_rccl.Send(b.send_hi, b.bytes, ncclUint8, r.rank + 1, m->comm, r.comm));
+                NCCLCHK(g_rccl.Recv(b.recv_hi, b.bytes, ncclUint8, r.rank + 1, m->comm, r.comm));
+            }
+        }
+        NCCLCHK(g_rccl.GroupEnd());
+        HIPCHK(0, hipEventRecord(r.ev_landed, r.comm));
+        return NS3D_OK;
+    }
+    // one process, P devices: every receiver pulls its ghost planes from its neighbours once BOTH sides are ready
+    for (int l = 0; l < n; ++l) {
+        MRank &r = m->loc[l];
+        ns3d_device_guard g(r.device);
+        HIPCHK(0, hipStreamWaitEvent(r.comm, r.ev_ready, 0));
+        if (l > 0) HIPCHK(0, hipStreamWaitEvent(r.comm, m->loc[l - 1].ev_ready, 0));
+        if (l < n - 1) HIPCHK(0, hipStreamWaitEvent(r.comm, m->loc[l + 1].ev_ready, 0));
+        for (size_t q = 0; q < blocks[l].size(); ++q) {
+            const Block &b = blocks[l][q];
+            if (l > 0)
+                HIPCHK(0, hipMemcpyPeerAsync(b.recv_lo, r.device, blocks[l - 1][q].send_hi, m->loc[l - 1].device, b.bytes, r.comm));
+            if (l < n - 1)
+                HIPCHK(0, hipMemcpyPeerAsync(b.recv_hi, r.device, blocks[l + 1][q].send_lo, m->loc[l + 1].device, b.bytes, r.comm));
+        }
+        HIPCHK(0, hipEventRecord(r.ev_landed, r.comm));
+    }
+    return NS3D_OK;
+}
+// What the compute streams enqueue from now on sees the ghosts — and does not overwrite a plane a neighbour still reads.
+int exchange_end(ns3d_mgpu *m)
+{
+    const int n = (int)m->loc.size();
+    if (m->P == 1) return NS3D_OK;
+    for (int l = 0; l < n; ++l) {
+        MRank &r = m->loc[l];
+        ns3d_device_guard g(r.device);
+        HIPCHK(0, hipStreamWaitEvent(compute(r), r.ev_landed, 0));
+        if (!m->rccl) {
+            if (l > 0) HIPCHK(0, hipStreamWaitEvent(compute(r), m->loc[l - 1].ev_landed, 0));
+            if (l < n - 1) HIPCHK(0, hipStreamWaitEvent(compute(r), m->loc[l + 1].ev_landed, 0));
+        }
+    }
+    return NS3D_OK;
+}
+int sync_all(ns3d_mgpu *m)
+{
+    for (MRank &r : m->loc) {
+        ns3d_device_guard g(r.device);
+        HIPCHK(0, hipStreamSynchronize(compute(r)));
+        HIPCHK(0, hipStreamSynchronize(r.comm));
+    }
+    return NS3D_OK;
+}
+int finish_m(ns3d_mgpu *m)
+{
+    return (m->flags & NS3D_ASYNC) ? NS3D_OK : sync_all(m);
+}
+
+void free_slab(MRank &r)
+{
+    ns3d_device_guard g(r.device);
+    for (int q = 0; q < 2; ++q) {
+        if (r.st.P[q]) (void)hipFree(r.st.P[q]);
+        if (r.st.D[q]) (void)hipFree(r.st.D[q]);
+        r.st.P[q] = r.st.D[q] = nullptr;
+    }
+    if (r.st.R) (void)hipFree(r.st.R);
+    r.st.R = nullptr;
+    r.st.bytes_P = r.st.bytes_D = 0;
+}
+
+int init_rank(ns3d_mgpu *m, MRank &r, int rank, int device, int flags)
+{
+    r.rank = rank;
+    r.device = device;
+    r.ctx = ns3d_create(device, flags);
+    if (!r.ctx) return NS3D_ERR_HIP;          // message already recorded
+    ns3d_device_guard g(device);
+    int lo = 0, hi = 0;
+    HIPCHK(0, hipDeviceGetStreamPriorityRange(&lo, &hi));       // hi = numerically lowest = highest priority
+    HIPCHK(0, hipStreamCreateWithPriority(&r.comm, hipStreamNonBlocking, hi));
+    HIPCHK(0, hipEventCreateWithFlags(&r.ev_ready, hipEventDisableTiming));
+    HIPCHK(0, hipEventCreateWithFlags(&r.ev_landed, hipEventDisableTiming));
+    (void)m;
+    return NS3D_OK;
+}
+
+ns3d_mgpu *new_mgpu(int P, int nx, int ny, int nz, int flags, const char *fn)
+{
+    if (P < 1) { fail(NS3D_ERR_ARG, "%s: P = %d", fn, P); return nullptr; }
+    if (nx < 3 || ny < 3 || nz < 3) { fail(NS3D_ERR_ARG, "%s: local grid %dx%dx%d too small (need >= 3)", fn, nx, ny, nz); return nullptr; }
+    ns3d_mgpu *m = new ns3d_mgpu();
+    m->P = P; m->nx = nx; m->ny = ny; m->nz = nz; m->flags = flags;
+    if (const char *ev = std::getenv("NS3D_SLAB_DEPTH")) m->depth = std::max(1, std::min(2, std::atoi(ev)));
+    return m;
+}
+
+// ---- deep-ghost slab state --------------------------------------------------------------------------------------
+template <class T>
+struct Ext {                       // geometry of one rank's extended buffers
+    int nx, ny, nz, G, glo, ghi, nze, k0, k1;
+    size_t plane, dplane;
+    Ext(const ns3d_mgpu *m, const MRank &r)
+    {
+        nx = m->nx; ny = m->ny; nz = m->nz; G = m->G;
+        glo = has_lower(m, r) ? G : 0;
+        ghi = has_upper(m, r) ? G : 0;
+        nze = nz + glo + ghi;
+        k0 = 1 + glo; k1 = nz - 1 + glo;
+        plane = (size_t)nx * ny; dplane = (size_t)(nx - 2) * (ny - 2);
+    }
+};
+
+ns3d_pt_params ext_params(const ns3d_mgpu *m, const MRank &r)
+{
+    ns3d_pt_params pe = m->p;
+    const int glo = has_lower(m, r) ? m->G : 0, ghi = has_upper(m, r) ? m->G : 0;
+    pe.nz = m->nz + glo + ghi;
+    // G = 0: the halo planes are the buffers' outermost planes and must not be treated as faces; G > 0: the sweeps never
+    // produce the outermost planes of a seam side at all (output planes start at 1+G)
+    pe.z_lo_is_halo = (m->G == 0 && has_lower(m, r)) ? 1 : 0;
+    pe.z_hi_is_halo = (m->G == 0 && has_upper(m, r)) ? 1 : 0;
+    return pe;
+}
+
+template <class T>
+std::vector<Block> ghost_blocks(const ns3d_mgpu *m, const MRank &r, int ip, int idd)
+{
+    const Ext<T> e(m, r);
+    const int G = m->G;
+    T *Pq = (T *)r.st.P[ip], *Dq = (T *)r.st.D[idd];
+    std::vector<Block> v;
+    // Pr: the depth outermost own planes → the neighbour's ghost + halo planes
+    const int np = G + 1;
+    v.push_back({Pq + e.plane * e.k0, Pq, Pq + e.plane * (e.k1 - np), Pq + e.plane * (e.nze - np), e.plane * np * sizeof(T)});
+    // dPrdτ (plane k ↔ index k−1): the G outermost own planes → the neighbour's ghost planes
+    if (G > 0)
+        v.push_back({Dq + e.dplane * (e.k0 - 1), Dq, Dq + e.dplane * (e.k1 - 1 - G), Dq + e.dplane * (e.nze - 2 - G),
+                     e.dplane * G * sizeof(T)});
+    return v;
+}
+
+template <class T>
+int slab_exchange(ns3d_mgpu *m, int ip_of_all, int id_of_all, bool wait)
+{
+    std::vector<std::vector<Block>> blocks;
+    for (MRank &r : m->loc) blocks.push_back(ghost_blocks<T>(m, r, ip_of_all, id_of_all));
+    int rc = exchange_begin(m, blocks);
+    if (rc) return rc;
+    return wait ? exchange_end(m) : NS3D_OK;
+}
+
+// one pass: `its` (1 or 2) PT iterations on every local rank, seam planes first, exchange behind the interior sweep
+template <class T>
+int slab_pass(ns3d_mgpu *m, int its)
+{
+    const int ip = m->loc[0].st.ip, idd = m->loc[0].st.id;          // the ranks advance in lockstep
+    const int idd_out = its == 2 ? idd ^ 1 : idd;
+    struct Rng { int lo_end, hi_beg; };
+    std::vector<Rng> rng(m->loc.size());
+    auto sweep = [&](MRank &r, int a, int b) -> int {
+        if (b <= a) return NS3D_OK;
+        const ns3d_pt_params pe = ext_params(m, r);
+        ns3d_device_guard g(r.device);
+        hipError_t e;
+        if (its == 2)
+            e = ns3d_enqueue_pt2<T>(r.ctx, compute(r), (const T *)r.st.P[ip], (T *)r.st.P[ip ^ 1], (const T *)r.st.D[idd],
+                                    (T *)r.st.D[idd_out], (const T *)r.st.R, &pe, a, b);
+        else
+            e = ns3d_enqueue_pt1<T>(r.ctx, compute(r), (const T *)r.st.P[ip], (T *)r.st.P[ip ^ 1], (T *)r.st.D[idd],
+                                    (const T *)r.st.R, &pe, a, b);
+        return e == hipSuccess ? NS3D_OK : fail(NS3D_ERR_HIP, "slab sweep launch: %s", hipGetErrorString(e));
+    };
+    int rc;
+    for (size_t l = 0; l < m->loc.size(); ++l) {
+        MRank &r = m->loc[l];
+        const Ext<T> e(m, r);
+        const int np = m->G + 1;                                    // planes the neighbour needs
+        rng[l].lo_end = has_lower(m, r) ? std::min(e.k0 + np, e.k1) : e.k0;
+        rng[l].hi_beg = has_upper(m, r) ? std::max(e.k1 - np, rng[l].lo_end) : e.k1;
+        if ((rc = sweep(r, e.k0, rng[l].lo_end))) return rc;
+        if ((rc = sweep(r, rng[l].hi_beg, e.k1))) return rc;
+    }
+    std::vector<std::vector<Block>> blocks;
+    for (MRank &r : m->loc) blocks.push_back(ghost_blocks<T>(m, r, ip ^ 1, idd_out));
+    if ((rc = exchange_begin(m, blocks))) return rc;
+    for (size_t l = 0; l < m->loc.size(); ++l)
+        if ((rc = sweep(m->loc[l], rng[l].lo_end, rng[l].hi_beg))) return rc;
+    if ((rc = exchange_end(m))) return rc;
+    for (MRank &r : m->loc) { r.st.ip = ip ^ 1; r.st.id = idd_out; }
+    return NS3D_OK;
+}
+
+template <class T>
+int slab_iterate(ns3d_mgpu *m, int n)
+{
+    int rc;
+    for (int it = 0; it < n;) {
+        const int its = (m->depth >= 2 && it + 2 <= n) ? 2 : 1;
+        if ((rc = slab_pass<T>(m, its))) return rc;
+        it += its;
+    }
+    return NS3D_OK;
+}
+
+// max_g of per-rank keys that sit in each rank's ctx->key_dev (device): host double out
+int reduce_keys(ns3d_mgpu *m, double *out)
+{
+    unsigned long long best = 0ull;
+    for (MRank &r : m->loc) {
+        ns3d_device_guard g(r.device);
+        hipStream_t s = compute(r);
+        if (m->rccl)        // also with one rank: the same RCCL path whatever the world size
+            NCCLCHK(g_rccl.AllReduce(r.ctx->key_dev, r.ctx->key_dev, 1, ncclUint64, ncclMax, m->comm, s));
+        HIPCHK(0, hipMemcpyAsync(r.ctx->key_host, r.ctx->key_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    }
+    for (MRank &r : m->loc) {
+        ns3d_device_guard g(r.device);
+        HIPCHK(0, hipStreamSynchronize(compute(r)));
+        best = std::max(best, *r.ctx->key_host);
+    }
+    double v;
+    std::memcpy(&v, &best, sizeof v);
+    *out = v;
+    return NS3D_OK;
+}
+
+template <class T>
+int slab_residual(ns3d_mgpu *m, double *out)
+{
+    for (MRank &r : m->loc) {
+        const ns3d_pt_params pe = ext_params(m, r);
+        ns3d_device_guard g(r.device);
+        hipError_t e = ns3d_enqueue_residual_key<T>(r.ctx, compute(r), (const T *)r.st.P[r.st.ip], (const T *)r.st.R, &pe,
+                                                    r.ctx->key_dev);
+        if (e != hipSuccess) return fail(NS3D_ERR_HIP, "residual launch: %s", hipGetErrorString(e));
+    }
+    return reduce_keys(m, out);
+}
+
+template <class T>
+int slab_load(ns3d_mgpu *m, const T *const *Pr, const T *const *D, const T *const *divV, const ns3d_pt_params *p)
+{
+    int rc = ns3d_check_pt_params(p, "ns3d_slab_load");
+    if (rc) return rc;
+    if (p->nx != m->nx || p->ny != m->ny || p->nz != m->nz)
+        return fail(NS3D_ERR_ARG, "ns3d_slab_load: params grid %dx%dx%d differs from the grid of ns3d_mgpu_create %dx%dx%d", p->nx,
+                    p->ny, p->nz, m->nx, m->ny, m->nz);
+    if (p->bc_kind != NS3D_BC_MULTI && m->P > 1)
+        return fail(NS3D_ERR_ARG, "ns3d_slab_load: gpu.jl's boundary set is single-device");
+    if (m->nz < 4 && m->P > 1) return fail(NS3D_ERR_ARG, "ns3d_slab_load: z-slab ranks need at least two interior planes");
+    m->p = *p;
+    m->G = m->depth - 1;
+    m->esize = (int)sizeof(T);
+    for (size_t l = 0; l < m->loc.size(); ++l) {
+        MRank &r = m->loc[l];
+        if (!Pr[l] || !D[l] || !divV[l]) return fail(NS3D_ERR_ARG, "ns3d_slab_load: null field pointer (local rank %zu)", l);
+        const Ext<T> e(m, r);
+        const size_t bp = e.plane * e.nze * sizeof(T), bd = e.dplane * (e.nze - 2) * sizeof(T);
+        ns3d_device_guard g(r.device);
+        hipStream_t s = compute(r);
+        if (r.st.bytes_P != bp || r.st.bytes_D != bd) {
+            HIPCHK(0, hipStreamSynchronize(s));
+            HIPCHK(0, hipStreamSynchronize(r.comm));
+            free_slab(r);
+            for (int q = 0; q < 2; ++q) {
+                HIPCHK(0, hipMalloc(&r.st.P[q], bp));
+                HIPCHK(0, hipMalloc(&r.st.D[q], bd));
+                HIPCHK(0, hipMemsetAsync(r.st.P[q], 0, bp, s));
+                HIPCHK(0, hipMemsetAsync(r.st.D[q], 0, bd, s));
+            }
+            HIPCHK(0, hipMalloc(&r.st.R, bp));
+            HIPCHK(0, hipMemsetAsync(r.st.R, 0, bp, s));
+            r.st.bytes_P = bp; r.st.bytes_D = bd;
+        }
+        r.st.glo = e.glo; r.st.ghi = e.ghi; r.st.nze = e.nze; r.st.ip = r.st.id = 0;
+        HIPCHK(0, hipMemcpyAsync((T *)r.st.P[0] + e.plane * e.glo, Pr[l], e.plane * e.nz * sizeof(T), hipMemcpyDeviceToDevice, s));
+        HIPCHK(0, hipMemcpyAsync((T *)r.st.D[0] + e.dplane * e.glo, D[l], e.dplane * (e.nz - 2) * sizeof(T), hipMemcpyDeviceToDevice, s));
+        HIPCHK(0, hipMemcpyAsync((T *)r.st.R + e.plane * e.glo, divV[l], e.plane * e.nz * sizeof(T), hipMemcpyDeviceToDevice, s));
+        if (m->G == 0) {    // single sweeps write Pr_out's interior planes only: seed the other buffer's outer planes
+            HIPCHK(0, hipMemcpyAsync(r.st.P[1], r.st.P[0], e.plane * sizeof(T), hipMemcpyDeviceToDevice, s));
+            HIPCHK(0, hipMemcpyAsync((T *)r.st.P[1] + e.plane * (e.nze - 1), (T *)r.st.P[0] + e.plane * (e.nze - 1),
+                                     e.plane * sizeof(T), hipMemcpyDeviceToDevice, s));
+        }
+    }
+    m->loaded = true;
+    return slab_exchange<T>(m, 0, 0, true);       // deep ghosts of the incoming state
+}
+
+template <class T>
+int slab_store(ns3d_mgpu *m, T *const *Pr, T *const *D)
+{
+    for (size_t l = 0; l < m->loc.size(); ++l) {
+        MRank &r = m->loc[l];
+        if (!Pr[l] || !D[l]) return fail(NS3D_ERR_ARG, "ns3d_slab_store: null field pointer (local rank %zu)", l);
+        const Ext<T> e(m, r);
+        ns3d_device_guard g(r.device);
+        hipStream_t s = compute(r);
+        HIPCHK(0, hipMemcpyAsync(Pr[l], (T *)r.st.P[r.st.ip] + e.plane * e.glo, e.plane * e.nz * sizeof(T), hipMemcpyDeviceToDevice, s));
+        HIPCHK(0, hipMemcpyAsync(D[l], (T *)r.st.D[r.st.id] + e.dplane * e.glo, e.dplane * (e.nz - 2) * sizeof(T), hipMemcpyDeviceToDevice, s));
+    }
+    return NS3D_OK;
+}
+
+// the two-iteration sweep's tile shape for the interior range of every rank: measured once, with no exchange in flight
+template <class T>
+int slab_plan(ns3d_mgpu *m)
+{
+    if (m->depth < 2) return NS3D_OK;
+    for (MRank &r : m->loc) {
+        const Ext<T> e(m, r);
+        const int np = m->G + 1;
+        const int a = has_lower(m, r) ? std::min(e.k0 + np, e.k1) : e.k0, b = has_upper(m, r) ? std::max(e.k1 - np, a) : e.k1;
+        if (b - a < 2) continue;
+        const ns3d_pt_params pe = ext_params(m, r);
+        // outputs go to the buffers the next pass overwrites anyway
+        int rc = ns3d_plan_pt_internal<T>(r.ctx, (const T *)r.st.P[r.st.ip], (T *)r.st.P[r.st.ip ^ 1], (const T *)r.st.D[r.st.id],
+                                          (T *)r.st.D[r.st.id ^ 1], (const T *)r.st.R, &pe, a, b);
+        if (rc) return rc;
+    }
+    return NS3D_OK;
+}
+
+template <class T>
+int solve_slab(ns3d_mgpu *m, T *const *Pr, T *const *D, const T *const *divV, const ns3d_pt_params *p, double eps, int niter,
+               int nchk, double err_mul, double err_div, int *iters_done, double *err_hist, int max_checks, int *n_checks)
+{
+    int rc;
+    if ((rc = slab_load<T>(m, Pr, D, divV, p))) return rc;
+    if ((rc = slab_plan<T>(m))) return rc;
+    int checks = 0, iter = 0, done = niter;
+    while (iter < niter) {
+        const int n = nchk > 0 ? std::min(nchk - iter % nchk, niter - iter) : niter - iter;   // multi.jl:464
+        if ((rc = slab_iterate<T>(m, n))) return rc;
+        iter += n;
+        if (nchk > 0 && iter % nchk == 0) {                                                     // multi.jl:465-469
+            double mx;
+            if ((rc = slab_residual<T>(m, &mx))) return rc;
+            const double err = mx * err_mul / err_div;
+            if (err_hist && checks < max_checks) err_hist[checks] = err;
+            ++checks;
+            if (eps >= 0 && (err < eps || !std::isfinite(err))) { done = iter; break; }
+        }
+    }
+    if ((rc = slab_store<T>(m, Pr, D))) return rc;
+    if (iters_done) *iters_done = done;
+    if (n_checks) *n_checks = checks;
+    return NS3D_OK;
+}
+
+template <class T>
+int update_halo_impl(ns3d_mgpu *m, T *const *fields, const int *extents, int nfields)
+{
+    const int n = (int)m->loc.size();
+    std::vector<std::vector<Block>> blocks(n);
+    for (int f = 0; f < nfields; ++f) {
+        const int sx = extents[3 * f], sy = extents[3 * f + 1], sz = extents[3 * f + 2];
+        if (sx < 1 || sy < 1 || sz < 2) return fail(NS3D_ERR_ARG, "ns3d_update_halo: field %d has extents %dx%dx%d", f, sx, sy, sz);
+        const int ol = 2 + (sz - m->nz);                  // ImplicitGlobalGrid: overlap of an array with nz+s planes
+        if (ol < 2) continue;                             // no halo in z (τxy…, dPrdτ, Rp)
+        if (sz < 2 * ol - 1) return fail(NS3D_ERR_ARG, "ns3d_update_halo: field %d too thin in z for overlap %d", f, ol);
+        const size_t plane = (size_t)sx * sy;
+        for (int l = 0; l < n; ++l) {
+            T *A = fields[(size_t)f * n + l];
+            if (!A) return fail(NS3D_ERR_ARG, "ns3d_update_halo: null pointer (field %d, local rank %d)", f, l);
+            // sends plane ol (1-based) to the lower / size−(ol−1) to the upper neighbour, receives into 1 / size
+            blocks[l].push_back({A + plane * (ol - 1), A, A + plane * (sz - ol), A + plane * (sz - 1), plane * sizeof(T)});
+        }
+    }
+    int rc = exchange_begin(m, blocks);
+    if (rc) return rc;
+    if ((rc = exchange_end(m))) return rc;
+    return finish_m(m);
+}
+
+template <class T>
+int gather_impl(ns3d_mgpu *m, const T *const *A, int sx, int sy, int sz, T *out_host)
+{
+    if (sx < 3 || sy < 3 || sz < 3) return fail(NS3D_ERR_ARG, "ns3d_gather: extents %dx%dx%d too small", sx, sy, sz);
+    const size_t blk = (size_t)(sx - 2) * (sy - 2) * (sz - 2), bytes = blk * sizeof(T);
+    for (size_t l = 0; l < m->loc.size(); ++l) {
+        MRank &r = m->loc[l];
+        if (!A[l]) return fail(NS3D_ERR_ARG, "ns3d_gather: null pointer (local rank %zu)", l);
+        ns3d_device_guard g(r.device);
+        if (r.gbuf_bytes < bytes) {
+            if (r.gbuf) { HIPCHK(0, hipStreamSynchronize(compute(r))); HIPCHK(0, hipFree(r.gbuf)); r.gbuf = nullptr; r.gbuf_bytes = 0; }
+            HIPCHK(0, hipMalloc(&r.gbuf, bytes));
+            r.gbuf_bytes = bytes;
+        }
+        hipError_t e = ns3d_enqueue_strip_inner<T>(r.ctx, compute(r), A[l], (T *)r.gbuf, sx, sy, sz);
+        if (e != hipSuccess) return fail(NS3D_ERR_HIP, "strip_inner launch: %s", hipGetErrorString(e));
+    }
+    if (!m->rccl) {
+        if (!out_host) return fail(NS3D_ERR_ARG, "ns3d_gather: null output");
+        for (size_t l = 0; l < m->loc.size(); ++l) {
+            MRank &r = m->loc[l];
+            ns3d_device_guard g(r.device);
+            HIPCHK(0, hipMemcpyAsync(out_host + blk * r.rank, r.gbuf, bytes, hipMemcpyDeviceToHost, compute(r)));
+        }
+        return sync_all(m);
+    }
+    MRank &r = m->loc[0];
+    ns3d_device_guard g(r.device);
+    hipStream_t s = compute(r);
+    if (r.rank != 0) {
+        if (m->P > 1) NCCLCHK(g_rccl.Send(r.gbuf, bytes, ncclUint8, 0, m->comm, s));
+        HIPCHK(0, hipStreamSynchronize(s));
+        return NS3D_OK;
+    }
+    if (!out_host) return fail(NS3D_ERR_ARG, "ns3d_gather: null output on rank 0");
+    if (m->stage_bytes < bytes * m->P) {
+        if (m->stage) { HIPCHK(0, hipStreamSynchronize(s)); HIPCHK(0, hipFree(m->stage)); m->stage = nullptr; m->stage_bytes = 0; }
+        HIPCHK(0, hipMalloc(&m->stage, bytes * m->P));
+        m->stage_bytes = bytes * m->P;
+    }
+    HIPCHK(0, hipMemcpyAsync(m->stage, r.gbuf, bytes, hipMemcpyDeviceToDevice, s));
+    if (m->P > 1) {
+        NCCLCHK(g_rccl.GroupStart());
+        for (int q = 1; q < m->P; ++q) NCCLCHK(g_rccl.Recv((char *)m->stage + bytes * q, bytes, ncclUint8, q, m->comm, s));
+        NCCLCHK(g_rccl.GroupEnd());
+    }
+    HIPCHK(0, hipMemcpyAsync(out_host, m->stage, bytes * m->P, hipMemcpyDeviceToHost, s));
+    HIPCHK(0, hipStreamSynchronize(s));
+    return NS3D_OK;
+}
+
+} // namespace
+
+#define CHECK_M(m)                                                                                          \
+    do {                                                                                                    \
+        if (!(m)) return fail(NS3D_ERR_ARG, "%s: null ns3d_mgpu", __func__);                                \
+    } while (0)
+
+extern "C" {
+
+// init_global_grid(nx,ny,nz) (multi.jl:325) with dims = (1,1,P), one process driving P devices
+ns3d_mgpu *ns3d_mgpu_create(int P, const int *devices, int nx, int ny, int nz_local, int flags)
+{
+    ns3d_mgpu *m = new_mgpu(P, nx, ny, nz_local, flags, "ns3d_mgpu_create");
+    if (!m) return nullptr;
+    if (!devices) { fail(NS3D_ERR_ARG, "ns3d_mgpu_create: null device list"); delete m; return nullptr; }
+    m->loc.resize(P);
+    for (int l = 0; l < P; ++l)
+        if (init_rank(m, m->loc[l], l, devices[l], flags)) { ns3d_mgpu_destroy(m); return nullptr; }
+    for (int l = 0; l + 1 < P; ++l) {      // xGMI peer access between z neighbours on different devices
+        const int a = devices[l], b = devices[l + 1];
+        if (a == b) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) {
+            (void)hipGetLastError();
+            fail(NS3D_ERR_HIP, "ns3d_mgpu_create: devices %d and %d have no peer access", a, b);
+            ns3d_mgpu_destroy(m);
+            return nullptr;
+        }
+        for (int dir = 0; dir < 2; ++dir) {
+            ns3d_device_guard g(dir ? b : a);
+            hipError_t e = hipDeviceEnablePeerAccess(dir ? a : b, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                fail(NS3D_ERR_HIP, "hipDeviceEnablePeerAccess(%d→%d): %s", dir ? b : a, dir ? a : b, hipGetErrorString(e));
+                ns3d_mgpu_destroy(m);
+                return nullptr;
+            }
+            (void)hipGetLastError();
+        }
+    }
+    return m;
+}
+
+int ns3d_mgpu_unique_id(void *id_out)
+{
+    if (!id_out) return fail(NS3D_ERR_ARG, "ns3d_mgpu_unique_id: null output");
+    int rc = load_rccl();
+    if (rc) return rc;
+    ncclUniqueId id;
+    NCCLCHK(g_rccl.GetUniqueId(&id));
+    std::memcpy(id_out, &id, sizeof id);
+    return NS3D_OK;
+}
+
+// init_global_grid for one rank of P processes (one per GPU); collective over the P ranks
+ns3d_mgpu *ns3d_mgpu_create_rank(int P, int rank, int device, const void *unique_id, int nx, int ny, int nz_local, int flags)
+{
+    ns3d_mgpu *m = new_mgpu(P, nx, ny, nz_local, flags, "ns3d_mgpu_create_rank");
+    if (!m) return nullptr;
+    if (rank < 0 || rank >= P || !unique_id) {
+        fail(NS3D_ERR_ARG, "ns3d_mgpu_create_rank: rank %d of %d, unique_id %p", rank, P, unique_id);
+        delete m;
+        return nullptr;
+    }
+    if (load_rccl()) { delete m; return nullptr; }
+    m->rccl = true;
+    m->loc.resize(1);
+    if (init_rank(m, m->loc[0], rank, device, flags)) { ns3d_mgpu_destroy(m); return nullptr; }
+    ns3d_device_guard g(device);
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof id);
+    ncclResult_t r = g_rccl.CommInitRank(&m->comm, P, id, rank);
+    if (r != ncclSuccess) {
+        fail(NS3D_ERR_RCCL, "ncclCommInitRank(rank %d of %d, device %d): %s", rank, P, device, g_rccl.GetErrorString(r));
+        m->comm = nullptr;
+        ns3d_mgpu_destroy(m);
+        return nullptr;
+    }
+    if (g_rccl.CommCount(m->comm, &m->rccl_ranks) != ncclSuccess) m->rccl_ranks = 0;
+    return m;
+}
+
+// finalize_global_grid() (multi.jl:534)
+void ns3d_mgpu_destroy(ns3d_mgpu *m)
+{
+    if (!m) return;
+    for (MRank &r : m->loc) {
+        if (!r.ctx) continue;
+        ns3d_device_guard g(r.device);
+        (void)hipStreamSynchronize(compute(r));
+        if (r.comm) (void)hipStreamSynchronize(r.comm);
+    }
+    if (m->comm) (void)g_rccl.CommDestroy(m->comm);
+    for (MRank &r : m->loc) {
+        ns3d_device_guard g(r.device);
+        free_slab(r);
+        if (r.gbuf) (void)hipFree(r.gbuf);
+        if (r.ev_ready) (void)hipEventDestroy(r.ev_ready);
+        if (r.ev_landed) (void)hipEventDestroy(r.ev_landed);
+        if (r.comm) (void)hipStreamDestroy(r.comm);
+        if (r.ctx) ns3d_destroy(r.ctx);
+    }
+    if (m->stage) (void)hipFree(m->stage);
+    delete m;
+}
+
+int ns3d_mgpu_world(const ns3d_mgpu *m) { return m ? m->P : -1; }
+int ns3d_mgpu_nlocal(const ns3d_mgpu *m) { return m ? (int)m->loc.size() : -1; }
+int ns3d_mgpu_rank(const ns3d_mgpu *m, int local) { return (m && local >= 0 && local < (int)m->loc.size()) ? m->loc[local].rank : -1; }
+ns3d_ctx *ns3d_mgpu_ctx(ns3d_mgpu *m, int local) { return (m && local >= 0 && local < (int)m->loc.size()) ? m->loc[local].ctx : nullptr; }
+int ns3d_mgpu_nz_g(const ns3d_mgpu *m) { return m ? m->P * (m->nz - 2) + 2 : -1; }
+const char *ns3d_mgpu_transport(const ns3d_mgpu *m) { return !m ? "" : (m->rccl ? "rccl" : "peer"); }
+int ns3d_mgpu_rccl_ranks(const ns3d_mgpu *m) { return m ? m->rccl_ranks : -1; }
+
+int ns3d_mgpu_set_temporal(ns3d_mgpu *m, int depth)
+{
+    CHECK_M(m);
+    if (depth < 1 || depth > 2) return fail(NS3D_ERR_ARG, "ns3d_mgpu_set_temporal: depth %d (1 or 2)", depth);
+    if (m->loaded && depth != m->depth) m->loaded = false;      // ghost depth changes: the state must be loaded again
+    m->depth = depth;
+    return NS3D_OK;
+}
+
+int ns3d_mgpu_sync(ns3d_mgpu *m)
+{
+    CHECK_M(m);
+    return sync_all(m);
+}
+
+// max_g(A) = MPI.Allreduce(maximum(A), MPI.MAX) (multi.jl:21) over every rank's local maximum; NaN-propagating
+int ns3d_max_g(ns3d_mgpu *m, const double *local_max, double *out)
+{
+    CHECK_M(m);
+    if (!local_max || !out) return fail(NS3D_ERR_ARG, "ns3d_max_g: null argument");
+    bool nan = false;
+    double best = -INFINITY;
+    for (size_t l = 0; l < m->loc.size(); ++l) {
+        if (local_max[l] != local_max[l]) nan = true;
+        else best = std::max(best, local_max[l]);
+    }
+    if (m->rccl) {
+        // max over doubles through two monotone unsigned keys: [is-NaN flag, order-preserving image of the double]
+        MRank &r = m->loc[0];
+        ns3d_device_guard g(r.device);
+        hipStream_t s = compute(r);
+        unsigned long long bits;
+        std::memcpy(&bits, &best, sizeof bits);
+        bits = (bits & 0x8000000000000000ull) ? ~bits : (bits | 0x8000000000000000ull);
+        r.ctx->key_host[1] = nan ? 1ull : 0ull;
+        r.ctx->key_host[2] = bits;
+        HIPCHK(0, hipMemcpyAsync(r.ctx->key_dev + 1, r.ctx->key_host + 1, 2 * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+        NCCLCHK(g_rccl.AllReduce(r.ctx->key_dev + 1, r.ctx->key_dev + 1, 2, ncclUint64, ncclMax, m->comm, s));
+        HIPCHK(0, hipMemcpyAsync(r.ctx->key_host + 1, r.ctx->key_dev + 1, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(0, hipStreamSynchronize(s));
+        nan = r.ctx->key_host[1] != 0ull;
+        bits = r.ctx->key_host[2];
+        bits = (bits & 0x8000000000000000ull) ? (bits & 0x7FFFFFFFFFFFFFFFull) : ~bits;
+        std::memcpy(&best, &bits, sizeof best);
+    }
+    *out = nan ? NAN : best;
+    return NS3D_OK;
+}
+
+// n × { update_dPrdτ!; update_Pr!; set_bc_Pr!; update_halo!(Pr) }  (multi.jl:459-463) on the loaded state
+int ns3d_slab_iterate(ns3d_mgpu *m, int n_iters)
+{
+    CHECK_M(m);
+    if (!m->loaded) return fail(NS3D_ERR_STATE, "ns3d_slab_iterate: no state loaded (ns3d_slab_load)");
+    if (n_iters < 0) return fail(NS3D_ERR_ARG, "ns3d_slab_iterate: negative count");
+    int rc = m->esize == 8 ? slab_iterate<double>(m, n_iters) : slab_iterate<float>(m, n_iters);
+    return rc ? rc : finish_m(m);
+}
+// the tile shape of the interior sweeps, measured now (ns3d_plan_pt on every local rank)
+int ns3d_slab_plan(ns3d_mgpu *m)
+{
+    CHECK_M(m);
+    if (!m->loaded) return fail(NS3D_ERR_STATE, "ns3d_slab_plan: no state loaded (ns3d_slab_load)");
+    return m->esize == 8 ? slab_plan<double>(m) : slab_plan<float>(m);
+}
+// max_g(maximum(abs.(Rp))) of the loaded state's current iterate (multi.jl:465-466,21)
+int ns3d_slab_residual(ns3d_mgpu *m, double *out)
+{
+    CHECK_M(m);
+    if (!m->loaded) return fail(NS3D_ERR_STATE, "ns3d_slab_residual: no state loaded (ns3d_slab_load)");
+    if (!out) return fail(NS3D_ERR_ARG, "ns3d_slab_residual: null output");
+    return m->esize == 8 ? slab_residual<double>(m, out) : slab_residual<float>(m, out);
+}
+
+} // extern "C"
+
+#define NS3D_MGPU_DEFINE(T, S)                                                                               \
+    extern "C" int ns3d_update_halo_##S(ns3d_mgpu *m, T *const *fields, const int *extents, int nfields)     \
+    {                                                                                                        \
+        CHECK_M(m);                                                                                          \
+        if (nfields < 0 || (nfields > 0 && (!fields || !extents)))                                           \
+            return fail(NS3D_ERR_ARG, "ns3d_update_halo: bad field list");                                   \
+        return update_halo_impl<T>(m, fields, extents, nfields);                                             \
+    }                                                                                                        \
+    extern "C" int ns3d_gather_##S(ns3d_mgpu *m, const T *const *A, int sx, int sy, int sz, T *out_host)     \
+    {                                                                                                        \
+        CHECK_M(m);                                                                                          \
+        if (!A) return fail(NS3D_ERR_ARG, "ns3d_gather: null field list");                                   \
+        return gather_impl<T>(m, A, sx, sy, sz, out_host);                                                   \
+    }                                                                                                        \
+    extern "C" int ns3d_slab_load_##S(ns3d_mgpu *m, const T *const *Pr, const T *const *dPrdtau,             \
+                                      const T *const *divV, const ns3d_pt_params *p)                         \
+    {                                                                                                        \
+        CHECK_M(m);                                                                                          \
+        if (!Pr || !dPrdtau || !divV) return fail(NS3D_ERR_ARG, "ns3d_slab_load: null field list");          \
+        m->loaded = false;                                                                                   \
+        int rc = slab_load<T>(m, Pr, dPrdtau, divV, p);                                                      \
+        return rc ? rc : finish_m(m);                                                                        \
+    }                                                                                                        \
+    extern "C" int ns3d_slab_store_##S(ns3d_mgpu *m, T *const *Pr, T *const *dPrdtau)                        \
+    {                                                                                                        \
+        CHECK_M(m);                                                                                          \
+        if (!m->loaded || m->esize != (int)sizeof(T))                                                        \
+            return fail(NS3D_ERR_STATE, "ns3d_slab_store: no state of this element type loaded");            \
+        if (!Pr || !dPrdtau) return fail(NS3D_ERR_ARG, "ns3d_slab_store: null field list");                  \
+        int rc = slab_store<T>(m, Pr, dPrdtau);                                                              \
+        return rc ? rc : finish_m(m);                                                                        \
+    }                                                                                                        \
+    extern "C" int ns3d_pt_solve_slab_##S(ns3d_mgpu *m, T *const *Pr, T *const *dPrdtau, const T *const *divV,\
+                                          const ns3d_pt_params *p, double eps, int niter, int nchk,          \
+                                          double err_mul, double err_div, int *iters_done, double *err_hist, \
+                                          int max_checks, int *n_checks)                                     \
+    {                                                                                                        \
+        CHECK_M(m);                                                                                          \
+        if (!Pr || !dPrdtau || !divV) return fail(NS3D_ERR_ARG, "ns3d_pt_solve_slab: null field list");      \
+        if (niter < 0 || nchk < 0) return fail(NS3D_ERR_ARG, "ns3d_pt_solve_slab: negative niter/nchk");     \
+        m->loaded = false;                                                                                   \
+        int rc = solve_slab<T>(m, Pr, dPrdtau, divV, p, eps, niter, nchk, err_mul, err_div, iters_done,      \
+                               err_hist, max_checks, n_checks);                                              \
+        return rc ? rc : finish_m(m);                                                                        \
+    }
+
+NS3D_MGPU_DEFINE(double, f64)
+NS3D_MGPU_DEFINE(float, f32)

@@ -50,35 +50,50 @@ def _inner(t):
     return K.to_numpy(t)[1:-1, 1:-1, 1:-1]
 
 
-def _gather_all(grid, f):
-    """multi.jl:399-403 / :528-532"""
-    return tuple(grid.gather(_inner(getattr(f, n))) for n in ("C", "Pr", "Vx", "Vy", "Vz"))
+def _gather_all(grid, fs):
+    """multi.jl:399-403 / :528-532 for the local ranks' fields `fs`"""
+    if hasattr(grid, "gather_fields"):                     # C-ABI grid: halo-stripping and transport inside libns3d
+        return tuple(grid.gather_fields([getattr(f, n) for f in fs]) for n in ("C", "Pr", "Vx", "Vy", "Vz"))
+    return tuple(grid.gather(_inner(getattr(fs[0], n))) for n in ("C", "Pr", "Vx", "Vy", "Vz"))
+
+
+def _is_root(grid):
+    return grid.is_root() if hasattr(grid, "is_root") else grid.me == 0
 
 
 def _save_frame(grid, fields_v, iframe):
     """multi.jl:404-413 / :515-522 — rank 0 writes Float32 raw dumps of the gathered arrays."""
-    if grid.me != 0:
+    if not _is_root(grid):
         return
     os.makedirs("./out_save", exist_ok=True)
     for name, A in zip(("C", "Pr", "Vx", "Vy", "Vz"), fields_v):
         save_array("out_save/out_%s_v_%04d" % (name, iframe), A.astype(np.float32))
 
 
-def pt_loop_reference(ctx, grid, f, p, niter, do_print=False):
-    """The inner loop exactly as written in multi.jl:458-471 (including its redundant halo updates)."""
+def pt_loop_reference(ctxs, grid, fs, ps, niter, do_print=False):
+    """The inner loop exactly as written in multi.jl:458-471 (including its redundant halo updates); `fs`, `ps`, `ctxs`
+    hold one entry per local rank."""
+    p = ps[0]
     errs, done = [], niter
+    col = lambda n: [getattr(f, n) for f in fs]
     for it in range(1, niter + 1):
-        K.update_dPrdtau(f.Pr, f.dPrdtau, f.divV, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, ctx=ctx)   # :459
-        grid.update_halo(f.divV)                                                                          # :460
-        K.update_Pr(f.Pr, f.dPrdtau, p.dtau, ctx=ctx)                                                     # :461
-        grid.update_halo(f.Pr)                                                                            # :462
-        K.set_bc_Pr_multi(f.Pr, p.owns_outlet, 0.0, ctx=ctx)                                              # :463 → :176-181
-        grid.update_halo(f.Pr)                                                                            # :182
+        for f, c in zip(fs, ctxs):
+            K.update_dPrdtau(f.Pr, f.dPrdtau, f.divV, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, ctx=c)   # :459
+        grid.update_halo(col("divV"))                                                                     # :460
+        for f, c in zip(fs, ctxs):
+            K.update_Pr(f.Pr, f.dPrdtau, p.dtau, ctx=c)                                                   # :461
+        grid.update_halo(col("Pr"))                                                                       # :462
+        for f, c, q in zip(fs, ctxs, ps):
+            K.set_bc_Pr_multi(f.Pr, q.owns_outlet, 0.0, ctx=c)                                            # :463 → :176-181
+        grid.update_halo(col("Pr"))                                                                       # :182
         if it % p.nchk == 0:                                                                              # :464
-            K.compute_res(f.Rp, f.Pr, f.divV, p.rho, p.dt, p.dx, p.dy, p.dz, ctx=ctx)                     # :465
-            err = grid.max_g(K.max_abs(f.Rp, ctx=ctx)) * (p.ly * p.ly) / p.psc                              # :466
+            loc = []
+            for f, c in zip(fs, ctxs):
+                K.compute_res(f.Rp, f.Pr, f.divV, p.rho, p.dt, p.dx, p.dy, p.dz, ctx=c)                   # :465
+                loc.append(K.max_abs(f.Rp, ctx=c))
+            err = grid.max_g(loc if len(loc) > 1 else loc[0]) * (p.ly * p.ly) / p.psc                      # :466
             errs.append(err)
-            if grid.me == 0 and do_print:
+            if _is_root(grid) and do_print:
                 print("  #iter = %d, err = %1.3e" % (it, err))                                            # :468
             if err < p.eps or not math.isfinite(err):                                                     # :469
                 done = it
@@ -119,91 +134,122 @@ def pt_loop_fused_slab(ctx, grid, f, p, pt, niter, do_print=False, scratch=None)
 
 def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=10, *, mode="strict", fused=True,
                        temporal=True, dtype=torch.float64, faithful=True, grid=None, device=None, niter_cap=None,
-                       return_info=False):
-    """run_navierstokes3D (multi.jl:287-536).  nx is the LOCAL streamwise size (ny = nz = ceil(0.6 nx) local);
-    with an initialised torch.distributed process group the domain is decomposed into one z-slab per rank."""
+                       return_info=False, shape=None):
+    """run_navierstokes3D (multi.jl:287-536).  nx is the LOCAL streamwise size (ny = nz = ceil(0.6 nx) local).
+    `grid` decides the decomposition: None = one rank; a halo.ZSlabGrid = this process is one z-slab rank of an
+    initialised torch.distributed group; a mgpu.MgpuGrid = the C-ABI grid (this process drives every local rank of an
+    ns3d_mgpu: all P of them in the one-process form, one under RCCL).
+    `shape` (dict: ny, nz, ly_lx, lz_lx) overrides the literals multi.jl:302-303,323-324 for grids the reference cannot
+    produce without editing them (BASELINE configs[3]: 512×512×1024 global)."""
     if do_vis:
         raise NotImplementedError("plotting (multi.jl:416-443, 486-513) is out of scope of this build")
     if device is None:
         device = torch.cuda.current_device()
-    dev = torch.device("cuda", device)
-    ctx = K.Context(device, mode, async_=True)
-    P, me = 1, 0
+    shape = dict(shape or {})
     if grid is None:
-        p0 = multi_params(nx)
+        p0 = multi_params(nx, **shape)
         grid = ZSlabGrid(p0.nx, p0.ny, p0.nz)                                                  # :325
-    P, me = grid.P, grid.me
-    p = multi_params(nx, P, me)
+    P = grid.P
+    local_ranks = list(getattr(grid, "local_ranks", [grid.me]))
+    if hasattr(grid, "contexts"):
+        ctxs = list(grid.contexts)                         # contexts of the ns3d_mgpu's ranks (their devices)
+    else:
+        ctxs = [K.Context(device, mode, async_=True)]
+    ps = [multi_params(nx, P, me, **shape) for me in local_ranks]
+    p = ps[0]
     nx, ny, nz = p.nx, p.ny, p.nz
     niter = p.niter if niter_cap is None else min(p.niter, niter_cap)
-    f = _alloc(nx, ny, nz, dtype, dev)                                                        # :343-360
+    fs = [_alloc(nx, ny, nz, dtype, torch.device("cuda", c.device)) for c in ctxs]             # :343-360
+    col = lambda n: [getattr(f, n) for f in fs]
     # initialization :369-373
-    f.Vy[0, :, :] = p.vin                                                                     # :369 (sic)
-    # :370 Pr = -(z_g-dz/2)*ρ*g (+0+0): identically 0 because g = 1/Fr² = 0 (:316); evaluated for fidelity
-    zg = np.array([(me * (nz - 2) + iz) * p.dz for iz in range(nz)])
-    f.Pr[:, :, :] = torch.from_numpy(-(zg - p.dz / 2) * p.rho * p.g + 0.0).to(dev, dtype)[None, None, :]
-    grid.update_halo(f.Pr)                                                                    # :371
-    cyl = (p.a2, p.b2, p.ox, p.oy, p.sinb, p.cosb, p.xco_g, p.yco_g, p.zco_g, p.lx, p.ly, p.lz, p.dx, p.dy, p.dz)
-    K.set_cylinder(f.C, f.Vx, f.Vy, f.Vz, *cyl, ctx=ctx)                                      # :372
-    grid.update_halo(f.C, f.Vx, f.Vy, f.Vz)                                                   # :373
+    for f, q in zip(fs, ps):
+        me = q.coords[2]
+        f.Vy[0, :, :] = q.vin                                                                 # :369 (sic)
+        # :370 Pr = -(z_g-dz/2)*ρ*g (+0+0): identically 0 because g = 1/Fr² = 0 (:316); evaluated for fidelity
+        zg = np.array([(me * (nz - 2) + iz) * q.dz for iz in range(nz)])
+        f.Pr[:, :, :] = torch.from_numpy(-(zg - q.dz / 2) * q.rho * q.g + 0.0).to(f.Pr.device, dtype)[None, None, :]
+    grid.update_halo(col("Pr"))                                                               # :371
+    cyls = [(q.a2, q.b2, q.ox, q.oy, q.sinb, q.cosb, q.xco_g, q.yco_g, q.zco_g, q.lx, q.ly, q.lz, q.dx, q.dy, q.dz)
+            for q in ps]
+    for f, c, cyl in zip(fs, ctxs, cyls):
+        K.set_cylinder(f.C, f.Vx, f.Vy, f.Vz, *cyl, ctx=c)                                    # :372
+    grid.update_halo(col("C"), col("Vx"), col("Vy"), col("Vz"))                               # :373
+    sync = lambda: [c.sync() for c in ctxs]
     iframe = 0
     if do_save:                                                                               # :404-413
-        ctx.sync()
-        _save_frame(grid, _gather_all(grid, f), iframe)
+        sync()
+        _save_frame(grid, _gather_all(grid, fs), iframe)
     iframe += 1
-    pt = K.pt_params(f.Pr, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, L.NS3D_BC_MULTI, p.owns_outlet, 0.0,
-                     p.g, grid.z_lo_is_halo(), grid.z_hi_is_halo())
+    pts = [K.pt_params(f.Pr, q.rho, q.dt, q.dtau, q.damp, q.dx, q.dy, q.dz, L.NS3D_BC_MULTI, q.owns_outlet, 0.0, q.g,
+                       me > 0, me < P - 1) for f, q, me in zip(fs, ps, local_ranks)]
     if not temporal:
-        ctx.set_pt2_variant(-1)
+        for c in ctxs:
+            c.set_pt2_variant(-1)
+    mg = getattr(grid, "mg", None)
+    if mg is not None:
+        mg.set_temporal(2 if (temporal and nz >= 4) else 1)
     slab = None
-    if fused and P > 1 and temporal and nz >= 4:
-        slab = SlabPTSolver(ctx, grid, f.Pr, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, L.NS3D_BC_MULTI,
+    if fused and P > 1 and mg is None and temporal and nz >= 4:
+        slab = SlabPTSolver(ctxs[0], grid, fs[0].Pr, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, L.NS3D_BC_MULTI,
                             p.owns_outlet, 0.0, p.g)
-    scratch = K.clone(f.Pr) if (fused and P > 1 and slab is None) else None
+    scratch = K.clone(fs[0].Pr) if (fused and P > 1 and mg is None and slab is None) else None
     info = SimpleNamespace(iters=[], errs=[], params=p)
     nsave = 10                                                                                # :332
+    root = _is_root(grid)
     for it in range(1, nt + 1):                                                               # :446
-        K.update_tau(f.txx, f.tyy, f.tzz, f.txy, f.txz, f.tyz, f.Vx, f.Vy, f.Vz, p.mu, p.dx, p.dy, p.dz, ctx=ctx)  # :449
-        grid.update_halo(f.txx, f.tyy, f.tzz)                                                 # :450
-        K.predict_V(f.Vx, f.Vy, f.Vz, f.txx, f.tyy, f.tzz, f.txy, f.txz, f.tyz, p.rho, p.g, p.dt, p.dx, p.dy, p.dz,
-                    ctx=ctx)                                                                  # :451
-        K.set_cylinder(f.C, f.Vx, f.Vy, f.Vz, *cyl, ctx=ctx)                                  # :452
-        grid.update_halo(f.C, f.Vx, f.Vy, f.Vz)                                               # :453
-        K.update_divV(f.divV, f.Vx, f.Vy, f.Vz, p.dx, p.dy, p.dz, ctx=ctx)                    # :454
-        grid.update_halo(f.divV)                                                              # :455
-        if me == 0 and do_print:
+        for f, c in zip(fs, ctxs):
+            K.update_tau(f.txx, f.tyy, f.tzz, f.txy, f.txz, f.tyz, f.Vx, f.Vy, f.Vz, p.mu, p.dx, p.dy, p.dz, ctx=c)  # :449
+        grid.update_halo(col("txx"), col("tyy"), col("tzz"))                                  # :450
+        for f, c, cyl in zip(fs, ctxs, cyls):
+            K.predict_V(f.Vx, f.Vy, f.Vz, f.txx, f.tyy, f.tzz, f.txy, f.txz, f.tyz, p.rho, p.g, p.dt, p.dx, p.dy, p.dz,
+                        ctx=c)                                                                # :451
+            K.set_cylinder(f.C, f.Vx, f.Vy, f.Vz, *cyl, ctx=c)                                # :452
+        grid.update_halo(col("C"), col("Vx"), col("Vy"), col("Vz"))                           # :453
+        for f, c in zip(fs, ctxs):
+            K.update_divV(f.divV, f.Vx, f.Vy, f.Vz, p.dx, p.dy, p.dz, ctx=c)                  # :454
+        grid.update_halo(col("divV"))                                                         # :455
+        if root and do_print:
             print("#it = %d" % it)                                                            # :456
+        show = (lambda i, e: print("  #iter = %d, err = %1.3e" % (i, e))) if (root and do_print) else None
         if not fused:                                                                         # :458-471
-            done, errs = pt_loop_reference(ctx, grid, f, p, niter, do_print)
+            done, errs = pt_loop_reference(ctxs, grid, fs, ps, niter, do_print)
         elif P == 1:
-            done, errs = K.pt_solve(f.Pr, f.dPrdtau, f.divV, pt, p.eps, niter, p.nchk, p.ly * p.ly, p.psc, ctx=ctx)
-            if me == 0 and do_print:
-                for q, e in enumerate(errs):
-                    print("  #iter = %d, err = %1.3e" % ((q + 1) * p.nchk, e))
-        elif slab is not None:                                  # z-slab rank, two iterations per pass, deep ghosts
-            slab.load(f.Pr, f.dPrdtau, f.divV)
-            show = (lambda i, e: print("  #iter = %d, err = %1.3e" % (i, e))) if (me == 0 and do_print) else None
+            done, errs = K.pt_solve(fs[0].Pr, fs[0].dPrdtau, fs[0].divV, pts[0], p.eps, niter, p.nchk, p.ly * p.ly, p.psc,
+                                    ctx=ctxs[0])
+        elif mg is not None:                                    # the whole loop inside libns3d (ns3d_pt_solve_slab)
+            done, errs = mg.pt_solve_slab(col("Pr"), col("dPrdtau"), col("divV"), pts[0], p.eps, niter, p.nchk,
+                                          p.ly * p.ly, p.psc)
+        elif slab is not None:                                  # z-slab rank over torch.distributed, deep ghosts
+            slab.load(fs[0].Pr, fs[0].dPrdtau, fs[0].divV)
             done, errs = slab.solve(p.eps, niter, p.nchk, p.ly * p.ly, p.psc, show)
-            slab.store(f.Pr, f.dPrdtau)
+            slab.store(fs[0].Pr, fs[0].dPrdtau)
+            show = None
         else:
-            done, errs = pt_loop_fused_slab(ctx, grid, f, p, pt, niter, do_print, scratch)
+            done, errs = pt_loop_fused_slab(ctxs[0], grid, fs[0], p, pts[0], niter, do_print, scratch)
+            show = None
+        if show is not None and fused:
+            for q, e in enumerate(errs):
+                show((q + 1) * p.nchk, e)
         info.iters.append(done); info.errs.append(errs)
-        K.correct_V(f.Vx, f.Vy, f.Vz, f.Pr, p.dt, p.rho, p.dx, p.dy, p.dz, ctx=ctx)            # :472
-        K.set_cylinder(f.C, f.Vx, f.Vy, f.Vz, *cyl, ctx=ctx)                                  # :473
-        K.set_bc_Vel_multi(f.Vx, f.Vy, f.Vz, p.owns_inlet, p.vin, ctx=ctx)                     # :474 → :157-166
-        grid.update_halo(f.Vx, f.Vy, f.Vz)                                                    # :167
-        K.copy(f.Vx_o, f.Vx, ctx=ctx); K.copy(f.Vy_o, f.Vy, ctx=ctx)                          # :475
-        K.copy(f.Vz_o, f.Vz, ctx=ctx); K.copy(f.C_o, f.C, ctx=ctx)
-        K.advect(f.Vx, f.Vx_o, f.Vy, f.Vy_o, f.Vz, f.Vz_o, f.C, f.C_o, p.dt, p.dx, p.dy, p.dz, faithful, ctx=ctx)  # :476
-        grid.update_halo(f.Vx, f.Vy, f.Vz)                                                    # :477 (not C)
+        for f, c, cyl, q in zip(fs, ctxs, cyls, ps):
+            K.correct_V(f.Vx, f.Vy, f.Vz, f.Pr, p.dt, p.rho, p.dx, p.dy, p.dz, ctx=c)          # :472
+            K.set_cylinder(f.C, f.Vx, f.Vy, f.Vz, *cyl, ctx=c)                                # :473
+            K.set_bc_Vel_multi(f.Vx, f.Vy, f.Vz, q.owns_inlet, p.vin, ctx=c)                   # :474 → :157-166
+        grid.update_halo(col("Vx"), col("Vy"), col("Vz"))                                     # :167
+        for f, c in zip(fs, ctxs):
+            K.copy(f.Vx_o, f.Vx, ctx=c); K.copy(f.Vy_o, f.Vy, ctx=c)                          # :475
+            K.copy(f.Vz_o, f.Vz, ctx=c); K.copy(f.C_o, f.C, ctx=c)
+            K.advect(f.Vx, f.Vx_o, f.Vy, f.Vy_o, f.Vz, f.Vz_o, f.C, f.C_o, p.dt, p.dx, p.dy, p.dz, faithful, ctx=c)  # :476
+        grid.update_halo(col("Vx"), col("Vy"), col("Vz"))                                     # :477 (not C)
         if do_save and it % nsave == 0:                                                       # :479-525
-            ctx.sync()
-            _save_frame(grid, _gather_all(grid, f), iframe)
+            sync()
+            _save_frame(grid, _gather_all(grid, fs), iframe)
             iframe += 1
-    ctx.sync()
-    out = _gather_all(grid, f)                                                                # :528-532
-    info.fields = f
-    info.ctx = ctx
+    sync()
+    out = _gather_all(grid, fs)                                                               # :528-532
+    info.fields = fs[0]
+    info.local_fields = fs
+    info.ctx = ctxs[0]
     return out + ((info,) if return_info else ())                                             # :535
 
 

@@ -30,6 +30,7 @@ class ZSlabGrid:
             self.me, self.P, self.backend = 0, 1, None
         self.dims = (1, 1, self.P)
         self.coords = (0, 0, self.me)
+        self.nlocal, self.local_ranks = 1, [self.me]     # one rank per process (mgpu.MgpuGrid may hold several)
         self.lower = self.me - 1 if self.me > 0 else None
         self.upper = self.me + 1 if self.me < self.P - 1 else None
         if transport == "auto":
@@ -75,6 +76,7 @@ class ZSlabGrid:
     def update_halo(self, *fields):
         """update_halo!(A…) (multi.jl:371,373,450,453,455,460,462,182,167,477): blocking for the caller's
         stream semantics (the exchanged planes are ready for the next kernel on the current stream)."""
+        fields = [f[0] if isinstance(f, (list, tuple)) else f for f in fields]   # per-local-rank lists of one
         work = self.start_halo(*fields)
         self.finish_halo(work)
 
@@ -168,6 +170,8 @@ class ZSlabGrid:
     # ---- max_g --------------------------------------------------------------------------------------------
     def max_g(self, local_max):
         """max_g(A) (multi.jl:21): MPI.Allreduce(max_l, MAX).  NaN-propagating like the local maximum."""
+        if isinstance(local_max, (list, tuple)):
+            local_max = local_max[0]
         if self.P == 1:
             return float(local_max)
         dev = "cuda" if (self.backend == "nccl") else "cpu"

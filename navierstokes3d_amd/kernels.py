@@ -61,6 +61,17 @@ class Context:
     (gpu.jl:4-8): device + arithmetic mode.  mode: 'strict' (bit-identical to the reference operation
     order) or 'fast' (reciprocals + FMA)."""
 
+    _owns = True
+
+    @classmethod
+    def from_handle(cls, handle, device, mode):
+        """Wrap an ns3d_ctx owned by someone else (a rank of an ns3d_mgpu): same calls, never destroyed from here."""
+        self = cls.__new__(cls)
+        self.lib = L.load()
+        self.device, self.mode, self.handle, self._owns = int(device), mode, handle, False
+        self.use_torch_stream()
+        return self
+
     def __init__(self, device=None, mode="strict", async_=False, ieee_div=False):
         self.lib = L.load()
         if not torch.cuda.is_available():
@@ -113,7 +124,8 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
-            self.lib.ns3d_destroy(self.handle)
+            if self._owns:
+                self.lib.ns3d_destroy(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -353,6 +365,16 @@ def pt_sweep2(Pr_in, Pr_out, dPrdtau_in, dPrdtau_out, divV, p, k0=None, k1=None,
     as two pt_sweep calls); all four buffers distinct."""
     nx, ny, nz = Pr_in.shape
     _ctx(ctx, Pr_in).call("pt_sweep2", Pr_in, _chk(Pr_in, None, "Pr_in"), _chk(Pr_out, (nx, ny, nz), "Pr_out"),
+                          _chk(dPrdtau_in, (nx - 2, ny - 2, nz - 2), "dPrdtau_in"),
+                          _chk(dPrdtau_out, (nx - 2, ny - 2, nz - 2), "dPrdtau_out"), _chk(divV, (nx, ny, nz), "divV"),
+                          C.byref(p), 1 if k0 is None else int(k0), nz - 1 if k1 is None else int(k1))
+
+
+def plan_pt(Pr_in, Pr_out, dPrdtau_in, dPrdtau_out, divV, p, k0=None, k1=None, ctx=None):
+    """Plan phase of the two-iteration sweep: time the tile shapes now, on these arguments, and remember the winner
+    (ns3d_plan_pt).  pt_iterate / pt_solve plan by themselves on first use; pt_sweep2 only looks the choice up."""
+    nx, ny, nz = Pr_in.shape
+    _ctx(ctx, Pr_in).call("plan_pt", Pr_in, _chk(Pr_in, None, "Pr_in"), _chk(Pr_out, (nx, ny, nz), "Pr_out"),
                           _chk(dPrdtau_in, (nx - 2, ny - 2, nz - 2), "dPrdtau_in"),
                           _chk(dPrdtau_out, (nx - 2, ny - 2, nz - 2), "dPrdtau_out"), _chk(divV, (nx, ny, nz), "divV"),
                           C.byref(p), 1 if k0 is None else int(k0), nz - 1 if k1 is None else int(k1))

@@ -7,6 +7,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NS3D_LIB") or os.path.join(_HERE, "libns3d.so")   # NS3D_LIB: A/B-test another build
 
 NS3D_OK = 0
+NS3D_ERR_ARG, NS3D_ERR_HIP, NS3D_ERR_STATE, NS3D_ERR_RCCL = 1, 2, 3, 4
+NS3D_UNIQUE_ID_BYTES = 128
 NS3D_STRICT, NS3D_FAST, NS3D_ASYNC, NS3D_IEEE_DIV = 0x0, 0x1, 0x2, 0x4
 NS3D_BC_MULTI, NS3D_BC_GPU = 0, 1
 
@@ -55,6 +57,7 @@ SIGNATURES = {
     "pt_iterate": [_P] * 3 + [C.POINTER(PtParams), _I],
     "pt_sweep": [_P] * 4 + [C.POINTER(PtParams), _I, _I],
     "pt_sweep2": [_P] * 5 + [C.POINTER(PtParams), _I, _I],
+    "plan_pt": [_P] * 5 + [C.POINTER(PtParams), _I, _I],
     "residual_max": [_P] * 2 + [C.POINTER(PtParams), C.POINTER(_D)],
     "selftest_exact_div": [_D, _L, C.c_ulonglong, C.POINTER(_L)],
     "pt_solve": [_P] * 3 + [C.POINTER(PtParams), _D, _I, _I, _D, _D, C.POINTER(_I), C.POINTER(_D), _I, C.POINTER(_I)],
@@ -64,10 +67,41 @@ CONTEXT_SYMBOLS = ["ns3d_version", "ns3d_last_error", "ns3d_create", "ns3d_destr
                    "ns3d_set_pt2_variant", "ns3d_set_graph_mode", "ns3d_set_autotune", "ns3d_last_pt2_variant"]
 
 
+_PP = C.POINTER(C.c_void_p)      # T *const *  — one device pointer per local rank (field-major for field lists)
+# multi-GPU layer (first argument ns3d_mgpu*): name → (restype, argtypes)
+MGPU_SYMBOLS = {
+    "ns3d_mgpu_create": (_P, [_I, C.POINTER(_I), _I, _I, _I, _I]),
+    "ns3d_mgpu_unique_id": (_I, [C.c_char_p]),
+    "ns3d_mgpu_create_rank": (_P, [_I, _I, _I, C.c_char_p, _I, _I, _I, _I]),
+    "ns3d_mgpu_destroy": (None, [_P]),
+    "ns3d_mgpu_world": (_I, [_P]),
+    "ns3d_mgpu_nlocal": (_I, [_P]),
+    "ns3d_mgpu_rank": (_I, [_P, _I]),
+    "ns3d_mgpu_ctx": (_P, [_P, _I]),
+    "ns3d_mgpu_nz_g": (_I, [_P]),
+    "ns3d_mgpu_transport": (C.c_char_p, [_P]),
+    "ns3d_mgpu_rccl_ranks": (_I, [_P]),
+    "ns3d_mgpu_sync": (_I, [_P]),
+    "ns3d_max_g": (_I, [_P, C.POINTER(_D), C.POINTER(_D)]),
+    "ns3d_mgpu_set_temporal": (_I, [_P, _I]),
+    "ns3d_slab_iterate": (_I, [_P, _I]),
+    "ns3d_slab_plan": (_I, [_P]),
+    "ns3d_slab_residual": (_I, [_P, C.POINTER(_D)]),
+}
+MGPU_SIGNATURES = {   # typed (_f64/_f32), after the leading ns3d_mgpu*
+    "update_halo": [_PP, C.POINTER(_I), _I],
+    "gather": [_PP, _I, _I, _I, _P],
+    "slab_load": [_PP, _PP, _PP, C.POINTER(PtParams)],
+    "slab_store": [_PP, _PP],
+    "pt_solve_slab": [_PP, _PP, _PP, C.POINTER(PtParams), _D, _I, _I, _D, _D, C.POINTER(_I), C.POINTER(_D), _I,
+                      C.POINTER(_I)],
+}
+
+
 def exported_symbols():
     """Every symbol include/ns3d.h declares."""
-    out = list(CONTEXT_SYMBOLS)
-    for n in SIGNATURES:
+    out = list(CONTEXT_SYMBOLS) + list(MGPU_SYMBOLS)
+    for n in list(SIGNATURES) + list(MGPU_SIGNATURES):
         out += ["ns3d_%s_f64" % n, "ns3d_%s_f32" % n]
     return out
 
@@ -104,6 +138,15 @@ def load():
     lib.ns3d_last_pt2_variant.argtypes = [_P]
     lib.ns3d_last_pt2_variant.restype = _I
     for name, args in SIGNATURES.items():
+        for suf in ("f64", "f32"):
+            fn = getattr(lib, "ns3d_%s_%s" % (name, suf))
+            fn.restype = _I
+            fn.argtypes = [_P] + args
+    for name, (res, args) in MGPU_SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    for name, args in MGPU_SIGNATURES.items():
         for suf in ("f64", "f32"):
             fn = getattr(lib, "ns3d_%s_%s" % (name, suf))
             fn.restype = _I

@@ -16,12 +16,13 @@ def _ceil_int(x):
     return int(math.ceil(x))
 
 
-def multi_params(nx, dims_z=1, coord_z=0):
+def multi_params(nx, dims_z=1, coord_z=0, ny=None, nz=None, ly_lx=0.6, lz_lx=0.6):
+    """ny, nz, ly_lx, lz_lx: explicit-shape overrides of the literals multi.jl:302-303 and the ceil(0.6 nx) rule
+    multi.jl:323-324 (defaults = the reference)."""
     p = SimpleNamespace()
     p.lx, p.rho, p.vin, p.mu = 1.0, 1000.0, 1.0, 0.001                     # :290-293
     p.psc = p.rho * (p.vin * p.vin)                                        # :296
     Fr = math.inf                                                          # :301
-    ly_lx, lz_lx = 0.6, 0.6                                                # :302-303
     a_lx, b_lx = 0.05, 0.05                                                # :304-305
     ox_lx, oy_lx = -0.4, 0.0                                               # :307-308
     beta = 0 * math.pi / 6                                                 # :309
@@ -32,8 +33,8 @@ def multi_params(nx, dims_z=1, coord_z=0):
     p.b2 = (b_lx * p.lx) * (b_lx * p.lx)                                   # :318
     p.sinb, p.cosb = math.sin(beta), math.cos(beta)                        # :319
     p.nx = int(nx)
-    p.ny = _ceil_int(nx * ly_lx)                                           # :323
-    p.nz = _ceil_int(nx * lz_lx)                                           # :324
+    p.ny = _ceil_int(nx * ly_lx) if ny is None else int(ny)                # :323
+    p.nz = _ceil_int(nx * lz_lx) if nz is None else int(nz)                # :324
     p.dims = (1, 1, int(dims_z))                                           # :325 (z-slabs only)
     p.coords = (0, 0, int(coord_z))
     p.nx_g, p.ny_g = p.nx, p.ny

@@ -28,13 +28,14 @@ def _ceil_int(x):
 # ------------------------------------------------------------------------------------------------
 # multi.jl
 # ------------------------------------------------------------------------------------------------
-def multi_params(nx, dims_z=1, dtype=np.float64):
-    """multi.jl:290-341 (local nx; ny,nz local; z decomposed over dims_z ranks)."""
+def multi_params(nx, dims_z=1, dtype=np.float64, ny=None, nz=None, ly_lx=0.6, lz_lx=0.6):
+    """multi.jl:290-341 (local nx; ny,nz local; z decomposed over dims_z ranks).  ny, nz, ly_lx, lz_lx override the
+    literals multi.jl:302-303,323-324 (defaults = the reference) for grids it cannot produce unedited."""
     p = Obj()
     p.lx, p.rho, p.vin, p.mu = 1.0, 1000.0, 1.0, 0.001           # :290-293
     p.psc = p.rho * (p.vin * p.vin)                             # :296
     Fr = math.inf                                                # :301
-    ly_lx, lz_lx, a_lx, b_lx, ox_lx, oy_lx = 0.6, 0.6, 0.05, 0.05, -0.4, 0.0   # :302-308
+    a_lx, b_lx, ox_lx, oy_lx = 0.05, 0.05, -0.4, 0.0            # :304-308 (ly_lx, lz_lx :302-303 are arguments)
     beta = 0 * math.pi / 6                                       # :309
     p.ly, p.lz = ly_lx * p.lx, lz_lx * p.lx                      # :312-313
     p.ox, p.oy = ox_lx * p.lx, oy_lx * p.lx                      # :314-315
@@ -42,8 +43,8 @@ def multi_params(nx, dims_z=1, dtype=np.float64):
     p.a2, p.b2 = (a_lx * p.lx) * (a_lx * p.lx), (b_lx * p.lx) * (b_lx * p.lx)   # :317-318
     p.sinb, p.cosb = math.sin(beta), math.cos(beta)              # :319
     p.nx = nx
-    p.ny = _ceil_int(nx * ly_lx)                                 # :323
-    p.nz = _ceil_int(nx * lz_lx)                                 # :324
+    p.ny = _ceil_int(nx * ly_lx) if ny is None else int(ny)      # :323
+    p.nz = _ceil_int(nx * lz_lx) if nz is None else int(nz)      # :324
     p.dims = (1, 1, dims_z)
     # ImplicitGlobalGrid: n_g = dims*(n-overlap)+overlap, overlap 2 [upstream]
     p.nx_g, p.ny_g, p.nz_g = p.nx, p.ny, dims_z * (p.nz - 2) + 2
@@ -115,10 +116,10 @@ def gather_z(ranks, name):
 
 
 def run_navierstokes3D_ref(nx=63, nt=1, dims_z=1, dtype=np.float64, faithful=True, niter_cap=None,
-                           record=None):
+                           record=None, shape=None):
     """multi.jl:287-536 without vis/save.  Returns (C_v,Pr_v,Vx_v,Vy_v,Vz_v, info) where info holds the
     per-step PT iteration counts and err histories, and the final local states."""
-    p = multi_params(nx, dims_z, dtype)
+    p = multi_params(nx, dims_z, dtype, **(shape or {}))
     nx, ny, nz = p.nx, p.ny, p.nz
     niter = p.niter if niter_cap is None else min(p.niter, niter_cap)
     P = dims_z

@@ -26,6 +26,31 @@ def test_bench_prints_one_json_line(extra):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert 0 < r["frac"] <= 1.0                                   # a physical fraction: bytes one launch must move
+    assert r["traffic_source"] in ("profiles lookup", "none") and (r["traffic"] is None) == (r["traffic_source"] == "none")
+    assert r["frac"] * (1 - 1e-9) <= r["effective_frac"] <= r["pt_iterations_per_launch"] * r["frac"] * (1 + 1e-9)
+    assert abs(d["hbm_gbps_algorithmic"] - r["effective_gbps"]) < 1e-6 * r["effective_gbps"]
     if "--no-cpu-baseline" not in extra:
         c = d["cpu_baseline"]
         assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+
+
+def test_bench_gpus_2_as_typed_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts two ranks (torch.distributed.run as a child,
+    before any GPU call) and relays rank 0's line.  On this one-GPU box the two ranks share the device, so the collective
+    transport choice is the host-staged one over gloo — and the line says so; the RCCL data plane needs the multi-GPU node."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "96", "--steps", "6", "--warmup", "2"]
+    out = subprocess.run(cmd, cwd=ROOT, check=True, capture_output=True, text=True, timeout=900, env=env).stdout
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["finite"] is True
+    assert d["config"]["global_grid"] == [96, 96, 2 * 94 + 2] and d["config"]["decomposition"] == "z-slabs x2"
+    assert "transport" in d["config"] and "rccl_ranks" in d["config"]
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert d["config"]["transport"].startswith("host-staged over gloo") and d["config"]["rccl_ranks"] == 0
+    else:
+        assert d["config"]["transport"].startswith("RCCL") and d["config"]["rccl_ranks"] == 2
+    assert 0 < d["roofline"]["frac"] <= 1.0 and "cpu_baseline" not in d

@@ -1,0 +1,224 @@
+"""The multi-GPU half of the C ABI (ns3d_mgpu_*, include/ns3d.h) on the one GPU of the test box: ONE process drives P
+virtual z-slab ranks that all sit on device 0 — the same schedule, events and peer copies that run across xGMI on a
+multi-GPU node — and everything is compared with the oracle's virtual ranks (oracle/driver_ref.py: a literal restatement
+of ImplicitGlobalGrid's update_halo!/gather!) or with the single-device solve of the global grid, bit for bit.
+The one-process-per-GPU form is exercised as far as one GPU allows: an RCCL communicator of ONE rank (dlopen, unique id,
+ncclCommInitRank, ncclAllReduce inside the residual check and max_g)."""
+import math
+
+import numpy as np
+import pytest
+
+from util import fields, geometry
+
+pytestmark = pytest.mark.gpu
+
+
+def _mg(P, nx, ny, nz, mode="strict"):
+    from navierstokes3d_amd.mgpu import MultiGpu
+    return MultiGpu.create([0] * P, nx, ny, nz, mode)
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_update_halo_follows_implicit_global_grid(hip, P):
+    """update_halo! (multi.jl:371…477) for every stagger: cell-centred (overlap 2), Vz (overlap 3), Vx/Vy (x/y staggered,
+    overlap 2), and the arrays without a z halo (τxy (n-1)³, dPrdτ (n-2)³) that must come back untouched."""
+    from oracle.driver_ref import update_halo_z
+    nx, ny, nz = 13, 9, 7
+    kinds = ["c", "vx", "vy", "vz", "s", "i"]
+    host = [dict(zip(kinds, fields(nx, ny, nz, kinds, 100 * (r + 1)))) for r in range(P)]
+    mg = _mg(P, nx, ny, nz)
+    assert mg.transport == "peer" and mg.P == P and mg.nlocal == P and mg.ranks == list(range(P)) and mg.nz_g() == P * (nz - 2) + 2
+    dev = {k: [hip.from_numpy(h[k]) for h in host] for k in kinds}
+    mg.update_halo(*[dev[k] for k in kinds])
+    mg.sync()
+    for k in kinds:
+        update_halo_z(host, k, nz)
+        for r in range(P):
+            assert np.array_equal(hip.to_numpy(dev[k][r]), host[r][k]), (k, r)
+    # f32 goes through the same code with 4-byte elements
+    h32 = [dict(c=fields(nx, ny, nz, ["c"], 7 + r, np.float32)[0]) for r in range(P)]
+    d32 = [hip.from_numpy(h["c"]) for h in h32]
+    mg.update_halo(d32)
+    mg.sync()
+    update_halo_z(h32, "c", nz)
+    for r in range(P):
+        assert np.array_equal(hip.to_numpy(d32[r]), h32[r]["c"])
+    mg.close()
+
+
+def test_max_g_and_gather(hip):
+    from oracle.driver_ref import gather_z
+    P, nx, ny, nz = 3, 11, 8, 6
+    mg = _mg(P, nx, ny, nz)
+    assert mg.max_g([1.5, -3.0, 2.25]) == 2.25
+    assert mg.max_g([-7.0, -3.0, -4.0]) == -3.0
+    assert math.isnan(mg.max_g([1.0, float("nan"), 5.0]))                     # Julia's maximum propagates NaN (App. B7)
+    assert mg.max_g([1.0, float("inf"), 5.0]) == float("inf")
+    for kind in ("c", "vx", "vz"):
+        host = [dict(a=fields(nx, ny, nz, [kind], 31 * (r + 1))[0]) for r in range(P)]
+        got = mg.gather([hip.from_numpy(h["a"]) for h in host])
+        assert np.array_equal(got, gather_z(host, "a")) and got.flags.f_contiguous
+    mg.close()
+
+
+def _global_solve(hip, Pg, Dg, Rg, g, n_iters, bc, dtype):
+    import torch
+    ctx = hip.Context(0, "strict")
+    dP, dD = hip.from_numpy(Pg), hip.from_numpy(Dg)
+    p = hip.pt_params(dP, g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, *bc)
+    hip.pt_iterate(dP, dD, hip.from_numpy(Rg), p, n_iters, ctx=ctx)
+    torch.cuda.synchronize()
+    out = hip.to_numpy(dP), hip.to_numpy(dD)
+    ctx.close()
+    return out
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("P,depth,shape,n_iters", [(2, 2, (40, 21, 10), 7), (3, 2, (70, 12, 6), 5), (3, 1, (24, 15, 9), 4),
+                                                   (2, 2, (200, 160, 66), 7), (4, 2, (33, 9, 4), 6)])
+def test_slab_state_equals_global_solve(hip, P, depth, shape, n_iters, dtype):
+    """Decomposition independence of the C++ deep-ghost schedule (ns3d_slab_load / iterate / store): P virtual ranks leave
+    exactly the planes of the single-device solve of the global grid — every local plane, halo planes included; odd
+    iteration counts mix two-iteration and single passes; the 4-plane slabs have seams that touch each other."""
+    nx, ny, nz = shape
+    nz_g = P * (nz - 2) + 2
+    g = geometry(nx, ny, nz_g)
+    Pg, Dg, Rg = fields(nx, ny, nz_g, ["c", "i", "c"], 211, dtype)
+    bc = (True, 0.25, 0.0)
+    Pref, Dref = _global_solve(hip, Pg, Dg, Rg, g, n_iters, bc, dtype)
+    mg = _mg(P, nx, ny, nz)
+    mg.set_temporal(depth)
+    Pr = [hip.from_numpy(Pg[:, :, r * (nz - 2):r * (nz - 2) + nz]) for r in range(P)]
+    D = [hip.from_numpy(Dg[:, :, r * (nz - 2):r * (nz - 2) + nz - 2]) for r in range(P)]
+    R = [hip.from_numpy(Rg[:, :, r * (nz - 2):r * (nz - 2) + nz]) for r in range(P)]
+    p = hip.pt_params(Pr[0], g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, *bc)
+    mg.slab_load(Pr, D, R, p)
+    mg.slab_plan()
+    mg.slab_iterate(n_iters)
+    res = mg.slab_residual()
+    mg.slab_store(Pr, D)
+    mg.sync()
+    for r in range(P):
+        lo = r * (nz - 2)
+        assert np.array_equal(hip.to_numpy(Pr[r]), Pref[:, :, lo:lo + nz]), "Pr of rank %d" % r
+        assert np.array_equal(hip.to_numpy(D[r]), Dref[:, :, lo:lo + nz - 2]), "dPrdτ of rank %d" % r
+    ctx = hip.Context(0, "strict")
+    pg = hip.pt_params(hip.from_numpy(Pref), g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, *bc)
+    assert res == hip.residual_max(hip.from_numpy(Pref), hip.from_numpy(Rg), pg, ctx=ctx)    # max_g of the slab residuals
+    ctx.close()
+    mg.close()
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_pt_solve_slab_equals_global_pt_solve(hip, oracle, P):
+    """ns3d_pt_solve_slab = the whole inner loop multi.jl:458-471 over the ranks: same iteration count, same error history
+    and same fields as ns3d_pt_solve on the global grid (and hence as the oracle's unfused loop)."""
+    import torch
+    nx, ny, nz = 34, 20, 9
+    nz_g = P * (nz - 2) + 2
+    g = geometry(nx, ny, nz_g)
+    Pg, Dg, Rg = fields(nx, ny, nz_g, ["c", "i", "c"], 77)
+    Pg *= 1e-3; Dg *= 1e-3; Rg *= 1e-6
+    eps, niter, nchk, mul, div = 1.0e-4, 400, 19, 0.36, 1000.0
+    ctx = hip.Context(0, "strict")
+    dP, dD = hip.from_numpy(Pg), hip.from_numpy(Dg)
+    pg = hip.pt_params(dP, g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, True, 0.0, 0.0)
+    it_ref, errs_ref = hip.pt_solve(dP, dD, hip.from_numpy(Rg), pg, eps, niter, nchk, mul, div, ctx=ctx)
+    torch.cuda.synchronize()
+    Pref, Dref = hip.to_numpy(dP), hip.to_numpy(dD)
+    ctx.close()
+    assert nchk < it_ref < niter and len(errs_ref) == it_ref // nchk          # a real early exit
+    mg = _mg(P, nx, ny, nz)
+    Pr = [hip.from_numpy(Pg[:, :, r * (nz - 2):r * (nz - 2) + nz]) for r in range(P)]
+    D = [hip.from_numpy(Dg[:, :, r * (nz - 2):r * (nz - 2) + nz - 2]) for r in range(P)]
+    R = [hip.from_numpy(Rg[:, :, r * (nz - 2):r * (nz - 2) + nz]) for r in range(P)]
+    p = hip.pt_params(Pr[0], g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, True, 0.0, 0.0)
+    it, errs = mg.pt_solve_slab(Pr, D, R, p, eps, niter, nchk, mul, div)
+    mg.sync()
+    assert it == it_ref and errs == errs_ref
+    for r in range(P):
+        lo = r * (nz - 2)
+        assert np.array_equal(hip.to_numpy(Pr[r]), Pref[:, :, lo:lo + nz])
+        assert np.array_equal(hip.to_numpy(D[r]), Dref[:, :, lo:lo + nz - 2])
+    # NaN in one rank's right-hand side breaks the loop at the first check on every rank (multi.jl:469)
+    Rbad = [hip.clone(t) for t in R]
+    Rbad[P - 1][3, 4, 4] = float("nan")
+    it, errs = mg.pt_solve_slab(Pr, D, Rbad, p, eps, niter, nchk, mul, div)
+    assert it == nchk and len(errs) == 1 and math.isnan(errs[0])
+    mg.close()
+
+
+@pytest.mark.parametrize("P,fused,temporal", [(2, True, True), (3, True, True), (2, True, False), (2, False, False)])
+def test_driver_on_mgpu_grid_vs_oracle_virtual_ranks(hip, P, fused, temporal):
+    """The product driver (multi.jl:287-536) on the C-ABI grid — update_halo!, max_g, gather!, and the inner loop as
+    ns3d_pt_solve_slab (fused) or as the literal per-kernel sequence — against the oracle's P virtual ranks: iteration
+    counts, every local field and the gathered return arrays, bit for bit."""
+    from navierstokes3d_amd.driver import run_navierstokes3D
+    from navierstokes3d_amd.mgpu import MgpuGrid, MultiGpu
+    from navierstokes3d_amd.params import multi_params
+    from oracle.driver_ref import run_navierstokes3D_ref
+    nx, nt = 32, 2
+    p0 = multi_params(nx)
+    mg = MultiGpu.create([0] * P, p0.nx, p0.ny, p0.nz, "strict")
+    out = run_navierstokes3D(nx=nx, nt=nt, mode="strict", fused=fused, temporal=temporal,
+                             grid=MgpuGrid(mg, p0.nx, p0.ny, p0.nz), return_info=True)
+    info = out[-1]
+    ref = run_navierstokes3D_ref(nx=nx, nt=nt, dims_z=P)
+    assert info.iters == ref[-1].iters and info.errs == ref[-1].errs
+    for r in range(P):
+        for n in ("C", "Pr", "Vx", "Vy", "Vz", "divV", "dPrdtau"):
+            assert np.array_equal(hip.to_numpy(getattr(info.local_fields[r], n)), ref[-1].ranks[r][n], equal_nan=True), (r, n)
+    for n, a, b in zip(("C", "Pr", "Vx", "Vy", "Vz"), out[:5], ref[:5]):
+        assert np.array_equal(a, b, equal_nan=True), n
+    mg.close()
+
+
+def test_rccl_communicator_of_one_rank(hip):
+    """The one-process-per-GPU form as far as one GPU goes: RCCL is found by dlopen, a unique id is made, a communicator
+    of one rank comes up, and the residual check / max_g run their ncclAllReduce on it; results equal the single-device
+    calls.  (Send/recv between ranks needs a second GPU: bench.py --gpus N probes and reports that on the multi-GPU node.)"""
+    import torch
+    from navierstokes3d_amd.mgpu import MultiGpu
+    nx, ny, nz = 40, 21, 12
+    uid = MultiGpu.unique_id()
+    assert len(uid) == 128 and any(uid)
+    mg = MultiGpu.create_rank(1, 0, 0, uid, nx, ny, nz, "strict")
+    assert mg.transport == "rccl" and mg.rccl_ranks() == 1 and mg.nlocal == 1 and mg.ranks == [0]
+    assert mg.max_g([-2.5]) == -2.5 and math.isnan(mg.max_g([float("nan")]))
+    g = geometry(nx, ny, nz)
+    Pg, Dg, Rg = fields(nx, ny, nz, ["c", "i", "c"], 5)
+    Pref, Dref = _global_solve(hip, Pg, Dg, Rg, g, 6, (True, 0.25, 0.0), np.float64)
+    Pr, D, R = hip.from_numpy(Pg), hip.from_numpy(Dg), hip.from_numpy(Rg)
+    p = hip.pt_params(Pr, g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, True, 0.25, 0.0)
+    mg.update_halo(Pr)                       # one rank: nothing to exchange, must not touch the field
+    mg.slab_load(Pr, D, R, p)
+    mg.slab_iterate(6)
+    res = mg.slab_residual()
+    mg.slab_store(Pr, D)
+    mg.sync()
+    assert np.array_equal(hip.to_numpy(Pr), Pref) and np.array_equal(hip.to_numpy(D), Dref)
+    ctx = hip.Context(0, "strict")
+    assert res == hip.residual_max(Pr, R, p, ctx=ctx)
+    got = mg.gather(Pr)
+    assert np.array_equal(got, Pref[1:-1, 1:-1, 1:-1])
+    ctx.close()
+    mg.close()
+    torch.cuda.synchronize()
+
+
+def test_mgpu_argument_errors(hip):
+    from navierstokes3d_amd import lib as L
+    from navierstokes3d_amd.mgpu import MultiGpu
+    with pytest.raises(L.Ns3dError):
+        MultiGpu.create([0, 0], 8, 8, 2)                      # grid too small
+    with pytest.raises(L.Ns3dError):
+        MultiGpu.create([0, 99], 8, 8, 8)                     # no such device
+    mg = _mg(2, 12, 8, 6)
+    with pytest.raises(L.Ns3dError):
+        mg.slab_iterate(2)                                    # nothing loaded
+    with pytest.raises(L.Ns3dError):
+        mg.set_temporal(5)
+    with pytest.raises(L.Ns3dError):
+        mg.update_halo([hip.zeros((12, 8, 6))])               # one tensor for two local ranks
+    mg.close()

@@ -361,9 +361,9 @@ def test_pt_exact_division_guard_extreme_values(hip, oracle, dtype, bc, mode):
 
 
 def test_pt2_first_use_tuning(hip, oracle):
-    """ns3d_set_autotune (default on): the first automatic two-iteration launch on a grid of >= 1.5 M cells times the tile
-    shapes on the caller's arguments; the result is the oracle's, the choice is remembered, and turning the tuner off
-    returns to the built-in choice."""
+    """ns3d_set_autotune (default on): ns3d_plan_pt — and the first ns3d_pt_iterate / ns3d_pt_solve — on a grid of >= 1.5 M
+    cells time the tile shapes on the caller's arguments; the result is the oracle's, the choice is remembered (ns3d_pt_sweep2
+    itself never measures, it looks the choice up), and turning the tuner off returns to the built-in choice."""
     import torch
     nx, ny, nz = 200, 164, 130
     g = geometry(nx, ny, nz)
@@ -376,6 +376,12 @@ def test_pt2_first_use_tuning(hip, oracle):
     for rep in range(3):
         dPr, dout, dd = hip.from_numpy(Pr0), hip.from_numpy(np.full_like(Pr0, 555.0)), hip.from_numpy(d0)
         ddout = hip.from_numpy(np.full_like(d0, 444.0))
+        if rep == 0:                                           # before any plan: the built-in choice, no measurement
+            hip.pt_sweep2(dPr, dout, dd, ddout, hip.from_numpy(rhs), p, ctx=ctx)
+            torch.cuda.synchronize()
+            assert ctx.last_pt2_variant() == 0
+            assert np.array_equal(hip.to_numpy(dout), Pr) and np.array_equal(hip.to_numpy(ddout), d)
+            hip.plan_pt(dPr, dout, dd, ddout, hip.from_numpy(rhs), p, ctx=ctx)
         hip.pt_sweep2(dPr, dout, dd, ddout, hip.from_numpy(rhs), p, ctx=ctx)
         torch.cuda.synchronize()
         seen.append(ctx.last_pt2_variant())
@@ -397,15 +403,13 @@ def test_pt2_first_use_tuning(hip, oracle):
     ctx.close()
 
 
-@pytest.mark.parametrize("dtype", ["f64", "f32"])
-def test_full_size_512_cubed_properties(hip, oracle, dtype):
-    """BASELINE.json configs[2] at its full size (512³, 134 M cells), where the oracle cannot sweep the whole grid in test
-    time: (a) the automatically chosen two-iteration kernel, two launches of the one-thread-per-cell sweep and two of the
-    z-marching sweep give the same bits on the whole grid (three independent kernels; compared on the device);
-    (b) locality — two iterations on planes [a+2, b-2) depend only on planes [a, b) — lets the oracle check a 30-plane
-    sub-slab cut out of the middle, x/y faces and outlet plane included, bit for bit."""
+def _full_size_properties(hip, oracle, n, dtype):
+    """A full-size BASELINE grid (n³ cells), where the oracle cannot sweep the whole grid in test time: (a) the planned
+    two-iteration kernel (ns3d_plan_pt times the tile shapes on these very arguments), two launches of the
+    one-thread-per-cell sweep and two of the z-marching sweep give the same bits on the whole grid (three independent kernels;
+    compared on the device); (b) locality — two iterations on planes [a+2, b-2) depend only on planes [a, b) — lets the oracle
+    check a 30-plane sub-slab cut out of the middle, x/y faces and outlet plane included, bit for bit."""
     import torch
-    n = 512
     g = geometry(n, n, n)
     gen = torch.Generator(device="cuda"); gen.manual_seed(20240512)
     tdt, bits = (torch.float64, torch.int64) if dtype == "f64" else (torch.float32, torch.int32)
@@ -419,32 +423,39 @@ def test_full_size_512_cubed_properties(hip, oracle, dtype):
     P0, D0, R = rnd_dev(n, n, n), rnd_dev(n - 2, n - 2, n - 2), rnd_dev(n, n, n)
     ctx = hip.Context(0, "strict")
     p = _params(hip, P0, g, 0, True, 0.75)
-    # (a1) the two-iteration kernel, automatic choice (first use: the tile shapes are timed on these very arguments)
+    # (a1) the two-iteration kernel: plan (times the tile shapes, keeps the winner), then the launch proper
     Pa, Da = zeros((n, n, n)), zeros((n - 2, n - 2, n - 2))
+    hip.plan_pt(P0, Pa, D0, Da, R, p, ctx=ctx)
+    Pa.zero_(); Da.zero_()
     hip.pt_sweep2(P0, Pa, D0, Da, R, p, ctx=ctx)
     # (a2/a3) two single sweeps, two different kernel families
-    results = []
     for variant in (100, 2200):
         ctx.set_pt_variant(variant)
         Pb, Pc, Db = zeros((n, n, n)), zeros((n, n, n)), hip.clone(D0)
         hip.pt_sweep(P0, Pb, Db, R, p, 1, n - 1, ctx=ctx)
         hip.pt_sweep(Pb, Pc, Db, R, p, 1, n - 1, ctx=ctx)
-        results.append((Pc, Db))
-        del Pb
-    torch.cuda.synchronize()
-    for Pc, Db in results:
-        assert torch.equal(Pa.view(bits), Pc.view(bits)), "Pr differs between kernels at 512^3"
-        assert torch.equal(Da.view(bits), Db.view(bits)), "dPrdτ differs between kernels at 512^3"
-    del results
-    # (b) oracle on the sub-slab of planes [a, b)
-    a, b = 240, 270
-    Ps = np.asfortranarray(hip.to_numpy(P0)[:, :, a:b])
-    Ds = np.asfortranarray(hip.to_numpy(D0)[:, :, a:b - 2])
-    Rs = np.asfortranarray(hip.to_numpy(R)[:, :, a:b])
-    gs = dict(g)
-    _oracle_iters(oracle, Ps, Ds, Rs, gs, 2, 0, True, 0.75)
-    got_P = hip.to_numpy(Pa)[:, :, a + 2:b - 2]
-    got_D = hip.to_numpy(Da)[:, :, a + 1:b - 3]          # dPrdτ index = plane − 1
-    assert np.array_equal(got_P, Ps[:, :, 2:-2])
-    assert np.array_equal(got_D, Ds[:, :, 1:-1])
+        torch.cuda.synchronize()
+        assert torch.equal(Pa.view(bits), Pc.view(bits)), "Pr differs between kernels at %d^3" % n
+        assert torch.equal(Da.view(bits), Db.view(bits)), "dPrdτ differs between kernels at %d^3" % n
+        del Pb, Pc, Db
+    # (b) oracle on the sub-slab of planes [a, b) (sliced on the device: only the sub-slab crosses PCIe)
+    a, b = n // 2 - 16, n // 2 + 14
+    Ps = hip.to_numpy(P0[:, :, a:b])
+    Ds = hip.to_numpy(D0[:, :, a:b - 2])
+    Rs = hip.to_numpy(R[:, :, a:b])
+    _oracle_iters(oracle, Ps, Ds, Rs, dict(g), 2, 0, True, 0.75)
+    assert np.array_equal(hip.to_numpy(Pa[:, :, a + 2:b - 2]), Ps[:, :, 2:-2])
+    assert np.array_equal(hip.to_numpy(Da[:, :, a + 1:b - 3]), Ds[:, :, 1:-1])          # dPrdτ index = plane − 1
     ctx.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_full_size_512_cubed_properties(hip, oracle, dtype):
+    """BASELINE.json configs[2] at its full size (512³, 134 M cells)."""
+    _full_size_properties(hip, oracle, 512, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_full_size_1024_cubed_properties(hip, oracle, dtype):
+    """BASELINE.json configs[4]'s one-GPU point (1024³, 1.07 G cells, fp64 and fp32): 8.6 / 4.3 GB per array."""
+    _full_size_properties(hip, oracle, 1024, dtype)
