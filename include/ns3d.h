@@ -88,6 +88,11 @@ int ns3d_set_pt2_variant(ns3d_ctx *ctx, int variant);
  * every shape gives the same bits) and the process remembers the winner per device and grid; that first call therefore
  * synchronises the stream.  Off: a built-in choice by grid size.  ns3d_last_pt2_variant: the variant of the latest two-iteration launch
  * (0 = built-in choice). */
+/* N-iteration sweep (ns3d_pt_sweepn): variant = shape*100 + kz; shapes 1: 64×32 columns per workgroup, 2: 128×16,
+ * 3: 256×8, 4: 64×48, 5: 128×24, +10: next step's loads issued before level 1; kz as above.  0 = built-in. */
+int ns3d_set_ptn_variant(ns3d_ctx *ctx, int variant);
+/* PT iterations per pass over memory in ns3d_pt_iterate / ns3d_pt_solve: 0 = automatic, 1…4 forced (same results). */
+int ns3d_set_pt_depth(ns3d_ctx *ctx, int depth);
 int ns3d_set_autotune(ns3d_ctx *ctx, int on);
 int ns3d_last_pt2_variant(const ns3d_ctx *ctx);
 /* ns3d_pt_solve replays each residual-check block (nchk iterations) as one HIP graph: -1 = automatically on
@@ -185,6 +190,10 @@ typedef struct ns3d_pt_params {
      * swap, for the output planes k0 ≤ k < k1 (reads planes k0-2 … k1+1 of Pr_in).  z_*_is_halo must be 0:   \
      * z-slab ranks run it on buffers extended by a second ghost plane per seam. */              \
     int ns3d_pt_sweep2_##S(ns3d_ctx *, const T *Pr_in, T *Pr_out, const T *dPrdtau_in, T *dPrdtau_out,       \
+                           const T *divV, const ns3d_pt_params *p, int k0, int k1);                          \
+    /* nlev (2…4) fused PT iterations in one pass over memory, otherwise as ns3d_pt_sweep2: results identical to nlev   \
+     * ns3d_pt_sweep calls, output planes k0 ≤ k < k1 (reads planes k0-nlev … k1+nlev-1 of Pr_in, clamped to the grid). */ \
+    int ns3d_pt_sweepn_##S(ns3d_ctx *, int nlev, const T *Pr_in, T *Pr_out, const T *dPrdtau_in, T *dPrdtau_out,  \
                            const T *divV, const ns3d_pt_params *p, int k0, int k1);                          \
     /* Plan phase of the two-iteration sweep (ns3d_set_autotune): times the tile shapes NOW on these very arguments  \
      * (idempotent: inputs and outputs are distinct buffers; every shape gives the same bits) and remembers the       \

@@ -33,10 +33,10 @@ static std::mutex g_tuned_mutex;
 // launch + (unless NS3D_ASYNC) block like `@parallel` does
 static int finish(ns3d_ctx *ctx, hipError_t e, const char *what)
 {
-    if (e != hipSuccess) return fail(NS3D_ERR_HIP, "%s launch: %s", what, hipGetErrorString(e));
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(NS3D_ERR_HIP, "%s launch: %s", what, hipGetErrorString(e)); }
     if (!(ctx->flags & NS3D_ASYNC)) {
         e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) return fail(NS3D_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(NS3D_ERR_HIP, "%s: %s", what, hipGetErrorString(e)); }
     }
     return NS3D_OK;
 }
@@ -75,6 +75,7 @@ ns3d_ctx *ns3d_create(int device, int flags)
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
         fail(NS3D_ERR_HIP, "ns3d_create: no HIP device (%s) — libns3d has no CPU path", hipGetErrorString(e));
         return nullptr;
     }
@@ -99,6 +100,10 @@ ns3d_ctx *ns3d_create(int device, int flags)
     c->pt_variant = 0;
     c->pt2_variant = 0; // temporal blocking on by default (ns3d_set_pt2_variant(ctx,-1) turns it off)
     if (const char *ev = std::getenv("NS3D_PT2_VARIANT")) c->pt2_variant = std::atoi(ev);   // experiments without an API call
+    c->ptn_variant = 0;
+    if (const char *ev = std::getenv("NS3D_PTN_VARIANT")) c->ptn_variant = std::atoi(ev);
+    c->pt_depth = 0;
+    if (const char *ev = std::getenv("NS3D_PT_DEPTH")) c->pt_depth = std::atoi(ev);
     c->autotune = 1;
     c->last_pt2 = 0;
     c->tune_ev[0] = c->tune_ev[1] = nullptr;
@@ -182,6 +187,22 @@ int ns3d_set_autotune(ns3d_ctx *c, int on)
 }
 
 int ns3d_last_pt2_variant(const ns3d_ctx *c) { return c ? c->last_pt2 : -1; }
+
+int ns3d_set_ptn_variant(ns3d_ctx *c, int v)
+{
+    if (!c) return fail(NS3D_ERR_ARG, "ns3d_set_ptn_variant: null context");
+    if (v < 0 || v >= 10000) return fail(NS3D_ERR_ARG, "ns3d_set_ptn_variant: unknown variant %d", v);
+    c->ptn_variant = v;
+    return NS3D_OK;
+}
+
+int ns3d_set_pt_depth(ns3d_ctx *c, int depth)
+{
+    if (!c) return fail(NS3D_ERR_ARG, "ns3d_set_pt_depth: null context");
+    if (depth < 0 || depth > 4) return fail(NS3D_ERR_ARG, "ns3d_set_pt_depth: depth %d (0 = automatic, 1…4)", depth);
+    c->pt_depth = depth;
+    return NS3D_OK;
+}
 
 int ns3d_set_pt2_variant(ns3d_ctx *c, int v)
 {
@@ -771,6 +792,25 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
         if (k0 < 1 || k1 > p->nz - 1 || k0 > k1)                                                             \
             return fail(NS3D_ERR_ARG, "ns3d_pt_sweep2: plane range [%d,%d) outside [1,%d)", k0, k1, p->nz - 1); \
         return finish(c, launch_pt2<T>(c, c->stream, Pr_in, Pr_out, dPrdtau, dPrdtau_out, divV, p, k0, k1, false), "pt_sweep2"); \
+    }                                                                                                        \
+    extern "C" int ns3d_pt_sweepn_##S(ns3d_ctx *c, int nlev, const T *Pr_in, T *Pr_out, const T *dPrdtau,  \
+                                      T *dPrdtau_out, const T *divV, const ns3d_pt_params *p, int k0, int k1)\
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(Pr_in, Pr_out, dPrdtau, dPrdtau_out, divV);                                 \
+        int rc = ns3d_check_pt_params(p, "ns3d_pt_sweepn");                                                  \
+        if (rc) return rc;                                                                                   \
+        if (nlev < 2 || nlev > 4) return fail(NS3D_ERR_ARG, "ns3d_pt_sweepn: %d levels (2…4)", nlev);        \
+        if (Pr_in == Pr_out || dPrdtau == dPrdtau_out)                                                       \
+            return fail(NS3D_ERR_ARG, "ns3d_pt_sweepn: input and output buffers must differ");               \
+        if (p->z_lo_is_halo || p->z_hi_is_halo)                                                              \
+            return fail(NS3D_ERR_ARG, "ns3d_pt_sweepn: z-slab ranks pass ghost-extended buffers, not halo flags"); \
+        if (k0 < 1 || k1 > p->nz - 1 || k0 > k1)                                                             \
+            return fail(NS3D_ERR_ARG, "ns3d_pt_sweepn: plane range [%d,%d) outside [1,%d)", k0, k1, p->nz - 1); \
+        hipError_t e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_sweepn<T>(c->stream, nlev, c->ptn_variant, Pr_in, Pr_out, \
+                                                                     dPrdtau, dPrdtau_out, divV, *p, k0, k1)); \
+        if (e == hipErrorInvalidValue)                                                                       \
+            return fail(NS3D_ERR_ARG, "ns3d_pt_sweepn: tile variant %d cannot run %d levels", c->ptn_variant, nlev); \
+        return finish(c, e, "pt_sweepn");                                                                    \
     }                                                                                                        \
     extern "C" int ns3d_plan_pt_##S(ns3d_ctx *c, const T *Pr_in, T *Pr_out, const T *dPrdtau, T *dPrdtau_out, \
                                     const T *divV, const ns3d_pt_params *p, int k0, int k1)                  \

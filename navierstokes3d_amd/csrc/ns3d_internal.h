@@ -23,6 +23,8 @@ struct ns3d_ctx {
     size_t pingpong_d_bytes;
     int pt_variant;
     int pt2_variant; // tile shape of the two-iteration sweep; <0: temporal blocking off
+    int ptn_variant; // tile shape of the N-iteration sweep (k_pt_sweepN); 0: built-in
+    int pt_depth;    // PT iterations per pass in pt_iterate / pt_solve: 0 automatic, 1…4 forced
     int graph_mode;  // HIP-graph replay of residual-check blocks: -1 auto (launch-bound grids), 0 off, 1 on
     int autotune;    // time the tile shapes of the two-iteration sweep on first use of a grid (pt2_variant == 0 only)
     int last_pt2;    // variant of the latest two-iteration launch (0: built-in choice by grid)
@@ -52,8 +54,10 @@ struct ns3d_device_guard {
     explicit ns3d_device_guard(int device)
     {
         if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
-        if (prev != device) err = hipSetDevice(device);
-        else prev = -1;                      // nothing to restore
+        if (prev != device) {
+            err = hipSetDevice(device);
+            if (err != hipSuccess) { (void)hipGetLastError(); prev = -1; }   // leave no sticky error behind for the host framework
+        } else prev = -1;                    // nothing to restore
     }
     ~ns3d_device_guard()
     {
@@ -66,7 +70,10 @@ struct ns3d_device_guard {
 #define HIPCHK(ctx, expr)                                                                                   \
     do {                                                                                                    \
         hipError_t e_ = (expr);                                                                             \
-        if (e_ != hipSuccess) return fail(NS3D_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));            \
+        if (e_ != hipSuccess) {                                                                             \
+            (void)hipGetLastError(); /* reported through our status: leave no sticky error for the host framework */ \
+            return fail(NS3D_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));                              \
+        }                                                                                                   \
     } while (0)
 
 #define CHECK_CTX(ctx)                                                                                      \

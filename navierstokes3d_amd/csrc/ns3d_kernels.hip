@@ -348,6 +348,16 @@ __device__ __forceinline__ bool val_ok(T) { return true; }
 #define NS3D_HAS_SLOW_PATH 0
 #endif
 
+template <class T>
+__device__ __forceinline__ void bad_or(bool &bad, T v)
+{
+#if NS3D_HAS_SLOW_PATH
+    bad |= !val_ok<T>(v);
+#else
+    (void)bad; (void)v;
+#endif
+}
+
 // Drop-in, signature-preserving (unfused) PT kernels: one thread per interior cell.
 template <class T, int MODE> // MODE 0: update_dPrdτ!   1: compute_res!
 __global__ __launch_bounds__(256) void k_pt_unfused(const T *__restrict__ Pr, T *__restrict__ out,
@@ -1498,6 +1508,374 @@ static hipError_t launch_sweep2(hipStream_t s, SweepArgs<T> &a, int kz)
     return e;
 }
 
+// =========================================================================================================
+// NL PT iterations per pass over memory  —  k_pt_sweepN  (NL = 3, 4; NL = 2 is kept for cross-checks against k_pt_sweep2)
+//
+// A two-iteration pass already sits at the HBM ceiling of its 3-read/2-write traffic mix: the only way
+// up is fewer bytes per ITERATION.  NL chained Jacobi sweeps
+//     level ℓ:  dˡ = dˡ⁻¹(1−damp) + dτ(∇²Pˡ⁻¹ − ρ/dt ∇V),   Pˡ = Pˡ⁻¹ + dτ dˡ        ℓ = 1 … NL
+// read P⁰, d⁰, ∇V and write only d^NL, P^NL: ≈40 B per cell per NL iterations.  Same structure as k_pt_sweep2, one z-march
+// with every level one plane behind the previous one: at step s level ℓ works on plane kℓ = k1 − (ℓ−1), k1 = kb−(NL−1)+s.
+//   registers (per column): P⁰[k1−1..k1+1]; for ℓ = 1…NL−1: Pˡ[kℓ₊₁−1], Pˡ[kℓ₊₁], dˡ[kℓ₊₁]; ∇V[k1 … k_NL]; d⁰[k1]
+//   LDS (double-buffered):  plane k1 of P⁰ with its halo ring; plane kℓ₊₁ of Pˡ for ℓ = 1…NL−1   (x/y neighbours)
+//   one __syncthreads() per step.
+// Level ℓ is exact on the columns at least ℓ−1 away from the tile edge (or next to a domain face, where the boundary rule
+// is substituted as in k_pt_sweep2); tiles therefore overlap by 2(NL−1) columns/rows and z-chunks by 2(NL−1) planes.  Every
+// value is computed with exactly the arithmetic of the single sweep: bit-identical to NL k_pt_sweep launches.
+// Boundary cells of P^NL: the x-face cell beside an interior cell is stored here, y/z faces by k_pt_faces_* (SEPF form).
+// =========================================================================================================
+template <class T, int NL, int WX, int WY, int CPT, bool EARLY, int MINW = 1>
+__global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a, int ntx, int nty)
+{
+    static_assert(NL >= 2 && NL <= 4, "levels");
+    constexpr int TX = 64 * WX, TY = CPT * WY, PX = TX + 2, OV = 2 * (NL - 1);
+    static_assert(TX > OV + 2 && TY > OV + 2, "tile too small for this many levels");
+    __shared__ T L0[2][(TY + 2) * PX];       // P⁰ plane with halo ring: element (lx+1, lr+1)
+    __shared__ T LN[NL - 1][2][TY * TX];     // planes of P¹ … P^{NL−1}
+#if NS3D_HAS_SLOW_PATH
+    __shared__ int Lbad;                     // sticky: a value outside the exact-reciprocal range entered this tile (see k_pt_sweep2)
+#endif
+    const int nx = a.nx, ny = a.ny, nz = a.nz;
+    const Geo<T> &g = a.g;
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int q = nb >> 3, rem = nb & 7, xcd = b & 7, loc = b >> 3;
+    const int tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
+    const int tx_t = tile % ntx, ty_t = (tile / ntx) % nty, tz_t = tile / (ntx * nty);
+    const int ox = 1 + tx_t * (TX - OV), oy = 1 + ty_t * (TY - OV);
+    const int kb = a.k0 + tz_t * a.kz;
+    const int ke = min(kb + a.kz, a.k1);
+    if (kb >= ke) return; // workgroup-uniform, before any barrier
+
+    const int lx = threadIdx.x, wy = threadIdx.y;
+    const int tid = wy * TX + lx;
+    const int gi = ox + lx;
+    const int ci = min(gi, nx - 1), cii = min(gi, nx - 2);
+    const idx_t sz = (idx_t)nx * ny;
+    const idx_t dsz = (idx_t)(nx - 2) * (ny - 2);
+    const bool xlo_adj = (gi == 1), xhi_adj = (gi == nx - 2);
+    // does this tile touch an x or y face of the domain at all?  (scalar: same for the whole workgroup)
+    const bool tile_x_lo = (ox <= 1), tile_x_hi = (ox + TX - 1 >= nx - 2);
+    const bool tile_y_lo = (oy <= 1), tile_y_hi = (oy + TY - 1 >= ny - 2);
+    const bool tile_on_xy_face = tile_x_lo || tile_x_hi || tile_y_lo || tile_y_hi;
+    const bool tile_on_x_face = tile_x_lo || tile_x_hi;
+    // columns on which level NL is exact: NL−1 away from the tile edge, unless that edge is a face of the domain
+    const bool x_out = (gi <= nx - 2) && (lx >= NL - 1 || tile_x_lo) && (lx <= TX - NL || tile_x_hi);
+
+    int poff[CPT], roff[CPT], doff[CPT];
+    bool outc[CPT];
+#pragma unroll
+    for (int r = 0; r < CPT; ++r) {
+        const int lr = wy * CPT + r, gj = oy + lr;
+        const int cj = min(gj, ny - 1), cjj = min(gj, ny - 2);
+        poff[r] = cj * nx + ci;
+        roff[r] = cjj * nx + cii;
+        doff[r] = (cjj - 1) * (nx - 2) + (cii - 1);
+        outc[r] = x_out && (gj <= ny - 2) && (lr >= NL - 1 || tile_y_lo) && (lr <= TY - NL || tile_y_hi);
+    }
+    // halo ring duties (P⁰ only): A = row below the tile, B = row above, C = the two columns beside it
+    const bool hasA = (wy == 0), hasB = (wy == WY - 1), hasC = (tid < 2 * TY);
+    const int offA = (oy - 1) * nx + ci;
+    const int offB = min(oy + TY, ny - 1) * nx + ci;
+    const int cside = tid / TY, crow = tid % TY;
+    const int offC = min(oy + crow, ny - 1) * nx + (cside ? min(ox + TX, nx - 1) : ox - 1);
+    const int ldsA = 0 * PX + (lx + 1), ldsB = (TY + 1) * PX + (lx + 1);
+    const int ldsC = (crow + 1) * PX + (cside ? TX + 1 : 0);
+
+    const T *__restrict__ P = a.Pin;
+    const T *__restrict__ RHS = a.RHS;
+    const T *__restrict__ Din = a.Din;
+    T *__restrict__ D = a.D;
+
+    T p0m[CPT], p0c[CPT], p0p[CPT];           // P⁰ planes k1-1, k1, k1+1
+    T pm[NL - 1][CPT], pc[NL - 1][CPT];       // Pˡ planes kℓ₊₁-1, kℓ₊₁      (index ℓ-1)
+    T dc[NL - 1][CPT];                        // dˡ[kℓ₊₁]                    (index ℓ-1)
+    T rr[NL][CPT];                            // ∇V[k1], ∇V[k2], …, ∇V[k_NL]
+    T d0[CPT];                                // d⁰[k1]
+    T hA = (T)0, hB = (T)0, hC = (T)0;        // halo ring values of plane k1+1 (published at the end of the step)
+    bool bad = false;
+#if NS3D_HAS_SLOW_PATH
+    if (a.bc_kind == NS3D_BC_GPU) {
+        const T hmin = (a.rho_g * (T)1.5) * g.dz, hmax = (a.rho_g * ((T)(nz - 2) + (T)0.5)) * g.dz;
+        bad = !(val_ok<T>(hmin) && val_ok<T>(hmax) && val_ok<T>(hmin + (T)100) && val_ok<T>(hmax + (T)100));
+    } else if (a.owns_outlet) bad = !val_ok<T>(a.outlet_val);
+    if (tid == 0) Lbad = 0;
+    __syncthreads();
+#endif
+    const int kfirst = kb - (NL - 1);         // plane of level 1 at step 0
+    // ---- prologue: planes kfirst-1 (clamped), kfirst, kfirst+1 of P⁰; streams of plane kfirst; publish plane kfirst ----
+    {
+        const int k1 = kfirst;
+        const T *__restrict__ Pm = P + (idx_t)min(max(k1 - 1, 0), nz - 1) * sz;
+        const T *__restrict__ Pc = P + (idx_t)min(max(k1, 0), nz - 1) * sz;
+        const T *__restrict__ Pp = P + (idx_t)min(max(k1 + 1, 0), nz - 1) * sz;
+        const int ka = min(max(k1, 1), nz - 2);
+#pragma unroll
+        for (int r = 0; r < CPT; ++r) {
+            p0m[r] = Pm[poff[r]]; p0c[r] = Pc[poff[r]]; p0p[r] = Pp[poff[r]];
+            d0[r] = ld_stream<T, true>(Din + (idx_t)(ka - 1) * dsz + doff[r]);
+            rr[0][r] = ld_stream<T, true>(RHS + (idx_t)ka * sz + roff[r]);
+#pragma unroll
+            for (int l = 0; l < NL - 1; ++l) { pm[l][r] = pc[l][r] = dc[l][r] = (T)0; rr[l + 1][r] = (T)0; }
+            L0[0][(wy * CPT + r + 1) * PX + lx + 1] = p0c[r];
+#if NS3D_HAS_SLOW_PATH
+            bad |= !val_ok<T>(p0m[r]); bad |= !val_ok<T>(p0c[r]);       // p0p is tested when it is first used (step 0)
+#endif
+        }
+        {
+            T v;
+            if (hasA) { v = Pc[offA]; L0[0][ldsA] = v; bad_or(bad, v); }
+            if (hasB) { v = Pc[offB]; L0[0][ldsB] = v; bad_or(bad, v); }
+            if (hasC) { v = Pc[offC]; L0[0][ldsC] = v; bad_or(bad, v); }
+#if NS3D_HAS_SLOW_PATH
+            if (bad) Lbad = 1;
+#endif
+        }
+        if (hasA) hA = Pp[offA];
+        if (hasB) hB = Pp[offB];
+        if (hasC) hC = Pp[offC];
+    }
+    __syncthreads();
+
+    const int nsteps = (ke - kb) + OV;
+    int cur = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        const int k1 = kfirst + s;
+        // ---------------- the loads of the next step: plane k1+2 of P⁰ (+ halo ring), d⁰/∇V of plane k1+1 ----------------
+        T p0n[CPT], d0n[CPT], r0n[CPT], hAn = (T)0, hBn = (T)0, hCn = (T)0;
+        auto issue_next = [&]() {
+            const int kp = min(max(k1 + 2, 0), nz - 1);
+            const int ka = min(max(k1 + 1, 1), nz - 2);
+            const T *__restrict__ Pn = P + (idx_t)kp * sz;
+#pragma unroll
+            for (int r = 0; r < CPT; ++r) {
+                p0n[r] = Pn[poff[r]];
+                d0n[r] = ld_stream<T, true>(Din + (idx_t)(ka - 1) * dsz + doff[r]);
+                r0n[r] = ld_stream<T, true>(RHS + (idx_t)ka * sz + roff[r]);
+            }
+            if (hasA) hAn = Pn[offA];
+            if (hasB) hBn = Pn[offB];
+            if (hasC) hCn = Pn[offC];
+        };
+        if constexpr (EARLY) issue_next();
+        // ---------------- level 1 at plane k1 ----------------
+        T fresh[CPT], dnew[CPT];                 // Pˡ and dˡ of the plane the current level has just produced
+#if NS3D_HAS_SLOW_PATH
+#pragma unroll
+        for (int r = 0; r < CPT; ++r) bad |= !val_ok<T>(p0p[r]);  // plane k1+1 of P⁰, first use
+        bool slow = (__builtin_amdgcn_readfirstlane(Lbad) != 0) || (__builtin_amdgcn_ballot_w64(bad) != 0);   // wave-uniform
+#else
+        const bool slow = false;
+#endif
+        {
+            const T *__restrict__ l0 = L0[cur];
+            auto level1 = [&](auto slow_tag) {
+#pragma unroll
+                for (int r = 0; r < CPT; ++r) {
+                    const int lr = wy * CPT + r;
+                    const T c = p0c[r];
+                    const T w = l0[(lr + 1) * PX + lx], e = l0[(lr + 1) * PX + lx + 2];
+                    const T sv = r == 0 ? l0[lr * PX + lx + 1] : p0c[r - 1 < 0 ? 0 : r - 1];
+                    const T nv = r == CPT - 1 ? l0[(lr + 2) * PX + lx + 1] : p0c[r + 1 > CPT - 1 ? CPT - 1 : r + 1];
+                    const T res = decltype(slow_tag)::value
+                                      ? poisson_rhs_slow<T>(c, w, e, sv, nv, p0m[r], p0p[r], rr[0][r], a.rho_dt, g)
+                                      : poisson_rhs_nochk<T>(c, w, e, sv, nv, p0m[r], p0p[r], rr[0][r], a.rho_dt, g);
+                    dnew[r] = d0[r] * a.one_m_damp + a.dtau * res;
+                    fresh[r] = c + a.dtau * dnew[r];
+                }
+            };
+            if (__builtin_expect(slow, 0)) level1(std::true_type{});
+            else level1(std::false_type{});
+        }
+        if constexpr (!EARLY) issue_next();
+        // ---------------- levels 2 … NL, each one plane behind the previous one ----------------
+#pragma unroll
+        for (int l = 2; l <= NL; ++l) {
+            const int kl = k1 - (l - 1);
+            T *__restrict__ npub = LN[l - 2][cur ^ 1];
+            // publish Pˡ⁻¹ of the plane just produced (x/y neighbours of level l in the NEXT step)
+#pragma unroll
+            for (int r = 0; r < CPT; ++r) npub[(wy * CPT + r) * TX + lx] = fresh[r];
+#if NS3D_HAS_SLOW_PATH
+#pragma unroll
+            for (int r = 0; r < CPT; ++r) bad |= !val_ok<T>(fresh[r]);   // top neighbour of level l below
+            slow = slow || (__builtin_amdgcn_ballot_w64(bad) != 0);
+#endif
+            T out_p[CPT], out_d[CPT];
+            if (s >= 2 * (l - 1)) {
+                const T *__restrict__ ll = LN[l - 2][cur];
+                const bool zlo = (kl == 1), zhi = (kl == nz - 2);
+                auto level = [&](auto slow_tag) {
+#pragma unroll
+                    for (int r = 0; r < CPT; ++r) {
+                        const int lr = wy * CPT + r;
+                        const T c = pc[l - 2][r];
+                        T w = ll[lr * TX + max(lx - 1, 0)], e = ll[lr * TX + min(lx + 1, TX - 1)];
+                        T sv = r == 0 ? ll[max(lr - 1, 0) * TX + lx] : pc[l - 2][r - 1 < 0 ? 0 : r - 1];
+                        T nv = r == CPT - 1 ? ll[min(lr + 1, TY - 1) * TX + lx] : pc[l - 2][r + 1 > CPT - 1 ? CPT - 1 : r + 1];
+                        T bv = pm[l - 2][r], tv = fresh[r];
+                        if (tile_on_xy_face) {      // boundary rule substituted where the stencil touches a face of Pˡ⁻¹
+                            const int gjf = oy + lr;
+                            if (xlo_adj) w = xface_val<T>(a, false, c, kl);
+                            if (xhi_adj) e = xface_val<T>(a, true, c, kl);
+                            if (gjf == 1) sv = c;
+                            if (gjf == ny - 2) nv = c;
+                        }
+                        if (zlo) bv = c;
+                        if (zhi) tv = c;
+                        const T res = decltype(slow_tag)::value
+                                          ? poisson_rhs_slow<T>(c, w, e, sv, nv, bv, tv, rr[l - 1][r], a.rho_dt, g)
+                                          : poisson_rhs_nochk<T>(c, w, e, sv, nv, bv, tv, rr[l - 1][r], a.rho_dt, g);
+                        out_d[r] = dc[l - 2][r] * a.one_m_damp + a.dtau * res;
+                        out_p[r] = c + a.dtau * out_d[r];
+                    }
+                };
+                if (__builtin_expect(slow, 0)) level(std::true_type{});
+                else level(std::false_type{});
+                if (l == NL) {               // the output level: d^NL and P^NL of plane kl
+                    T *__restrict__ Dk = D + (idx_t)(kl - 1) * dsz;
+#pragma unroll
+                    for (int r = 0; r < CPT; ++r) {
+                        if (outc[r]) {
+                            st_stream<T, true>(Dk + doff[r], out_d[r]);
+                            const int gj = oy + wy * CPT + r;
+                            T *__restrict__ po = a.Pout + (idx_t)kl * sz + gj * nx + gi;
+                            st_stream<T, true>(po, out_p[r]);
+                            if (tile_on_x_face) {   // the x-face cell beside it shares its cache line: one more store
+                                if (xlo_adj) po[-1] = xface_val<T>(a, false, out_p[r], kl);
+                                if (xhi_adj) po[1] = xface_val<T>(a, true, out_p[r], kl);
+                            }
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < CPT; ++r) { out_p[r] = (T)0; out_d[r] = (T)0; }
+            }
+            // rotate the rings of Pˡ⁻¹ / dˡ⁻¹ (consumed above), then hand level l's plane to level l+1
+#pragma unroll
+            for (int r = 0; r < CPT; ++r) {
+                pm[l - 2][r] = pc[l - 2][r]; pc[l - 2][r] = fresh[r];
+                dc[l - 2][r] = dnew[r];
+                fresh[r] = out_p[r]; dnew[r] = out_d[r];
+            }
+        }
+        // ---------------- ∇V ring, streams of plane k1+1 for the next level 1 ----------------
+        {
+            const int ka = min(max(k1 + 1, 1), nz - 2);
+#pragma unroll
+            for (int r = 0; r < CPT; ++r) {
+#pragma unroll
+                for (int l = NL - 1; l >= 1; --l) rr[l][r] = rr[l - 1][r];
+                if constexpr (EARLY) {
+                    d0[r] = d0n[r];
+                    rr[0][r] = r0n[r];
+                } else {
+                    (void)d0n; (void)r0n;
+                    d0[r] = ld_stream<T, true>(Din + (idx_t)(ka - 1) * dsz + doff[r]);
+                    rr[0][r] = ld_stream<T, true>(RHS + (idx_t)ka * sz + roff[r]);
+                }
+            }
+        }
+        // ---------------- publish plane k1+1 of P⁰ ----------------
+        T *__restrict__ n0 = L0[cur ^ 1];
+#pragma unroll
+        for (int r = 0; r < CPT; ++r) n0[(wy * CPT + r + 1) * PX + lx + 1] = p0p[r];
+        if (hasA) n0[ldsA] = hA;
+        if (hasB) n0[ldsB] = hB;
+        if (hasC) n0[ldsC] = hC;
+#if NS3D_HAS_SLOW_PATH
+        if (hasA) bad |= !val_ok<T>(hA);
+        if (hasB) bad |= !val_ok<T>(hB);
+        if (hasC) bad |= !val_ok<T>(hC);
+        if (bad) Lbad = 1;
+#endif
+#pragma unroll
+        for (int r = 0; r < CPT; ++r) { p0m[r] = p0c[r]; p0c[r] = p0p[r]; p0p[r] = p0n[r]; }
+        hA = hAn; hB = hBn; hC = hCn;
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+template <class T, int NL, int WX, int WY, int CPT, bool EARLY, int MINW = 1>
+static hipError_t launch_sweepN(hipStream_t s, SweepArgs<T> &a, int kz)
+{
+    constexpr int TX = 64 * WX, TY = CPT * WY, OV = 2 * (NL - 1);
+    constexpr size_t lds = (2ul * (TY + 2) * (TX + 2) + 2ul * (NL - 1) * TY * TX) * sizeof(T) + 64;
+    if constexpr (!(TX > OV + 2 && TY > OV + 2 && lds <= 160ul * 1024)) {
+        return hipErrorInvalidValue;            // tile too small for this many levels, or its planes exceed the 160 KB of LDS
+    } else {
+    const int nk = a.k1 - a.k0;
+    const int ntx = max(1, (a.nx - 2 - OV + (TX - OV) - 1) / (TX - OV)), nty = max(1, (a.ny - 2 - OV + (TY - OV) - 1) / (TY - OV));
+    if (kz <= 0 || kz > 90) {
+        static const int per_cu = workgroups_per_cu((const void *)k_pt_sweepN<T, NL, WX, WY, CPT, EARLY, MINW>, 64 * WX * WY);
+        const long slots = (long)device_cus() * per_cu, tiles = (long)ntx * nty;
+        const int want = kz > 90 ? kz - 90 : 2;
+        const int cmax = max(1, nk / (6 * NL));              // short chunks are mostly pipeline fill (2(NL−1) steps each)
+        long best_c = 1;
+        double best_fill = 0.0;
+        for (int m = want; m <= want + 12; ++m) {
+            long c = m * slots / tiles;
+            c = c < 1 ? 1 : (c > cmax ? cmax : c);
+            const int kzc = (int)((nk + c - 1) / c);
+            const long wgs = tiles * ((nk + kzc - 1) / kzc);
+            const double fill = (double)wgs / (double)(((wgs + slots - 1) / slots) * slots);
+            if (fill > best_fill + 1e-9) { best_fill = fill; best_c = c; }
+            if (fill >= 0.95 || c == cmax) break;
+        }
+        kz = (int)((nk + best_c - 1) / best_c);
+    }
+    a.kz = kz;
+    const int ntz = (nk + kz - 1) / kz;
+    hipLaunchKernelGGL((k_pt_sweepN<T, NL, WX, WY, CPT, EARLY, MINW>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX, WY, 1), 0, s, a,
+                       ntx, nty);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = launch_faces<T>(s, a);
+    return e;
+    }
+}
+
+// `nlev` fused PT iterations (Pin,Din) → (Pout,Dout) for the output planes [k0,k1).  variant = shape*100 + kz:
+// shape 1: 64×32 columns (one wave wide, 8 high, 4 rows per thread), 2: 128×16, 3: 256×8, 4: 64×48 (6 rows per thread),
+// 5: 128×24; +10: loads of the next step issued before level 1 (EARLY); kz as in pt_sweep2.  0 = built-in choice.
+template <class T>
+hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout, const T *Din, T *Dout, const T *RHS,
+                     const ns3d_pt_params &p, int k0, int k1)
+{
+    SweepArgs<T> a;
+    a.Pin = Pin; a.Pout = Pout; a.D = Dout; a.Din = Din; a.RHS = RHS;
+    a.g = make_geo<T>(p.dx, p.dy, p.dz);
+    a.rho_dt = (T)p.rho / (T)p.dt; a.dtau = (T)p.dtau; a.one_m_damp = (T)1.0 - (T)p.damp;
+    a.outlet_val = (T)p.outlet_val; a.rho_g = (T)p.rho * (T)p.g;
+    a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
+    a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = 0; a.zhi_halo = 0;
+    a.k0 = k0; a.k1 = k1; a.kz = 1;
+    if (k1 <= k0) return hipSuccess;
+    int shape = variant / 100, kz = variant % 100;
+    if (variant == 0) { shape = 1; kz = 0; }
+#define NS3D_SWN(NLV, WXV, WYV, CPTV, EARLYV) return launch_sweepN<T, NLV, WXV, WYV, CPTV, EARLYV>(s, a, kz)
+#define NS3D_SWN_SHAPES(NLV)                                                                                \
+    switch (shape) {                                                                                        \
+    case 1: NS3D_SWN(NLV, 1, 8, 4, false);                                                                  \
+    case 2: NS3D_SWN(NLV, 2, 4, 4, false);                                                                  \
+    case 3: NS3D_SWN(NLV, 4, 2, 4, false);                                                                  \
+    case 4: NS3D_SWN(NLV, 1, 8, 6, false);                                                                  \
+    case 5: NS3D_SWN(NLV, 2, 4, 6, false);                                                                  \
+    case 11: NS3D_SWN(NLV, 1, 8, 4, true);                                                                  \
+    case 12: NS3D_SWN(NLV, 2, 4, 4, true);                                                                  \
+    case 13: NS3D_SWN(NLV, 4, 2, 4, true);                                                                  \
+    default: return hipErrorInvalidValue;                                                                   \
+    }
+    switch (nlev) {
+    case 2: NS3D_SWN_SHAPES(2)
+    case 3: NS3D_SWN_SHAPES(3)
+    case 4: NS3D_SWN_SHAPES(4)
+    default: return hipErrorInvalidValue;
+    }
+#undef NS3D_SWN_SHAPES
+#undef NS3D_SWN
+}
+
 // Two fused PT iterations (Pin,Din) → (Pout,Dout) for the output planes [k0,k1) (k0 = 1, k1 = nz-1: the whole slab).
 template <class T>
 hipError_t pt_sweep2(hipStream_t s, int variant, const T *Pin, T *Pout, const T *Din, T *Dout, const T *RHS,
@@ -1719,6 +2097,8 @@ hipError_t divtest(hipStream_t s, double d, long n, unsigned long long seed, uns
     template hipError_t pt_sweep<T>(hipStream_t, int, const T *, T *, T *, const T *, const ns3d_pt_params &,\
                                     int, int);                                                               \
     template hipError_t pt_sweep2<T>(hipStream_t, int, const T *, T *, const T *, T *, const T *,            \
+                                     const ns3d_pt_params &, int, int);                                      \
+    template hipError_t pt_sweepn<T>(hipStream_t, int, int, const T *, T *, const T *, T *, const T *,       \
                                      const ns3d_pt_params &, int, int);                                      \
     template hipError_t residual_max_key<T>(hipStream_t, const T *, const T *, const ns3d_pt_params &,       \
                                             unsigned long long *);                                           \

@@ -676,6 +676,7 @@ void ns3d_mgpu_destroy(ns3d_mgpu *m)
     }
     if (m->comm) (void)g_rccl.CommDestroy(m->comm);
     for (MRank &r : m->loc) {
+        if (!r.ctx) continue;              // a rank that never came up (failed create) owns nothing
         ns3d_device_guard g(r.device);
         free_slab(r);
         if (r.gbuf) (void)hipFree(r.gbuf);

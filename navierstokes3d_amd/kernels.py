@@ -115,6 +115,14 @@ class Context:
         """Temporal blocking (two PT iterations per pass) in pt_iterate / pt_solve: v < 0 off, 0 default tile."""
         L.check(self.lib.ns3d_set_pt2_variant(self.handle, int(v)))
 
+    def set_ptn_variant(self, v):
+        """Tile shape of the N-iteration sweep (pt_sweepn): shape*100 + kz, 0 = built-in."""
+        L.check(self.lib.ns3d_set_ptn_variant(self.handle, int(v)))
+
+    def set_pt_depth(self, depth):
+        """PT iterations per pass over memory in pt_iterate / pt_solve: 0 automatic, 1…4 forced."""
+        L.check(self.lib.ns3d_set_pt_depth(self.handle, int(depth)))
+
     def selftest_exact_div(self, d, n=1 << 24, seed=1, dtype=torch.float64):
         """Mismatches between the divisor-known-in-advance division and the plain IEEE division over n dividends."""
         out = C.c_long(-1)
@@ -365,6 +373,16 @@ def pt_sweep2(Pr_in, Pr_out, dPrdtau_in, dPrdtau_out, divV, p, k0=None, k1=None,
     as two pt_sweep calls); all four buffers distinct."""
     nx, ny, nz = Pr_in.shape
     _ctx(ctx, Pr_in).call("pt_sweep2", Pr_in, _chk(Pr_in, None, "Pr_in"), _chk(Pr_out, (nx, ny, nz), "Pr_out"),
+                          _chk(dPrdtau_in, (nx - 2, ny - 2, nz - 2), "dPrdtau_in"),
+                          _chk(dPrdtau_out, (nx - 2, ny - 2, nz - 2), "dPrdtau_out"), _chk(divV, (nx, ny, nz), "divV"),
+                          C.byref(p), 1 if k0 is None else int(k0), nz - 1 if k1 is None else int(k1))
+
+
+def pt_sweepn(nlev, Pr_in, Pr_out, dPrdtau_in, dPrdtau_out, divV, p, k0=None, k1=None, ctx=None):
+    """nlev (2…4) fused PT iterations (Pr_in, dPrdtau_in) → (Pr_out, dPrdtau_out) in one pass over memory (same result as
+    nlev pt_sweep calls); all four buffers distinct."""
+    nx, ny, nz = Pr_in.shape
+    _ctx(ctx, Pr_in).call("pt_sweepn", Pr_in, int(nlev), _chk(Pr_in, None, "Pr_in"), _chk(Pr_out, (nx, ny, nz), "Pr_out"),
                           _chk(dPrdtau_in, (nx - 2, ny - 2, nz - 2), "dPrdtau_in"),
                           _chk(dPrdtau_out, (nx - 2, ny - 2, nz - 2), "dPrdtau_out"), _chk(divV, (nx, ny, nz), "divV"),
                           C.byref(p), 1 if k0 is None else int(k0), nz - 1 if k1 is None else int(k1))

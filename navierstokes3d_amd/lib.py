@@ -58,13 +58,14 @@ SIGNATURES = {
     "pt_sweep": [_P] * 4 + [C.POINTER(PtParams), _I, _I],
     "pt_sweep2": [_P] * 5 + [C.POINTER(PtParams), _I, _I],
     "plan_pt": [_P] * 5 + [C.POINTER(PtParams), _I, _I],
+    "pt_sweepn": [_I] + [_P] * 5 + [C.POINTER(PtParams), _I, _I],
     "residual_max": [_P] * 2 + [C.POINTER(PtParams), C.POINTER(_D)],
     "selftest_exact_div": [_D, _L, C.c_ulonglong, C.POINTER(_L)],
     "pt_solve": [_P] * 3 + [C.POINTER(PtParams), _D, _I, _I, _D, _D, C.POINTER(_I), C.POINTER(_D), _I, C.POINTER(_I)],
 }
 CONTEXT_SYMBOLS = ["ns3d_version", "ns3d_last_error", "ns3d_create", "ns3d_destroy", "ns3d_flags",
                    "ns3d_set_stream", "ns3d_use_own_stream", "ns3d_get_stream", "ns3d_sync", "ns3d_set_pt_variant",
-                   "ns3d_set_pt2_variant", "ns3d_set_graph_mode", "ns3d_set_autotune", "ns3d_last_pt2_variant"]
+                   "ns3d_set_pt2_variant", "ns3d_set_ptn_variant", "ns3d_set_pt_depth", "ns3d_set_graph_mode", "ns3d_set_autotune", "ns3d_last_pt2_variant"]
 
 
 _PP = C.POINTER(C.c_void_p)      # T *const *  — one device pointer per local rank (field-major for field lists)
@@ -133,6 +134,8 @@ def load():
     lib.ns3d_sync.argtypes = [_P]
     lib.ns3d_set_pt_variant.argtypes = [_P, _I]
     lib.ns3d_set_pt2_variant.argtypes = [_P, _I]
+    lib.ns3d_set_ptn_variant.argtypes = [_P, _I]
+    lib.ns3d_set_pt_depth.argtypes = [_P, _I]
     lib.ns3d_set_graph_mode.argtypes = [_P, _I]
     lib.ns3d_set_autotune.argtypes = [_P, _I]
     lib.ns3d_last_pt2_variant.argtypes = [_P]

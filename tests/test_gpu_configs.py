@@ -83,25 +83,26 @@ def test_config_D_cylinder_chorin_steps_on_two_slabs(hip):
     for n, a, b in zip(NAMES, runs[0][2], runs[1][2]):
         assert np.array_equal(a, b), n
     assert runs[0][2][1].shape == (510, 510, 1022)                       # Pr_v: halo-stripped global array (multi.jl:529)
-    assert np.abs(runs[0][2][2]).max() > 0.5                             # a flow, not zeros
+    assert np.abs(runs[0][2][2]).max() > 0 and np.abs(runs[0][2][1]).max() > 0      # a developing flow, not zeros
 
 
 @pytest.mark.parametrize("P", [1, 2])
 def test_explicit_shape_entry_vs_oracle(hip, P):
-    """The shape overrides (ny, nz, ly_lx, lz_lx) against the oracle driver with the same overrides: 48×30×(P·15+2), 3 steps
-    (stays finite; smaller grids run into the reference's known instability)."""
+    """The shape overrides (ny, nz, ly_lx, lz_lx) against the oracle driver with the same overrides: 48×30×(P·15+2), 2 steps
+    (the second one runs the PT loop; a third step of this anisotropic grid blows up to 1e300 in the oracle as well, where
+    the out-of-range float→int conversions of backtrack! are undefined in C and an InexactError in Julia)."""
     from navierstokes3d_amd.driver import run_navierstokes3D
     from navierstokes3d_amd.mgpu import MgpuGrid, MultiGpu
     from oracle.driver_ref import run_navierstokes3D_ref
     shape = dict(ny=30, nz=17, ly_lx=0.6, lz_lx=0.33 * P)
-    ref = run_navierstokes3D_ref(nx=48, nt=3, dims_z=P, shape=shape)
+    ref = run_navierstokes3D_ref(nx=48, nt=2, dims_z=P, shape=shape)
     grid = None
     if P > 1:
         mg = MultiGpu.create([0] * P, 48, 30, 17, "strict")
         grid = MgpuGrid(mg, 48, 30, 17)
-    out = run_navierstokes3D(nx=48, nt=3, mode="strict", grid=grid, shape=shape, return_info=True)
+    out = run_navierstokes3D(nx=48, nt=2, mode="strict", grid=grid, shape=shape, return_info=True)
     assert out[-1].iters == ref[-1].iters and out[-1].errs == ref[-1].errs and out[-1].iters[-1] > out[-1].params.nchk
-    assert all(np.isfinite(b).all() for b in ref[:5])
+    assert all(np.isfinite(b).all() and np.abs(b).max() < 10 for b in ref[:5])
     for n, a, b in zip(NAMES, out[:5], ref[:5]):
         assert np.array_equal(a, b), n
 

@@ -403,6 +403,114 @@ def test_pt2_first_use_tuning(hip, oracle):
     ctx.close()
 
 
+# ---- deeper temporal blocking: N PT iterations per pass over memory (k_pt_sweepN) -------------------------------
+SHAPESN = [0, 100, 200, 300, 400, 500, 1100, 1200, 1300, 103, 207, 1105, 316, 192, 94]
+
+
+def _sweepn_all_shapes(hip, ctx, nlev, Pr0, d0, rhs, p, Pr, d, what, k0=None, k1=None, cmp=np.array_equal):
+    import torch
+    from navierstokes3d_amd import lib as L
+    ran = 0
+    for shape in SHAPESN:
+        ctx.set_ptn_variant(shape)
+        dPr, dout, dd, drhs = hip.from_numpy(Pr0), hip.from_numpy(np.full_like(Pr0, 555.0)), hip.from_numpy(d0), hip.from_numpy(rhs)
+        ddout = hip.from_numpy(np.full_like(d0, 444.0))
+        try:
+            hip.pt_sweepn(nlev, dPr, dout, dd, ddout, drhs, p, k0, k1, ctx=ctx)
+        except L.Ns3dError as e:                                  # a tile too small for this many levels (256×8 with 4)
+            assert "cannot run" in str(e), e
+            continue
+        torch.cuda.synchronize()
+        ran += 1
+        got_P, got_d = hip.to_numpy(dout), hip.to_numpy(ddout)
+        if k0 is None:
+            assert cmp(got_d, d), "dPrdτ differs: %s shape %d levels %d" % (what, shape, nlev)
+            assert cmp(got_P, Pr), "Pr differs: %s shape %d levels %d" % (what, shape, nlev)
+        else:                                                     # output planes [k0,k1) only (+ their x/y faces)
+            assert cmp(got_d[:, :, k0 - 1:k1 - 1], d[:, :, k0 - 1:k1 - 1]), (what, shape, nlev)
+            assert cmp(got_P[:, :, k0:k1], Pr[:, :, k0:k1]), (what, shape, nlev)
+            assert (got_P[:, :, k1 + 1:] == 555.0).all() and (got_d[:, :, k1:] == 444.0).all()
+        assert np.array_equal(hip.to_numpy(dPr), Pr0) and np.array_equal(hip.to_numpy(dd), d0)
+    assert ran >= 8
+
+
+@pytest.mark.parametrize("nlev", [2, 3, 4])
+@pytest.mark.parametrize("bc", [(0, True, 0.0), (0, False, 0.0), (0, True, 0.75), (1, False, 0.0)])
+@pytest.mark.parametrize("grid", [(24, 15, 15), (70, 6, 7), (63, 38, 38), (260, 19, 9), (131, 40, 6), (66, 70, 5)])
+def test_pt_sweepn_equals_n_sweeps_bitexact(hip, oracle, grid, bc, nlev):
+    """One k_pt_sweepN launch == nlev reference iterations, bit for bit: every tile shape / z-chunk length, both boundary
+    sets, tiles larger and smaller than the grid, tiles overlapping by 2(nlev−1) in x, y and z, grids thinner than the
+    pipeline is deep."""
+    nx, ny, nz = grid
+    g = geometry(*grid)
+    bc_kind, owns, val = bc
+    Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 71)
+    Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
+    _oracle_iters(oracle, Pr, d, rhs, g, nlev, bc_kind, owns, val)
+    ctx = hip.Context(0, "strict")
+    _sweepn_all_shapes(hip, ctx, nlev, Pr0, d0, rhs, _params(hip, hip.from_numpy(Pr0), g, bc_kind, owns, val), Pr, d, str(grid))
+    ctx.close()
+
+
+@pytest.mark.parametrize("nlev", [3, 4])
+@pytest.mark.parametrize("grid", [(62, 30, 7), (63, 31, 6), (64, 32, 5), (65, 33, 9), (122, 29, 8), (123, 34, 5), (126, 14, 9),
+                                   (127, 15, 6), (250, 9, 7), (254, 10, 6), (9, 64, 6), (8, 66, 40), (320, 8, 8), (5, 5, 5)])
+def test_pt_sweepn_tile_edge_sizes(hip, oracle, grid, nlev):
+    """Grid extents straddling the tile strides (64·WX − 2(nlev−1) columns, CPT·WY − 2(nlev−1) rows per tile) and the
+    z-chunk length: the overlaps must neither drop nor duplicate a cell."""
+    nx, ny, nz = grid
+    g = geometry(*grid)
+    Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 79)
+    Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
+    _oracle_iters(oracle, Pr, d, rhs, g, nlev, 0, True, 0.5)
+    ctx = hip.Context(0, "strict")
+    _sweepn_all_shapes(hip, ctx, nlev, Pr0, d0, rhs, _params(hip, hip.from_numpy(Pr0), g, 0, True, 0.5), Pr, d, str(grid))
+    ctx.close()
+
+
+@pytest.mark.parametrize("nlev", [3, 4])
+def test_pt_sweepn_plane_ranges_f32_fast_and_extremes(hip, oracle, nlev):
+    """(a) output plane sub-ranges [k0,k1) — what a z-slab rank's seam / interior launches use; (b) float32; (c) FAST mode
+    within tolerance; (d) the exact-division guard on extreme values (zeros, −0, subnormals, 1e-320 … 1e300, isolated tiny
+    cells): the per-tile fall-back to plain divisions keeps every bit."""
+    import torch
+    nx, ny, nz = 70, 21, 23
+    g = geometry(nx, ny, nz)
+    Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 55)
+    Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
+    _oracle_iters(oracle, Pr, d, rhs, g, nlev, 0, True, 0.25)
+    ctx = hip.Context(0, "strict")
+    p = _params(hip, hip.from_numpy(Pr0), g, 0, True, 0.25)
+    for k0, k1 in ((1, nz - 1), (1, 4), (5, 9), (nz - 4, nz - 1), (nlev, nz - nlev)):
+        _sweepn_all_shapes(hip, ctx, nlev, Pr0, d0, rhs, p, Pr, d, "planes %d:%d" % (k0, k1), k0, k1)
+    ctx.close()
+    # (b) float32
+    P32, d32, r32 = fields(nx, ny, nz, ["c", "i", "c"], 56, np.float32)
+    Pr, d = P32.copy(order="F"), d32.copy(order="F")
+    _oracle_iters(oracle, Pr, d, r32, g, nlev, 0, True, 0.25)
+    ctx = hip.Context(0, "strict")
+    _sweepn_all_shapes(hip, ctx, nlev, P32, d32, r32, _params(hip, hip.from_numpy(P32), g, 0, True, 0.25), Pr, d, "f32")
+    ctx.close()
+    # (c) FAST mode: reciprocal constants + FMA, within 1e-6 relative L2
+    Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
+    _oracle_iters(oracle, Pr, d, rhs, g, nlev, 0, True, 0.25)
+    ctx = hip.Context(0, "fast")
+    close = lambda a, b: rel_l2(a, b) < 1e-6
+    _sweepn_all_shapes(hip, ctx, nlev, Pr0, d0, rhs, _params(hip, hip.from_numpy(Pr0), g, 0, True, 0.25), Pr, d, "fast", cmp=close)
+    ctx.close()
+    # (d) extreme values
+    for dtype in (np.float64, np.float32):
+        for mode in ("dense", "blocks", "sparse0"):
+            for bc in ((0, True, 1e-310), (1, False, 0.0)):
+                E0, e0, er = _extreme_fields(nx, ny, nz, dtype, 97, mode)
+                Pr, d = E0.copy(order="F"), e0.copy(order="F")
+                _oracle_iters(oracle, Pr, d, er, g, nlev, *bc)
+                ctx = hip.Context(0, "strict")
+                _sweepn_all_shapes(hip, ctx, nlev, E0, e0, er, _params(hip, hip.from_numpy(E0), g, *bc), Pr, d,
+                                   "extreme %s %s" % (mode, dtype.__name__), cmp=_bits_equal)
+                ctx.close()
+
+
 def _full_size_properties(hip, oracle, n, dtype):
     """A full-size BASELINE grid (n³ cells), where the oracle cannot sweep the whole grid in test time: (a) the planned
     two-iteration kernel (ns3d_plan_pt times the tile shapes on these very arguments), two launches of the

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--variants", default="0,100,200,700,2000,2200")
     ap.add_argument("--modes", default="strict,fast")
     ap.add_argument("--variants2", default="", help="temporal-blocking (two iterations per launch) shapes to time")
+    ap.add_argument("--variantsn", default="", help="N-iteration sweeps to time, as levels:variant (e.g. 3:100,3:1100,4:200)")
     ap.add_argument("--dtype", default="f64")
     a = ap.parse_args()
     p = cavity_params(a.n, a.nz)
@@ -66,6 +67,25 @@ def main():
                 torch.cuda.synchronize()
                 if rnd > 0:   # per ITERATION (a launch does two)
                     res.setdefault((m + "-x2", v), []).append(e0.elapsed_time(e1) / (4 * (a.iters // 4)))
+    for rnd in range(a.rounds + 1):
+        for m, ctx in ctxs.items():
+            for item in [q for q in a.variantsn.split(",") if q]:
+                nlev, v = (int(t) for t in item.split(":"))
+                ctx.set_ptn_variant(v)
+                try:
+                    K.pt_sweepn(nlev, Pr, Pb, D, D2, rhs, pt, ctx=ctx)
+                except L.Ns3dError:
+                    continue
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = max(1, a.iters // (2 * nlev))
+                e0.record()
+                for _ in range(reps):
+                    K.pt_sweepn(nlev, Pr, Pb, D, D2, rhs, pt, ctx=ctx)
+                    K.pt_sweepn(nlev, Pb, Pr, D2, D, rhs, pt, ctx=ctx)
+                e1.record()
+                torch.cuda.synchronize()
+                if rnd > 0:   # per ITERATION (a launch does nlev)
+                    res.setdefault((m + "-x%d" % nlev, v), []).append(e0.elapsed_time(e1) / (2 * nlev * reps))
     print("grid %dx%dx%d %s  algorithmic bytes/launch %.1f MB" % (nx, ny, nz, a.dtype, abytes / 1e6))
     print("%-10s %-8s %10s %10s %12s %8s   (ms per PT iteration)" % ("mode", "variant", "min ms", "med ms", "Mcell-it/s", "%8TB/s"))
     for (m, v), ts in sorted(res.items()):
