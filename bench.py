@@ -173,6 +173,9 @@ def main():
     ap.add_argument("--variant", type=int, default=int(os.environ.get("NS3D_PT_VARIANT", "0")))
     ap.add_argument("--variant2", type=int, default=None, help="tile shape of the two-iteration sweep")
     ap.add_argument("--no-temporal-blocking", action="store_true")
+    ap.add_argument("--depth", type=int, default=int(os.environ.get("NS3D_BENCH_DEPTH", "0")),
+                    help="PT iterations per pass over memory: 0 = what the plan phase measures as fastest (2 or 3), 2…4 forced")
+    ap.add_argument("--variantn", type=int, default=None, help="tile shape of the N-iteration sweep")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: n x n x nz per GPU (the reference's model); strong: n x n x nz is the GLOBAL grid, split in z")
     ap.add_argument("--no-autotune", action="store_true", help="built-in tile choice instead of timing the shapes once")
@@ -240,6 +243,10 @@ def main():
     ctx.set_pt_variant(a.variant)
     if a.variant2 is not None:
         ctx.set_pt2_variant(a.variant2)
+    if a.variantn is not None:
+        ctx.set_ptn_variant(a.variantn)
+    if a.depth > 0:
+        ctx.set_pt_depth(a.depth)
     if a.no_autotune:
         ctx.set_autotune(False)
     grid = ZSlabGrid(nx, ny, nz, transport="host") if world > 1 else ZSlabGrid(nx, ny, nz)
@@ -254,26 +261,40 @@ def main():
     pt = K.pt_params(Pr, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, L.NS3D_BC_MULTI, False, 0.0, 0.0,
                      grid.z_lo_is_halo(), grid.z_hi_is_halo())
 
-    depth = 1 if a.no_temporal_blocking else 2      # PT iterations per pass over memory
-    use2 = (world == 1) and depth == 2
+    depth = 1 if a.no_temporal_blocking else (a.depth if a.depth > 0 else 2)      # PT iterations per pass over memory
+    use2 = (world == 1) and depth >= 2
     slab = None
     if mg is not None:                              # the whole schedule inside libns3d: ns3d_slab_load / _plan / _iterate
-        mg.set_temporal(depth)
+        mg.set_temporal(1 if a.no_temporal_blocking else 3)
         mg.update_halo(rhs)                         # update_halo!(∇V), multi.jl:455: the seam planes of the RHS agree
         mg.slab_load(Pr, D, rhs, pt)
-        if not a.no_autotune:
-            mg.slab_plan()                          # plan phase, untimed: tile shape of the interior sweeps
+        depth = mg.slab_plan()                      # plan phase, untimed: tile shapes and iterations per pass (all ranks agree)
     elif world > 1:
         from navierstokes3d_amd.slab import SlabPTSolver
         grid.update_halo(rhs)
         slab = SlabPTSolver(ctx, grid, Pr, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, L.NS3D_BC_MULTI, False, 0.0, 0.0)
+        depth = 2 if depth >= 2 else 1              # the torch.distributed schedule blocks two iterations at most
         slab.set_temporal_blocking(depth == 2)
         slab.load(Pr, D, rhs)
     D2 = K.zeros((nx - 2, ny - 2, nz - 2), tdt, dev) if use2 else None
 
+    def schedule(n):
+        """the passes ns3d_pt_iterate makes for n iterations at `depth` iterations per pass (4 = 2+2, not 3+1)"""
+        out = []
+        while n > 0:
+            if depth < 2 or n < 2:
+                its = 1
+            elif n >= depth:
+                its = depth - 1 if (n == depth + 1 and depth >= 3) else depth
+            else:
+                its = 3 if n >= 3 else 2
+            out.append(its)
+            n -= its
+        return out
+
     def run(n):
         """n PT iterations {update_dPrdτ!; update_Pr!; set_bc_Pr!}.  One GPU: what ns3d_pt_iterate does, with the buffer
-        swaps visible (two iterations per pass over memory where n allows).  z-slab ranks: seam planes first, their
+        swaps visible (`depth` iterations per pass over memory where n allows).  z-slab ranks: seam planes first, their
         exchange behind the interior sweep."""
         nonlocal Pr, Pb, D, D2
         if mg is not None:
@@ -282,19 +303,22 @@ def main():
         if slab is not None:
             slab.iterate(n)
             return
-        if use2:
-            for _ in range(n // 2):
+        for its in schedule(n):
+            if its == 1:
+                K.pt_sweep(Pr, Pb, D, rhs, pt, 1, nz - 1, ctx=ctx)
+                Pr, Pb = Pb, Pr
+                continue
+            if its == 2:
                 K.pt_sweep2(Pr, Pb, D, D2, rhs, pt, ctx=ctx)
-                Pr, Pb, D, D2 = Pb, Pr, D2, D
-            n = n % 2
-        for _ in range(n):
-            K.pt_sweep(Pr, Pb, D, rhs, pt, 1, nz - 1, ctx=ctx)
-            Pr, Pb = Pb, Pr
+            else:
+                K.pt_sweepn(its, Pr, Pb, D, D2, rhs, pt, ctx=ctx)
+            Pr, Pb, D, D2 = Pb, Pr, D2, D
 
-    # plan phase, untimed and outside the warmup count: ns3d_plan_pt times the tile shapes of k_pt_sweep2 on these
-    # arguments and the process keeps the winner (every shape gives the same bits)
+    # plan phase, untimed and outside the warmup count: ns3d_plan_pt times the tile shapes of k_pt_sweep2 / k_pt_sweepN on
+    # these arguments, decides how many iterations a pass advances, and the process keeps the winner (same bits either way)
     if use2 and not a.no_autotune:
         K.plan_pt(Pr, Pb, D, D2, rhs, pt, ctx=ctx)
+        depth = ctx.last_pt_depth() if a.depth <= 0 else a.depth
         Pb.zero_(); D2.zero_()
         torch.cuda.synchronize()
     run(a.warmup)
@@ -328,9 +352,10 @@ def main():
     if rank == 0:
         cells_g = nx * ny * grid.nz_g()
         itemsize = 8 if a.dtype == "f64" else 4
-        # the dominant kernel: k_pt_sweep2 advances TWO iterations per launch (k_pt_sweep: one)
-        its_per_launch = 2 if depth == 2 and a.steps >= 2 else 1
-        launches = a.steps // 2 + a.steps % 2 if its_per_launch == 2 else a.steps
+        # the dominant kernel: k_pt_sweep2 / k_pt_sweepN advance `depth` iterations per launch (k_pt_sweep: one)
+        passes = schedule(a.steps)
+        its_per_launch = max(passes)
+        launches = len(passes)
         kern_ms = dev_ms / launches                  # HIP events around the timed launches on the launch stream
         must_move = algorithmic_bytes(nx, ny, nz, itemsize)          # bytes ONE pass has to move, per launch
         physical = must_move / (kern_ms * 1e-3) / 1e9
@@ -359,13 +384,14 @@ def main():
                        "decomposition": "z-slabs x%d" % world,
                        "transport": transport, "rccl_ranks": rccl_ranks,
                        "arith_mode": a.mode, "variant": a.variant,
-                       "pt2_variant": ctx.last_pt2_variant(), "residual_after_run": err, "finite": finite},
+                       "pt_depth": its_per_launch, "pt2_variant": ctx.last_pt2_variant(),
+                       "ptn_variant": ctx.last_ptn_variant(), "residual_after_run": err, "finite": finite},
             "hbm_gbps_algorithmic": effective * world,
             "roofline": {"bound": "hbm", "achieved": physical, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": physical / HBM_PEAK_GBPS,
                          "definition": "bytes one launch must move (one pass: itemsize*(N+4*N_inner)) / launch time / peak",
                          "traffic": traffic, "traffic_source": "profiles lookup" if traffic is not None else "none",
-                         "kernel": "k_pt_sweep2" if its_per_launch == 2 else "k_pt_sweep",
+                         "kernel": {1: "k_pt_sweep", 2: "k_pt_sweep2"}.get(its_per_launch, "k_pt_sweepN<%d levels>" % its_per_launch),
                          "kernel_ms": kern_ms,
                          "pt_iterations_per_launch": its_per_launch, "bytes_per_launch": must_move,
                          "effective_gbps": effective, "effective_frac": effective / HBM_PEAK_GBPS,

@@ -95,6 +95,8 @@ int ns3d_set_ptn_variant(ns3d_ctx *ctx, int variant);
 int ns3d_set_pt_depth(ns3d_ctx *ctx, int depth);
 int ns3d_set_autotune(ns3d_ctx *ctx, int on);
 int ns3d_last_pt2_variant(const ns3d_ctx *ctx);
+int ns3d_last_ptn_variant(const ns3d_ctx *ctx);   /* tile variant of the latest N-iteration launch */
+int ns3d_last_pt_depth(const ns3d_ctx *ctx);      /* PT iterations of the latest multi-iteration pass; after ns3d_plan_pt: the planned depth */
 /* ns3d_pt_solve replays each residual-check block (nchk iterations) as one HIP graph: -1 = automatically on
  * launch-bound grids (< 3 M cells), 0 = never, 1 = always.  Same results either way. */
 int ns3d_set_graph_mode(ns3d_ctx *ctx, int mode);
@@ -257,8 +259,11 @@ const char *ns3d_mgpu_transport(const ns3d_mgpu *m);   /* "peer" | "rccl" */
 int ns3d_mgpu_rccl_ranks(const ns3d_mgpu *m);          /* ncclCommCount of the communicator (0 in the one-process form) */
 int ns3d_mgpu_sync(ns3d_mgpu *m);
 int ns3d_max_g(ns3d_mgpu *m, const double *local_max, double *out);    /* NaN-propagating */
-/* PT iterations per pass over memory in ns3d_slab_* / ns3d_pt_solve_slab: 2 (default; two ghost planes per seam) or 1 */
+/* Most PT iterations a pass over memory may advance in ns3d_slab_* / ns3d_pt_solve_slab = ghost planes per seam: 3 (default),
+ * 2 or 1 (plain one-plane halo, single sweeps).  Passes run two iterations until ns3d_slab_plan has measured whether three
+ * pay on this grid; every rank uses the same depth. */
 int ns3d_mgpu_set_temporal(ns3d_mgpu *m, int depth);
+int ns3d_mgpu_pass_depth(const ns3d_mgpu *m);
 /* The pseudo-transient state of a z-slab rank lives in library-owned buffers extended by the ghost planes temporal
  * blocking needs: load → iterate / residual → store; ns3d_pt_solve_slab is the whole inner loop multi.jl:458-471
  * (load, plan, iterate with a global residual check every nchk iterations, store).  Iterates are bit-identical to the

@@ -2,9 +2,10 @@
 
     python -m navierstokes3d_amd.build [--force]
 
-The kernel translation unit is compiled three times: STRICT (-ffp-contract=off: reference operation order, IEEE
+The kernel translation unit is compiled four times: STRICT (-ffp-contract=off: reference operation order, IEEE
 division, no FMA — bit-identical to the CPU oracle), STRICT with exact division-by-known-divisor (same results,
-fewer instructions) and FAST (-ffp-contract=fast + reciprocal constants).
+fewer instructions), STRICT for power-of-two spacings (same results: x/d ≡ x·(1/d) exactly) and FAST
+(-ffp-contract=fast + reciprocal constants).
 hipcc cross-compiles without a GPU; the resulting .so is git-ignored but travels to the GPU box.
 """
 import os
@@ -22,6 +23,7 @@ UNITS = [
     # (source, object, extra flags)
     ("ns3d_kernels.hip", "ns3d_kernels_strict.o", ["-DNS3D_MODE_STRICT", "-ffp-contract=off"]),
     ("ns3d_kernels.hip", "ns3d_kernels_strictx.o", ["-DNS3D_MODE_STRICT", "-DNS3D_EXACT_RECIP", "-ffp-contract=off"]),
+    ("ns3d_kernels.hip", "ns3d_kernels_strictp.o", ["-DNS3D_MODE_STRICT", "-DNS3D_POW2_RECIP", "-ffp-contract=off"]),
     ("ns3d_kernels.hip", "ns3d_kernels_fast.o", ["-DNS3D_MODE_FAST", "-ffp-contract=fast"]),
     ("ns3d_api.cpp", "ns3d_api.o", ["-x", "hip"]),
     ("ns3d_mgpu.cpp", "ns3d_mgpu.o", ["-x", "hip"]),

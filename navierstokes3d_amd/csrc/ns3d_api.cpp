@@ -26,7 +26,7 @@ int ns3d_fail(int code, const char *fmt, ...)
 
 // tile choices measured so far in this process (per device and grid): contexts come and go (one per driver call), the
 // measurement should not be repeated
-struct Tuned { int device, nx, ny, nz, nk, esize, mode, variant; };
+struct Tuned { int device, nx, ny, nz, nk, esize, mode, variant, depth, variantn; };
 static std::vector<Tuned> g_tuned;
 static std::mutex g_tuned_mutex;
 
@@ -55,13 +55,23 @@ static bool recip_ok(double d)
     if (!(f > 0x1p-20f && f < 0x1p20f) || (fb & 0x007FFFFFu) == 0x007FFFFFu) return false;
     return true;
 }
+// d = 2^e exactly, with 1/d representable in double and float alike
+static bool pow2_ok(double d)
+{
+    if (!(d > 0x1p-100 && d < 0x1p100)) return false;
+    int e;
+    return std::frexp(d, &e) == 0.5;
+}
+// 3 = STRICT on power-of-two spacings (x/d ≡ x·(1/d), same bits as 0 and 1 with plain multiplications)
 static int mode_of(const ns3d_ctx *c, double dx, double dy, double dz)
 {
     if (c->flags & NS3D_FAST) return 2;
     if (c->flags & NS3D_IEEE_DIV) return 0;
+    if (pow2_ok(dx) && pow2_ok(dy) && pow2_ok(dz)) return 3;
     return (recip_ok(dx) && recip_ok(dy) && recip_ok(dz)) ? 1 : 0;
 }
-#define DISPATCHM(mode, call) ((mode) == 2 ? ns3d_fast::call : (mode) == 1 ? ns3d_strictx::call : ns3d_strict::call)
+#define DISPATCHM(mode, call)                                                                               \
+    ((mode) == 2 ? ns3d_fast::call : (mode) == 3 ? ns3d_strictp::call : (mode) == 1 ? ns3d_strictx::call : ns3d_strict::call)
 #define DISPATCH(ctx, call) DISPATCHM(((ctx)->flags & NS3D_FAST) ? 2 : 0, call)      /* kernels without divisions */
 #define DISPATCHG(ctx, dx, dy, dz, call) DISPATCHM(mode_of((ctx), (dx), (dy), (dz)), call)
 
@@ -106,6 +116,8 @@ ns3d_ctx *ns3d_create(int device, int flags)
     if (const char *ev = std::getenv("NS3D_PT_DEPTH")) c->pt_depth = std::atoi(ev);
     c->autotune = 1;
     c->last_pt2 = 0;
+    c->last_ptn = 0;
+    c->last_depth = 0;
     c->tune_ev[0] = c->tune_ev[1] = nullptr;
     c->graph_mode = -1;
     c->fence = nullptr;
@@ -187,6 +199,8 @@ int ns3d_set_autotune(ns3d_ctx *c, int on)
 }
 
 int ns3d_last_pt2_variant(const ns3d_ctx *c) { return c ? c->last_pt2 : -1; }
+int ns3d_last_ptn_variant(const ns3d_ctx *c) { return c ? c->last_ptn : -1; }
+int ns3d_last_pt_depth(const ns3d_ctx *c) { return c ? c->last_depth : -1; }
 
 int ns3d_set_ptn_variant(ns3d_ctx *c, int v)
 {
@@ -243,8 +257,8 @@ int ns3d_check_pt_params(const ns3d_pt_params *p, const char *fn)
 static const long long NS3D_TWO_MIN_CELLS = 1500ll * 1000;
 static bool use_two(const ns3d_ctx *c, const ns3d_pt_params *p)
 {
-    if (c->pt2_variant < 0) return false;
-    if (c->pt2_variant > 0) return true;
+    if (c->pt2_variant < 0 || c->pt_depth == 1) return false;
+    if (c->pt2_variant > 0 || c->pt_depth >= 2) return true;
     return (long long)p->nx * p->ny * p->nz >= NS3D_TWO_MIN_CELLS;
 }
 
@@ -295,100 +309,171 @@ static int ensure_pingpong_d(ns3d_ctx *c, const ns3d_pt_params *p, T **buf)
 // grid times the candidates on the caller's own arguments — the operation is idempotent: inputs and outputs are
 // distinct buffers — and remembers the winner in the context.  Skipped (built-in choice by grid instead) while the
 // stream is being captured, for launches under 1.5 M cells, after ns3d_set_autotune(ctx, 0), or with an explicit variant.
-// explicit variant / tuning off / launch too small → that answer; a choice measured earlier in this process → it; -1: unknown
+// How a pass over memory is made: PT iterations per pass (depth 2: k_pt_sweep2 with tile variant v2; 3, 4: k_pt_sweepN with
+// tile variant vn).  Explicit settings (ns3d_set_pt2_variant / _ptn_variant / _pt_depth) always win.
+struct Plan { int depth, v2, vn; bool known; };
+static const long long NS3D_DEEP_MIN_CELLS = 16ll * 1000 * 1000;    // below this three iterations per pass never paid
 template <class T>
-static int lookup_pt2_variant(const ns3d_ctx *c, int mode, const ns3d_pt_params *p, int k0, int k1)
+static Plan lookup_plan(const ns3d_ctx *c, int mode, const ns3d_pt_params *p, int k0, int k1)
 {
-    if (c->pt2_variant > 0) return c->pt2_variant;
+    Plan pl{c->pt_depth > 0 ? c->pt_depth : 2, c->pt2_variant > 0 ? c->pt2_variant : 0, c->ptn_variant, true};
     const int nk = k1 - k0;
-    if (!c->autotune || (long long)p->nx * p->ny * nk < NS3D_TWO_MIN_CELLS) return 0;
+    const long long cells = (long long)p->nx * p->ny * nk;
+    if (!c->autotune || cells < NS3D_TWO_MIN_CELLS) return pl;
+    if (c->pt2_variant > 0 && (c->pt_depth > 0 || cells < NS3D_DEEP_MIN_CELLS)) return pl;      // nothing left to decide
     std::lock_guard<std::mutex> lock(g_tuned_mutex);
     for (const auto &t : g_tuned)
         if (t.device == c->device && t.nx == p->nx && t.ny == p->ny && t.nz == p->nz && t.nk == nk &&
-            t.esize == (int)sizeof(T) && t.mode == mode)
-            return t.variant;
-    return -1;
+            t.esize == (int)sizeof(T) && t.mode == mode) {
+            if (c->pt2_variant <= 0) pl.v2 = t.variant;
+            if (c->pt_depth <= 0) pl.depth = t.depth;
+            if (c->ptn_variant <= 0) pl.vn = t.variantn;
+            return pl;
+        }
+    pl.known = false;
+    return pl;
 }
 // the measurement: runs on the caller's own arguments (idempotent: inputs and outputs are distinct buffers), blocks on
-// its events.  Called from ns3d_plan_pt, ns3d_pt_iterate and ns3d_pt_solve only — never from ns3d_pt_sweep2, whose callers
-// (z-slab schedules with an exchange in flight) must not be stalled by ≈100 extra launches.
+// its events.  Called from ns3d_plan_pt, ns3d_pt_iterate and ns3d_pt_solve only — never from ns3d_pt_sweep2 / _sweepn, whose
+// callers (z-slab schedules with an exchange in flight) must not be stalled by ≈100 extra launches.
 template <class T>
-static int tune_pt2_variant(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV,
-                            const ns3d_pt_params *p, int k0, int k1)
+static Plan tune_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV,
+                      const ns3d_pt_params *p, int k0, int k1)
 {
+    Plan pl = lookup_plan<T>(c, mode, p, k0, k1);
+    pl.known = true;
     const int nk = k1 - k0;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    if (cap != hipStreamCaptureStatusNone) return 0;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return pl; }
+    if (cap != hipStreamCaptureStatusNone) return pl;
     for (int q = 0; q < 2; ++q)
-        if (!c->tune_ev[q] && hipEventCreate(&c->tune_ev[q]) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    // candidates: variant = shape*100 + kz (ns3d.h).  Stage 1: every shape with round-filling chunks (92) and with short
-    // 16-plane chunks (which keep neighbouring tiles close in time: their overlaps then hit the L2); stage 2: the other
-    // chunk lengths for the three best shapes.  0 = the built-in choice; it wins ties.
-    static const int shapes[] = {11, 8, 9, 7, 13, 19, 12};
-    static const int stage1[] = {92, 16}, stage2[] = {94, 91, 98, 32};
-    constexpr int NS = (int)(sizeof shapes / sizeof shapes[0]);
-    auto time_variant = [&](int v, float &ms, int timed = 3) -> bool {
+        if (!c->tune_ev[q] && hipEventCreate(&c->tune_ev[q]) != hipSuccess) { (void)hipGetLastError(); return pl; }
+    // `depth` iterations per launch; ms = time of ONE launch
+    auto time_launch = [&](int depth, int v, float &ms, int timed = 3) -> bool {
         bool ok = true;
         for (int rep = 0; rep <= timed && ok; ++rep) {     // one untimed launch, then `timed` timed ones
             if (rep == 1) ok = hipEventRecord(c->tune_ev[0], s) == hipSuccess;
-            ok = ok && DISPATCHM(mode, pt_sweep2<T>(s, v, src, dst, dsrc, ddst, divV, *p, k0, k1)) == hipSuccess;
+            hipError_t e = depth == 2 ? DISPATCHM(mode, pt_sweep2<T>(s, v, src, dst, dsrc, ddst, divV, *p, k0, k1))
+                                      : DISPATCHM(mode, pt_sweepn<T>(s, depth, v, src, dst, dsrc, ddst, divV, *p, k0, k1));
+            ok = ok && e == hipSuccess;
         }
         ok = ok && hipEventRecord(c->tune_ev[1], s) == hipSuccess && hipEventSynchronize(c->tune_ev[1]) == hipSuccess &&
              hipEventElapsedTime(&ms, c->tune_ev[0], c->tune_ev[1]) == hipSuccess;
         ms /= (float)timed;
+        if (!ok) (void)hipGetLastError();
         return ok;
     };
-    int best = 0;
-    float best_ms = 0.f, ms = 0.f, shape_ms[NS];
-    if (!time_variant(0, best_ms, 6)) { (void)hipGetLastError(); return 0; }   // also brings the clocks up
-    if (!time_variant(0, best_ms)) { (void)hipGetLastError(); return 0; }
-    for (int q = 0; q < NS; ++q) {
-        shape_ms[q] = 0.f;
-        for (int kz : stage1) {
-            if (!time_variant(shapes[q] * 100 + kz, ms)) { (void)hipGetLastError(); return 0; }
-            if (shape_ms[q] == 0.f || ms < shape_ms[q]) shape_ms[q] = ms;
-            if (ms < 0.99f * best_ms) { best_ms = ms; best = shapes[q] * 100 + kz; }
+    // ---- two iterations per pass: variant = shape*100 + kz (ns3d.h).  Stage 1: every shape with round-filling chunks (92)
+    // and with short 16-plane chunks (which keep neighbouring tiles close in time: their overlaps then hit the L2); stage 2:
+    // the other chunk lengths for the three best shapes.  0 = the built-in choice; it wins ties.
+    float ms2 = 0.f;                                       // per launch of the chosen two-iteration variant
+    if (c->pt2_variant > 0) {
+        if (!time_launch(2, pl.v2, ms2, 6) || !time_launch(2, pl.v2, ms2)) return pl;
+    } else {
+        static const int shapes[] = {11, 8, 9, 7, 13, 19, 12};
+        static const int stage1[] = {92, 16}, stage2[] = {94, 91, 98, 32};
+        constexpr int NS = (int)(sizeof shapes / sizeof shapes[0]);
+        int best = 0;
+        float best_ms = 0.f, ms = 0.f, shape_ms[NS];
+        if (!time_launch(2, 0, best_ms, 6)) return pl;     // also brings the clocks up
+        if (!time_launch(2, 0, best_ms)) return pl;
+        for (int q = 0; q < NS; ++q) {
+            shape_ms[q] = 0.f;
+            for (int kz : stage1) {
+                if (!time_launch(2, shapes[q] * 100 + kz, ms)) return pl;
+                if (shape_ms[q] == 0.f || ms < shape_ms[q]) shape_ms[q] = ms;
+                if (ms < 0.99f * best_ms) { best_ms = ms; best = shapes[q] * 100 + kz; }
+            }
         }
-    }
-    for (int pick = 0; pick < 3; ++pick) {
-        int q = -1;
-        for (int r = 0; r < NS; ++r)
-            if (shape_ms[r] > 0.f && (q < 0 || shape_ms[r] < shape_ms[q])) q = r;
-        if (q < 0) break;
-        shape_ms[q] = 0.f;                                 // taken
-        for (int kz : stage2) {
-            if (!time_variant(shapes[q] * 100 + kz, ms)) { (void)hipGetLastError(); return 0; }
-            if (ms < 0.99f * best_ms) { best_ms = ms; best = shapes[q] * 100 + kz; }
+        for (int pick = 0; pick < 3; ++pick) {
+            int q = -1;
+            for (int r = 0; r < NS; ++r)
+                if (shape_ms[r] > 0.f && (q < 0 || shape_ms[r] < shape_ms[q])) q = r;
+            if (q < 0) break;
+            shape_ms[q] = 0.f;                             // taken
+            for (int kz : stage2) {
+                if (!time_launch(2, shapes[q] * 100 + kz, ms)) return pl;
+                if (ms < 0.99f * best_ms) { best_ms = ms; best = shapes[q] * 100 + kz; }
+            }
         }
+        if (best != 0) {                                   // head to head against the built-in choice, longer runs
+            float ms0 = 0.f, ms1 = 0.f;
+            if (!time_launch(2, 0, ms0, 6) || !time_launch(2, best, ms1, 6)) return pl;
+            if (!(ms1 < 0.97f * ms0)) { best = 0; best_ms = ms0; } else best_ms = ms1;
+        }
+        pl.v2 = best;
+        ms2 = best_ms;
     }
-    if (best != 0) {                                       // head to head against the built-in choice, longer runs
-        float ms0 = 0.f, ms1 = 0.f;
-        if (!time_variant(0, ms0, 6) || !time_variant(best, ms1, 6)) { (void)hipGetLastError(); return 0; }
-        if (!(ms1 < 0.97f * ms0)) best = 0;              // run-to-run noise is a few per cent: change only for a clear gain
+    // ---- three iterations per pass (k_pt_sweepN): fewer bytes per iteration, more arithmetic per byte — pays where the
+    // two-iteration pass is bandwidth-bound (FAST mode, power-of-two spacings), not where it is VALU-bound.  Taken only for
+    // a clear per-ITERATION gain, head to head.
+    const long long cells = (long long)p->nx * p->ny * nk;
+    if (c->pt_depth <= 0 && cells >= NS3D_DEEP_MIN_CELLS && nk >= 12) {
+        static const int cand[] = {100, 1100, 116, 200, 1200, 400};
+        int bestn = c->ptn_variant;
+        float best3 = 0.f, ms = 0.f;
+        if (c->ptn_variant > 0) { if (!time_launch(3, bestn, best3)) best3 = 0.f; }
+        else
+            for (int v : cand) {
+                if (!time_launch(3, v, ms)) continue;      // a shape that cannot run here (LDS / tile size)
+                if (best3 == 0.f || ms < best3) { best3 = ms; bestn = v; }
+            }
+        if (best3 > 0.f && best3 / 3.f < 0.98f * ms2 / 2.f) {
+            float a2 = 0.f, a3 = 0.f;
+            if (time_launch(2, pl.v2, a2, 6) && time_launch(3, bestn, a3, 6) && a3 / 3.f < 0.97f * a2 / 2.f) {
+                pl.depth = 3;
+                pl.vn = bestn;
+            }
+        }
+    } else if (c->pt_depth >= 3 && c->ptn_variant <= 0 && cells >= NS3D_TWO_MIN_CELLS) {
+        static const int cand[] = {100, 1100, 116, 200, 1200, 400};
+        float bestd = 0.f, ms = 0.f;
+        for (int v : cand) {
+            if (!time_launch(c->pt_depth, v, ms)) continue;
+            if (bestd == 0.f || ms < bestd) { bestd = ms; pl.vn = v; }
+        }
     }
     {
         std::lock_guard<std::mutex> lock(g_tuned_mutex);
-        g_tuned.push_back({c->device, p->nx, p->ny, p->nz, nk, (int)sizeof(T), mode, best});
+        g_tuned.push_back({c->device, p->nx, p->ny, p->nz, nk, (int)sizeof(T), mode, pl.v2, pl.depth, pl.vn});
     }
-    return best;
+    return pl;
 }
 template <class T>
-static int pick_pt2_variant(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV,
-                            const ns3d_pt_params *p, int k0, int k1, bool may_tune)
+static Plan pick_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV,
+                      const ns3d_pt_params *p, int k0, int k1, bool may_tune)
 {
-    int v = lookup_pt2_variant<T>(c, mode, p, k0, k1);
-    if (v < 0) v = may_tune ? tune_pt2_variant<T>(c, s, mode, src, dst, dsrc, ddst, divV, p, k0, k1) : 0;
-    return v;
+    Plan pl = lookup_plan<T>(c, mode, p, k0, k1);
+    if (!pl.known && may_tune) pl = tune_plan<T>(c, s, mode, src, dst, dsrc, ddst, divV, p, k0, k1);
+    return pl;
+}
+// one pass of `depth` (2…4) PT iterations
+template <class T>
+static hipError_t launch_pass(ns3d_ctx *c, hipStream_t s, int depth, const Plan &pl, const T *src, T *dst, const T *dsrc, T *ddst,
+                              const T *divV, const ns3d_pt_params *p, int k0, int k1)
+{
+    const int mode = mode_of(c, p->dx, p->dy, p->dz);
+    c->last_depth = depth;
+    if (depth == 2) {
+        c->last_pt2 = pl.v2;
+        return DISPATCHM(mode, pt_sweep2<T>(s, pl.v2, src, dst, dsrc, ddst, divV, *p, k0, k1));
+    }
+    c->last_ptn = pl.vn;
+    return DISPATCHM(mode, pt_sweepn<T>(s, depth, pl.vn, src, dst, dsrc, ddst, divV, *p, k0, k1));
+}
+// iterations of the next pass when `rem` remain until the next residual check / the end
+static int next_depth(const Plan &pl, bool blocked, int rem)
+{
+    if (!blocked || rem < 2) return 1;
+    if (rem >= pl.depth) return (rem == pl.depth + 1 && pl.depth >= 3) ? pl.depth - 1 : pl.depth;   // 4 = 2+2, not 3+1
+    return rem >= 3 ? 3 : 2;
 }
 template <class T>
 static hipError_t launch_pt2(ns3d_ctx *c, hipStream_t s, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV,
                              const ns3d_pt_params *p, int k0, int k1, bool may_tune)
 {
-    const int mode = mode_of(c, p->dx, p->dy, p->dz);
-    const int v = pick_pt2_variant<T>(c, s, mode, src, dst, dsrc, ddst, divV, p, k0, k1, may_tune);
-    c->last_pt2 = v;
-    return DISPATCHM(mode, pt_sweep2<T>(s, v, src, dst, dsrc, ddst, divV, *p, k0, k1));
+    const Plan pl = pick_plan<T>(c, s, mode_of(c, p->dx, p->dy, p->dz), src, dst, dsrc, ddst, divV, p, k0, k1, may_tune);
+    return launch_pass<T>(c, s, 2, pl, src, dst, dsrc, ddst, divV, p, k0, k1);
 }
 
 // ---- what the multi-GPU layer enqueues on its ranks' contexts (ns3d_internal.h) ----------------------------------
@@ -399,11 +484,19 @@ hipError_t ns3d_enqueue_pt2(ns3d_ctx *c, hipStream_t s, const T *src, T *dst, co
     return launch_pt2<T>(c, s, src, dst, dsrc, ddst, divV, p, k0, k1, false);
 }
 template <class T>
+hipError_t ns3d_enqueue_pass(ns3d_ctx *c, hipStream_t s, int depth, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV,
+                             const ns3d_pt_params *p, int k0, int k1)
+{
+    const Plan pl = lookup_plan<T>(c, mode_of(c, p->dx, p->dy, p->dz), p, k0, k1);
+    return launch_pass<T>(c, s, depth, pl, src, dst, dsrc, ddst, divV, p, k0, k1);
+}
+template <class T>
 int ns3d_plan_pt_internal(ns3d_ctx *c, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV, const ns3d_pt_params *p,
                           int k0, int k1)
 {
-    (void)pick_pt2_variant<T>(c, c->stream, mode_of(c, p->dx, p->dy, p->dz), src, dst, dsrc, ddst, divV, p, k0, k1, true);
-    return NS3D_OK;
+    const Plan pl = pick_plan<T>(c, c->stream, mode_of(c, p->dx, p->dy, p->dz), src, dst, dsrc, ddst, divV, p, k0, k1, true);
+    c->last_pt2 = pl.v2; c->last_ptn = pl.vn; c->last_depth = pl.depth;
+    return pl.depth;
 }
 template <class T>
 hipError_t ns3d_enqueue_pt1(ns3d_ctx *c, hipStream_t s, const T *src, T *dst, T *d, const T *divV, const ns3d_pt_params *p,
@@ -425,6 +518,8 @@ hipError_t ns3d_enqueue_strip_inner(ns3d_ctx *c, hipStream_t s, const T *A, T *o
 #define NS3D_INST_INTERNAL(T)                                                                                       \
     template hipError_t ns3d_enqueue_pt2<T>(ns3d_ctx *, hipStream_t, const T *, T *, const T *, T *, const T *,      \
                                             const ns3d_pt_params *, int, int);                                      \
+    template hipError_t ns3d_enqueue_pass<T>(ns3d_ctx *, hipStream_t, int, const T *, T *, const T *, T *, const T *, \
+                                             const ns3d_pt_params *, int, int);                                     \
     template int ns3d_plan_pt_internal<T>(ns3d_ctx *, const T *, T *, const T *, T *, const T *,                     \
                                           const ns3d_pt_params *, int, int);                                        \
     template hipError_t ns3d_enqueue_pt1<T>(ns3d_ctx *, hipStream_t, const T *, T *, T *, const T *,                 \
@@ -435,6 +530,10 @@ hipError_t ns3d_enqueue_strip_inner(ns3d_ctx *c, hipStream_t s, const T *A, T *o
 NS3D_INST_INTERNAL(double)
 NS3D_INST_INTERNAL(float)
 #undef NS3D_INST_INTERNAL
+
+template <class T>
+static hipError_t enqueue_iters(ns3d_ctx *c, hipStream_t s, int n, bool two, T *&src, T *&dst, T *&dsrc, T *&ddst,
+                                const T *divV, const ns3d_pt_params *p, bool may_tune);
 
 // n_iters fused sweeps, result left in Pr (one D2D copy when n_iters is odd).  With z halos the scratch
 // buffer's halo planes are seeded from Pr first (a sweep never writes them).
@@ -454,19 +553,8 @@ static int pt_iterate_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_p
     T *dsrc = D, *ddst = nullptr;
     const bool two = use_two(c, p) && !p->z_lo_is_halo && !p->z_hi_is_halo && n_iters >= 2;
     if (two && (rc = ensure_pingpong_d<T>(c, p, &ddst))) return rc;
-    for (int it = 0; it < n_iters;) {
-        hipError_t e;
-        if (two && it + 2 <= n_iters) {
-            e = launch_pt2<T>(c, c->stream, src, dst, dsrc, ddst, divV, p, 1, p->nz - 1, true);
-            T *t = dsrc; dsrc = ddst; ddst = t;
-            it += 2;
-        } else {
-            e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_sweep<T>(c->stream, c->pt_variant, src, dst, dsrc, divV, *p, 1, p->nz - 1));
-            it += 1;
-        }
-        if (e != hipSuccess) return fail(NS3D_ERR_HIP, "pt_sweep launch: %s", hipGetErrorString(e));
-        T *t = src; src = dst; dst = t;
-    }
+    hipError_t e = enqueue_iters<T>(c, c->stream, n_iters, two, src, dst, dsrc, ddst, divV, p, true);
+    if (e != hipSuccess) return fail(NS3D_ERR_HIP, "pt_sweep launch: %s", hipGetErrorString(e));
     if (dsrc != D)
         HIPCHK(c, hipMemcpyAsync(D, dsrc, (size_t)(p->nx - 2) * (p->ny - 2) * (p->nz - 2) * sizeof(T),
                                  hipMemcpyDeviceToDevice, c->stream));
@@ -479,18 +567,20 @@ static int pt_iterate_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_p
 // enqueue exactly n iterations on stream s (two per pass where allowed) and leave the result pointers in src/dsrc
 template <class T>
 static hipError_t enqueue_iters(ns3d_ctx *c, hipStream_t s, int n, bool two, T *&src, T *&dst, T *&dsrc, T *&ddst,
-                                const T *divV, const ns3d_pt_params *p)
+                                const T *divV, const ns3d_pt_params *p, bool may_tune)
 {
     hipError_t e = hipSuccess;
+    Plan pl{2, 0, 0, true};
+    if (two && n >= 2)
+        pl = pick_plan<T>(c, s, mode_of(c, p->dx, p->dy, p->dz), src, dst, dsrc, ddst, divV, p, 1, p->nz - 1, may_tune);
     for (int it = 0; it < n && e == hipSuccess;) {
-        if (two && it + 2 <= n) {
-            e = launch_pt2<T>(c, s, src, dst, dsrc, ddst, divV, p, 1, p->nz - 1, true);
+        const int d = next_depth(pl, two, n - it);
+        if (d >= 2) {
+            e = launch_pass<T>(c, s, d, pl, src, dst, dsrc, ddst, divV, p, 1, p->nz - 1);
             T *t = dsrc; dsrc = ddst; ddst = t;
-            it += 2;
-        } else {
+        } else
             e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_sweep<T>(s, c->pt_variant, src, dst, dsrc, divV, *p, 1, p->nz - 1));
-            it += 1;
-        }
+        it += d;
         T *t = src; src = dst; dst = t;
     }
     return e;
@@ -505,7 +595,8 @@ static int run_block_graph(ns3d_ctx *c, hipStream_t s, int n, bool two, T *&src,
     const int mode = mode_of(c, p->dx, p->dy, p->dz);
     for (auto &g : c->graphs)
         if (g.src == src && g.dst == dst && g.dsrc == dsrc && g.ddst == ddst && g.rhs == divV && g.n == n && g.two == two &&
-            g.mode == mode && g.v1 == c->pt_variant && g.v2 == c->pt2_variant && g.esize == (int)sizeof(T) &&
+            g.mode == mode && g.v1 == c->pt_variant && g.v2 == c->pt2_variant && g.vn == c->ptn_variant && g.depth == c->pt_depth &&
+            g.esize == (int)sizeof(T) &&
             std::memcmp(&g.p, p, sizeof *p) == 0) {
             HIPCHK(c, hipGraphLaunch(g.exec, s));
             src = (T *)g.src_out; dst = (T *)g.dst_out; dsrc = (T *)g.dsrc_out; ddst = (T *)g.ddst_out;
@@ -514,10 +605,10 @@ static int run_block_graph(ns3d_ctx *c, hipStream_t s, int n, bool two, T *&src,
     if (c->graphs.size() >= 16) c->clear_graphs();
     ns3d_ctx::BlockGraph g;
     g.src = src; g.dst = dst; g.dsrc = dsrc; g.ddst = ddst; g.rhs = divV; g.n = n; g.two = two; g.mode = mode;
-    g.v1 = c->pt_variant; g.v2 = c->pt2_variant; g.esize = (int)sizeof(T); g.p = *p;
+    g.v1 = c->pt_variant; g.v2 = c->pt2_variant; g.vn = c->ptn_variant; g.depth = c->pt_depth; g.esize = (int)sizeof(T); g.p = *p;
     hipGraph_t graph = nullptr;
     HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    hipError_t e = enqueue_iters<T>(c, s, n, two, src, dst, dsrc, ddst, divV, p);
+    hipError_t e = enqueue_iters<T>(c, s, n, two, src, dst, dsrc, ddst, divV, p, false);
     hipError_t e2 = hipStreamEndCapture(s, &graph);
     if (e != hipSuccess || e2 != hipSuccess) {
         if (graph) (void)hipGraphDestroy(graph);
@@ -564,14 +655,14 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
     }
     // settle the tile choice of the two-iteration sweep now (eagerly, into the scratch buffers): inside a stream capture
     // it could only be looked up
-    if (two) (void)pick_pt2_variant<T>(c, s, mode_of(c, p->dx, p->dy, p->dz), src, dst, dsrc, ddst, divV, p, 1, p->nz - 1, true);
+    if (two) (void)pick_plan<T>(c, s, mode_of(c, p->dx, p->dy, p->dz), src, dst, dsrc, ddst, divV, p, 1, p->nz - 1, true);
     while (iter < niter) {
         // iterations until the next residual check (multi.jl:464) or the end of the budget
         const int n = nchk > 0 ? std::min(nchk - iter % nchk, niter - iter) : niter - iter;
         if (graphs && n == nchk) {
             if ((rc = run_block_graph<T>(c, s, n, two, src, dst, dsrc, ddst, divV, p))) return rc;
         } else {
-            hipError_t e = enqueue_iters<T>(c, s, n, two, src, dst, dsrc, ddst, divV, p);
+            hipError_t e = enqueue_iters<T>(c, s, n, two, src, dst, dsrc, ddst, divV, p, true);
             if (e != hipSuccess) return fail(NS3D_ERR_HIP, "pt_sweep launch: %s", hipGetErrorString(e));
         }
         iter += n;
@@ -806,8 +897,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
             return fail(NS3D_ERR_ARG, "ns3d_pt_sweepn: z-slab ranks pass ghost-extended buffers, not halo flags"); \
         if (k0 < 1 || k1 > p->nz - 1 || k0 > k1)                                                             \
             return fail(NS3D_ERR_ARG, "ns3d_pt_sweepn: plane range [%d,%d) outside [1,%d)", k0, k1, p->nz - 1); \
-        hipError_t e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_sweepn<T>(c->stream, nlev, c->ptn_variant, Pr_in, Pr_out, \
-                                                                     dPrdtau, dPrdtau_out, divV, *p, k0, k1)); \
+        hipError_t e = ns3d_enqueue_pass<T>(c, c->stream, nlev, Pr_in, Pr_out, dPrdtau, dPrdtau_out, divV, p, k0, k1); \
         if (e == hipErrorInvalidValue)                                                                       \
             return fail(NS3D_ERR_ARG, "ns3d_pt_sweepn: tile variant %d cannot run %d levels", c->ptn_variant, nlev); \
         return finish(c, e, "pt_sweepn");                                                                    \
@@ -822,8 +912,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
             return fail(NS3D_ERR_ARG, "ns3d_plan_pt: input and output buffers must differ");                 \
         if (k0 < 1 || k1 > p->nz - 1 || k0 > k1)                                                             \
             return fail(NS3D_ERR_ARG, "ns3d_plan_pt: plane range [%d,%d) outside [1,%d)", k0, k1, p->nz - 1);\
-        (void)pick_pt2_variant<T>(c, c->stream, mode_of(c, p->dx, p->dy, p->dz), Pr_in, Pr_out, dPrdtau,     \
-                                  dPrdtau_out, divV, p, k0, k1, true);                                       \
+        (void)ns3d_plan_pt_internal<T>(c, Pr_in, Pr_out, dPrdtau, dPrdtau_out, divV, p, k0, k1);             \
         return finish(c, hipSuccess, "plan_pt");                                                             \
     }                                                                                                        \
     extern "C" int ns3d_residual_max_##S(ns3d_ctx *c, const T *Pr, const T *divV, const ns3d_pt_params *p,   \

@@ -28,12 +28,14 @@ struct ns3d_ctx {
     int graph_mode;  // HIP-graph replay of residual-check blocks: -1 auto (launch-bound grids), 0 off, 1 on
     int autotune;    // time the tile shapes of the two-iteration sweep on first use of a grid (pt2_variant == 0 only)
     int last_pt2;    // variant of the latest two-iteration launch (0: built-in choice by grid)
+    int last_ptn;    // variant of the latest N-iteration launch
+    int last_depth;  // PT iterations of the latest multi-iteration pass
     hipEvent_t tune_ev[2];
     hipEvent_t fence;
     struct BlockGraph {
         const void *src, *dst, *dsrc, *ddst, *rhs;
         void *src_out, *dst_out, *dsrc_out, *ddst_out;
-        int n, mode, v1, v2, esize;
+        int n, mode, v1, v2, vn, depth, esize;
         bool two;
         ns3d_pt_params p;
         hipGraphExec_t exec;
@@ -101,7 +103,11 @@ int ns3d_check_pt_params(const ns3d_pt_params *p, const char *fn);
 template <class T>
 hipError_t ns3d_enqueue_pt2(ns3d_ctx *c, hipStream_t s, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV,
                             const ns3d_pt_params *p, int k0, int k1);
-// the plan phase of ns3d_plan_pt on the context's stream (blocks on its own events)
+// one pass of `depth` (2…4) PT iterations on stream s with the planned tile shapes (looked up; never measured here)
+template <class T>
+hipError_t ns3d_enqueue_pass(ns3d_ctx *c, hipStream_t s, int depth, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV,
+                             const ns3d_pt_params *p, int k0, int k1);
+// the plan phase of ns3d_plan_pt on the context's stream (blocks on its own events); returns the planned depth
 template <class T>
 int ns3d_plan_pt_internal(ns3d_ctx *c, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV, const ns3d_pt_params *p,
                           int k0, int k1);

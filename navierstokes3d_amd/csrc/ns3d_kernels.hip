@@ -1,8 +1,12 @@
 // ns3d_kernels.hip — hand-written HIP kernels (gfx950 / CDNA4, wave64) for the NavierStokes3D hot path.
 //
-// Compiled twice by navierstokes3d_amd/build.py:
+// Compiled four times by navierstokes3d_amd/build.py:
 //   -DNS3D_MODE_STRICT -ffp-contract=off   → namespace ns3d_strict : the reference's operation order, IEEE
 //                                            divisions, no FMA  (bit-identical to oracle/ns3d_oracle.c)
+//   … -DNS3D_EXACT_RECIP                   → namespace ns3d_strictx: same bits, x/d by the correctly rounded
+//                                            divisor-known-in-advance sequence (guarded; plain divisions otherwise)
+//   … -DNS3D_POW2_RECIP                    → namespace ns3d_strictp: same bits when dx, dy, dz are powers of two
+//                                            (x/d ≡ x·(1/d) exactly), chosen by the host for such grids (512³ with lx = 1)
 //   -DNS3D_MODE_FAST   -ffp-contract=fast  → namespace ns3d_fast   : reciprocal constants + FMA
 //
 // Reference kernel bodies restated here: scripts/NavierStokes3D_multi_gpu.jl:15-281 ("multi.jl"),
@@ -16,6 +20,9 @@
 #define NS3D_FASTMATH 1
 #elif defined(NS3D_MODE_STRICT) && defined(NS3D_EXACT_RECIP)
 #define NS3D_NS ns3d_strictx
+#define NS3D_FASTMATH 0
+#elif defined(NS3D_MODE_STRICT) && defined(NS3D_POW2_RECIP)
+#define NS3D_NS ns3d_strictp
 #define NS3D_FASTMATH 0
 #elif defined(NS3D_MODE_STRICT)
 #define NS3D_NS ns3d_strict
@@ -86,6 +93,16 @@ __device__ __forceinline__ float div_by_known(float x, float d, float r)
 #define DIV_YY(v) ((v)*g.rdy2)
 #define DIV_ZZ(v) ((v)*g.rdz2)
 #define DIV_3(v) ((v) * (T)(1.0 / 3.0))
+#elif defined(NS3D_POW2_RECIP)
+// Every spacing is a power of two (checked on the host): r = 1/d is exact, so x·r and x/d are the SAME real number and
+// round identically — always, overflow and subnormal results included; x/d/d is two such steps.  No guard, no fall-back.
+#define DIV_X(v) ((v)*g.rdx)
+#define DIV_Y(v) ((v)*g.rdy)
+#define DIV_Z(v) ((v)*g.rdz)
+#define DIV_XX(v) (((v)*g.rdx) * g.rdx)
+#define DIV_YY(v) (((v)*g.rdy) * g.rdy)
+#define DIV_ZZ(v) (((v)*g.rdz) * g.rdz)
+#define DIV_3(v) ((v) / (T)3.0)
 #elif defined(NS3D_EXACT_RECIP)
 #define DIV_X(v) div_by_known((v), g.dx, g.rdx)
 #define DIV_Y(v) div_by_known((v), g.dy, g.rdy)

@@ -58,4 +58,5 @@
 
 NS3D_LAUNCHER_DECLS(ns3d_strict)
 NS3D_LAUNCHER_DECLS(ns3d_strictx)
+NS3D_LAUNCHER_DECLS(ns3d_strictp)
 NS3D_LAUNCHER_DECLS(ns3d_fast)

@@ -23,7 +23,7 @@
 // Pseudo-transient loop of a slab rank (ns3d_slab_*, ns3d_pt_solve_slab): the single-GPU fast path advances `depth` PT
 // iterations per pass over memory.  Level 2 of a rank's first own plane needs level 1 of the seam halo plane, which needs
 // the previous iterate one plane further out: the solve state therefore lives in library-owned buffers EXTENDED by
-// G = depth−1 ghost planes per seam.  Every pass recomputes the lower levels on the ghost planes (bit-identical on both
+// G = depth−1 ghost planes per seam (depth = the most iterations a pass may advance, 3 by default).  Every pass recomputes the lower levels on the ghost planes (bit-identical on both
 // ranks: same inputs, same arithmetic), afterwards the depth outermost own planes of Pr and the G outermost own planes of
 // dPrdτ travel to the neighbour (depth=2: 3 planes per two iterations instead of the reference's ≥2 exchanges per single
 // iteration, multi.jl:460-463,182).  The seam-adjacent output planes are swept first, their exchange is posted on the
@@ -122,7 +122,8 @@ struct ns3d_mgpu {
     bool rccl = false;
     ncclComm_t comm = nullptr;
     int rccl_ranks = 0;
-    int depth = 2;                // PT iterations per pass over memory (1: single sweeps, plain one-plane halo)
+    int depth = 3;                // most PT iterations a pass may advance = ghost depth + 1 (1: single sweeps, plain one-plane halo)
+    int pass_depth = 2;           // iterations per pass actually used (ns3d_slab_plan may raise it to `depth`; same on every rank)
     // loaded solve
     bool loaded = false;
     int esize = 0, G = 0;
@@ -250,7 +251,8 @@ ns3d_mgpu *new_mgpu(int P, int nx, int ny, int nz, int flags, const char *fn)
     if (nx < 3 || ny < 3 || nz < 3) { fail(NS3D_ERR_ARG, "%s: local grid %dx%dx%d too small (need >= 3)", fn, nx, ny, nz); return nullptr; }
     ns3d_mgpu *m = new ns3d_mgpu();
     m->P = P; m->nx = nx; m->ny = ny; m->nz = nz; m->flags = flags;
-    if (const char *ev = std::getenv("NS3D_SLAB_DEPTH")) m->depth = std::max(1, std::min(2, std::atoi(ev)));
+    if (const char *ev = std::getenv("NS3D_SLAB_DEPTH")) m->depth = std::max(1, std::min(3, std::atoi(ev)));
+    m->pass_depth = std::min(2, m->depth);
     return m;
 }
 
@@ -309,12 +311,12 @@ int slab_exchange(ns3d_mgpu *m, int ip_of_all, int id_of_all, bool wait)
     return wait ? exchange_end(m) : NS3D_OK;
 }
 
-// one pass: `its` (1 or 2) PT iterations on every local rank, seam planes first, exchange behind the interior sweep
+// one pass: `its` (1 … depth) PT iterations on every local rank, seam planes first, exchange behind the interior sweep
 template <class T>
 int slab_pass(ns3d_mgpu *m, int its)
 {
     const int ip = m->loc[0].st.ip, idd = m->loc[0].st.id;          // the ranks advance in lockstep
-    const int idd_out = its == 2 ? idd ^ 1 : idd;
+    const int idd_out = its >= 2 ? idd ^ 1 : idd;
     struct Rng { int lo_end, hi_beg; };
     std::vector<Rng> rng(m->loc.size());
     auto sweep = [&](MRank &r, int a, int b) -> int {
@@ -322,9 +324,9 @@ int slab_pass(ns3d_mgpu *m, int its)
         const ns3d_pt_params pe = ext_params(m, r);
         ns3d_device_guard g(r.device);
         hipError_t e;
-        if (its == 2)
-            e = ns3d_enqueue_pt2<T>(r.ctx, compute(r), (const T *)r.st.P[ip], (T *)r.st.P[ip ^ 1], (const T *)r.st.D[idd],
-                                    (T *)r.st.D[idd_out], (const T *)r.st.R, &pe, a, b);
+        if (its >= 2)
+            e = ns3d_enqueue_pass<T>(r.ctx, compute(r), its, (const T *)r.st.P[ip], (T *)r.st.P[ip ^ 1], (const T *)r.st.D[idd],
+                                     (T *)r.st.D[idd_out], (const T *)r.st.R, &pe, a, b);
         else
             e = ns3d_enqueue_pt1<T>(r.ctx, compute(r), (const T *)r.st.P[ip], (T *)r.st.P[ip ^ 1], (T *)r.st.D[idd],
                                     (const T *)r.st.R, &pe, a, b);
@@ -355,7 +357,8 @@ int slab_iterate(ns3d_mgpu *m, int n)
 {
     int rc;
     for (int it = 0; it < n;) {
-        const int its = (m->depth >= 2 && it + 2 <= n) ? 2 : 1;
+        const int rem = n - it, d = std::min(m->pass_depth, m->G + 1);
+        int its = rem >= d ? ((rem == d + 1 && d >= 3) ? d - 1 : d) : rem;      // 4 = 2+2, not 3+1
         if ((rc = slab_pass<T>(m, its))) return rc;
         it += its;
     }
@@ -409,7 +412,8 @@ int slab_load(ns3d_mgpu *m, const T *const *Pr, const T *const *D, const T *cons
         return fail(NS3D_ERR_ARG, "ns3d_slab_load: gpu.jl's boundary set is single-device");
     if (m->nz < 4 && m->P > 1) return fail(NS3D_ERR_ARG, "ns3d_slab_load: z-slab ranks need at least two interior planes");
     m->p = *p;
-    m->G = m->depth - 1;
+    // a rank sends its G+1 outermost OWN planes: slabs thinner than that get fewer ghost planes (and shallower passes)
+    m->G = (m->P > 1 ? std::min(m->depth, m->nz - 2) : m->depth) - 1;
     m->esize = (int)sizeof(T);
     for (size_t l = 0; l < m->loc.size(); ++l) {
         MRank &r = m->loc[l];
@@ -461,22 +465,42 @@ int slab_store(ns3d_mgpu *m, T *const *Pr, T *const *D)
     return NS3D_OK;
 }
 
-// the two-iteration sweep's tile shape for the interior range of every rank: measured once, with no exchange in flight
+// Tile shapes and iterations per pass for the interior range of every rank: measured once, with no exchange in flight.  The
+// ranks must advance in lockstep, so the pass depth is the MINIMUM of what the ranks measured (ncclAllReduce(min) across
+// processes), capped by the ghost depth.
 template <class T>
 int slab_plan(ns3d_mgpu *m)
 {
-    if (m->depth < 2) return NS3D_OK;
-    for (MRank &r : m->loc) {
-        const Ext<T> e(m, r);
-        const int np = m->G + 1;
-        const int a = has_lower(m, r) ? std::min(e.k0 + np, e.k1) : e.k0, b = has_upper(m, r) ? std::max(e.k1 - np, a) : e.k1;
-        if (b - a < 2) continue;
-        const ns3d_pt_params pe = ext_params(m, r);
-        // outputs go to the buffers the next pass overwrites anyway
-        int rc = ns3d_plan_pt_internal<T>(r.ctx, (const T *)r.st.P[r.st.ip], (T *)r.st.P[r.st.ip ^ 1], (const T *)r.st.D[r.st.id],
-                                          (T *)r.st.D[r.st.id ^ 1], (const T *)r.st.R, &pe, a, b);
-        if (rc) return rc;
+    int depth = m->G + 1;
+    if (depth >= 2) {
+        for (MRank &r : m->loc) {
+            const Ext<T> e(m, r);
+            const int np = m->G + 1;
+            const int a = has_lower(m, r) ? std::min(e.k0 + np, e.k1) : e.k0, b = has_upper(m, r) ? std::max(e.k1 - np, a) : e.k1;
+            if (b - a < 2) {        // nothing to measure on: two iterations per pass unless the context asks for more
+                depth = std::min(depth, r.ctx->pt_depth >= 2 ? r.ctx->pt_depth : 2);
+                continue;
+            }
+            const ns3d_pt_params pe = ext_params(m, r);
+            ns3d_device_guard g(r.device);
+            // outputs go to the buffers the next pass overwrites anyway
+            const int d = ns3d_plan_pt_internal<T>(r.ctx, (const T *)r.st.P[r.st.ip], (T *)r.st.P[r.st.ip ^ 1],
+                                                   (const T *)r.st.D[r.st.id], (T *)r.st.D[r.st.id ^ 1], (const T *)r.st.R, &pe, a, b);
+            depth = std::min(depth, std::max(2, d));
+        }
     }
+    if (m->rccl) {
+        MRank &r = m->loc[0];
+        ns3d_device_guard g(r.device);
+        hipStream_t s = compute(r);
+        r.ctx->key_host[3] = ~(unsigned long long)depth;           // min through the max reduction
+        HIPCHK(0, hipMemcpyAsync(r.ctx->key_dev + 3, r.ctx->key_host + 3, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+        NCCLCHK(g_rccl.AllReduce(r.ctx->key_dev + 3, r.ctx->key_dev + 3, 1, ncclUint64, ncclMax, m->comm, s));
+        HIPCHK(0, hipMemcpyAsync(r.ctx->key_host + 3, r.ctx->key_dev + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(0, hipStreamSynchronize(s));
+        depth = (int)~r.ctx->key_host[3];
+    }
+    m->pass_depth = std::max(1, std::min(depth, m->G + 1));
     return NS3D_OK;
 }
 
@@ -696,13 +720,15 @@ ns3d_ctx *ns3d_mgpu_ctx(ns3d_mgpu *m, int local) { return (m && local >= 0 && lo
 int ns3d_mgpu_nz_g(const ns3d_mgpu *m) { return m ? m->P * (m->nz - 2) + 2 : -1; }
 const char *ns3d_mgpu_transport(const ns3d_mgpu *m) { return !m ? "" : (m->rccl ? "rccl" : "peer"); }
 int ns3d_mgpu_rccl_ranks(const ns3d_mgpu *m) { return m ? m->rccl_ranks : -1; }
+int ns3d_mgpu_pass_depth(const ns3d_mgpu *m) { return m ? m->pass_depth : -1; }
 
 int ns3d_mgpu_set_temporal(ns3d_mgpu *m, int depth)
 {
     CHECK_M(m);
-    if (depth < 1 || depth > 2) return fail(NS3D_ERR_ARG, "ns3d_mgpu_set_temporal: depth %d (1 or 2)", depth);
+    if (depth < 1 || depth > 3) return fail(NS3D_ERR_ARG, "ns3d_mgpu_set_temporal: depth %d (1 … 3)", depth);
     if (m->loaded && depth != m->depth) m->loaded = false;      // ghost depth changes: the state must be loaded again
     m->depth = depth;
+    m->pass_depth = std::min(2, depth);                         // until ns3d_slab_plan measures
     return NS3D_OK;
 }
 

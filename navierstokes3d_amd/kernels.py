@@ -111,6 +111,13 @@ class Context:
         """Variant (shape·100 + z-chunk) of the latest two-iteration launch; 0 = built-in choice by grid."""
         return int(self.lib.ns3d_last_pt2_variant(self.handle))
 
+    def last_ptn_variant(self):
+        return int(self.lib.ns3d_last_ptn_variant(self.handle))
+
+    def last_pt_depth(self):
+        """PT iterations of the latest multi-iteration pass (after plan_pt: the planned depth)."""
+        return int(self.lib.ns3d_last_pt_depth(self.handle))
+
     def set_pt2_variant(self, v):
         """Temporal blocking (two PT iterations per pass) in pt_iterate / pt_solve: v < 0 off, 0 default tile."""
         L.check(self.lib.ns3d_set_pt2_variant(self.handle, int(v)))

@@ -65,7 +65,7 @@ SIGNATURES = {
 }
 CONTEXT_SYMBOLS = ["ns3d_version", "ns3d_last_error", "ns3d_create", "ns3d_destroy", "ns3d_flags",
                    "ns3d_set_stream", "ns3d_use_own_stream", "ns3d_get_stream", "ns3d_sync", "ns3d_set_pt_variant",
-                   "ns3d_set_pt2_variant", "ns3d_set_ptn_variant", "ns3d_set_pt_depth", "ns3d_set_graph_mode", "ns3d_set_autotune", "ns3d_last_pt2_variant"]
+                   "ns3d_set_pt2_variant", "ns3d_set_ptn_variant", "ns3d_set_pt_depth", "ns3d_set_graph_mode", "ns3d_set_autotune", "ns3d_last_pt2_variant", "ns3d_last_ptn_variant", "ns3d_last_pt_depth"]
 
 
 _PP = C.POINTER(C.c_void_p)      # T *const *  — one device pointer per local rank (field-major for field lists)
@@ -82,6 +82,7 @@ MGPU_SYMBOLS = {
     "ns3d_mgpu_nz_g": (_I, [_P]),
     "ns3d_mgpu_transport": (C.c_char_p, [_P]),
     "ns3d_mgpu_rccl_ranks": (_I, [_P]),
+    "ns3d_mgpu_pass_depth": (_I, [_P]),
     "ns3d_mgpu_sync": (_I, [_P]),
     "ns3d_max_g": (_I, [_P, C.POINTER(_D), C.POINTER(_D)]),
     "ns3d_mgpu_set_temporal": (_I, [_P, _I]),
@@ -140,6 +141,10 @@ def load():
     lib.ns3d_set_autotune.argtypes = [_P, _I]
     lib.ns3d_last_pt2_variant.argtypes = [_P]
     lib.ns3d_last_pt2_variant.restype = _I
+    lib.ns3d_last_ptn_variant.argtypes = [_P]
+    lib.ns3d_last_ptn_variant.restype = _I
+    lib.ns3d_last_pt_depth.argtypes = [_P]
+    lib.ns3d_last_pt_depth.restype = _I
     for name, args in SIGNATURES.items():
         for suf in ("f64", "f32"):
             fn = getattr(lib, "ns3d_%s_%s" % (name, suf))

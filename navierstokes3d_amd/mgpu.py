@@ -166,7 +166,12 @@ class MultiGpu:
                                               C.byref(p)))
 
     def slab_plan(self):
+        """Measure tile shapes and iterations per pass for the loaded state's interior sweeps (same depth on every rank)."""
         L.check(self.lib.ns3d_slab_plan(self.handle))
+        return self.pass_depth()
+
+    def pass_depth(self):
+        return int(self.lib.ns3d_mgpu_pass_depth(self.handle))
 
     def slab_iterate(self, n):
         L.check(self.lib.ns3d_slab_iterate(self.handle, int(n)))

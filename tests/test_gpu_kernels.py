@@ -341,3 +341,48 @@ def test_full_size_512_cubed_substeps_against_oracle_subslab(hip, oracle):
     check("advect", ["vx", "vx", "vy", "vy", "vz", "vz", "c", "c"], (g["dt"], g["dx"], g["dy"], g["dz"], True),
           [0, 2, 4, 6], scales={1: vs, 3: vs, 5: vs})
     ctx.close()
+
+
+POW2 = [dict(dx=1.0 / 64, dy=1.0 / 32, dz=1.0 / 128), dict(dx=0.5, dy=2.0, dz=1.0), dict(dx=2.0 ** -20, dy=2.0 ** -3, dz=4.0)]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("sp", POW2)
+def test_power_of_two_spacings_strict_bitexact(hip, oracle, sp, dtype):
+    """Grids whose spacings are powers of two (512³ with lx = 1: dx = 2⁻⁹) run STRICT mode in the `ns3d_strictp` build, where
+    x/dx is x·(1/dx) — the same real number, hence the same rounding, always (d > 1 and d < 1, overflow and subnormal
+    results included).  Every kernel with a division against the oracle's plain divisions, bit for bit, including values
+    that under/overflow when scaled."""
+    import torch
+    grid = (70, 9, 7)
+    nx, ny, nz = grid
+    g = dict(geometry(*grid)); g.update(sp)
+    ctx = hip.Context(0, "strict")
+
+    def both(name, kinds, scalars, out_idx, seed0, scale=1.0, kwargs=None):
+        kwargs = kwargs or {}
+        host = [np.asfortranarray((a * scale).astype(dtype)) for a in fields(nx, ny, nz, kinds, seed0)]
+        ref = [a.copy(order="F") for a in host]
+        getattr(oracle, name)(*ref, *scalars, **kwargs)
+        dev = [hip.from_numpy(a) for a in host]
+        getattr(hip, name)(*dev, *scalars, ctx=ctx, **kwargs)
+        torch.cuda.synchronize()
+        for q in out_idx:
+            got = hip.to_numpy(dev[q])
+            assert got.view(np.uint8).tobytes() == ref[q].view(np.uint8).tobytes() or np.array_equal(got, ref[q], equal_nan=True), \
+                "%s output %d differs on spacings %r (scale %g)" % (name, q, sp, scale)
+
+    big = 1e300 if dtype == np.float64 else 1e36
+    tiny = 1e-305 if dtype == np.float64 else 1e-42
+    for scale in (1.0, big, tiny):
+        both("update_tau", ["c", "c", "c", "s", "s", "s", "vx", "vy", "vz"], (g["mu"], g["dx"], g["dy"], g["dz"]), range(6), 1, scale)
+        both("predict_V", ["vx", "vy", "vz", "c", "c", "c", "s", "s", "s"], (g["rho"], g["g"], g["dt"], g["dx"], g["dy"], g["dz"]),
+             range(3), 2, scale)
+        both("update_divV", ["c", "vx", "vy", "vz"], (g["dx"], g["dy"], g["dz"]), [0], 3, scale)
+        both("update_dPrdtau", ["c", "i", "c"], (g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"]), [1], 4, scale)
+        both("compute_res", ["i", "c", "c"], (g["rho"], g["dt"], g["dx"], g["dy"], g["dz"]), [0], 5, scale)
+        both("correct_V", ["vx", "vy", "vz", "c"], (g["dt"], g["rho"], g["dx"], g["dy"], g["dz"]), range(3), 6, scale)
+    cfl = 0.7 * min(g["dx"], g["dy"], g["dz"])
+    both("advect", ["vx", "vx", "vy", "vy", "vz", "vz", "c", "c"], (cfl, g["dx"], g["dy"], g["dz"]), [0, 2, 6], 7,
+         kwargs=dict(faithful=True))
+    ctx.close()

@@ -76,11 +76,15 @@ def _global_solve(hip, Pg, Dg, Rg, g, n_iters, bc, dtype):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("P,depth,shape,n_iters", [(2, 2, (40, 21, 10), 7), (3, 2, (70, 12, 6), 5), (3, 1, (24, 15, 9), 4),
-                                                   (2, 2, (200, 160, 66), 7), (4, 2, (33, 9, 4), 6)])
+                                                   (2, 2, (200, 160, 66), 7), (4, 2, (33, 9, 4), 6), (2, 3, (40, 21, 10), 8),
+                                                   (3, 3, (70, 12, 6), 11), (4, 3, (33, 9, 4), 7), (3, 3, (33, 9, 5), 10),
+                                                   (2, 3, (200, 160, 66), 7)])
 def test_slab_state_equals_global_solve(hip, P, depth, shape, n_iters, dtype):
     """Decomposition independence of the C++ deep-ghost schedule (ns3d_slab_load / iterate / store): P virtual ranks leave
     exactly the planes of the single-device solve of the global grid — every local plane, halo planes included; odd
-    iteration counts mix two-iteration and single passes; the 4-plane slabs have seams that touch each other."""
+    iteration counts mix multi-iteration and single passes; the 4-plane slabs have seams that touch each other (and get
+    one ghost plane fewer than asked for).  depth 3: two ghost planes per seam and three iterations per pass (forced through
+    the ranks' contexts — the planner would only choose it on much larger grids)."""
     nx, ny, nz = shape
     nz_g = P * (nz - 2) + 2
     g = geometry(nx, ny, nz_g)
@@ -93,8 +97,12 @@ def test_slab_state_equals_global_solve(hip, P, depth, shape, n_iters, dtype):
     D = [hip.from_numpy(Dg[:, :, r * (nz - 2):r * (nz - 2) + nz - 2]) for r in range(P)]
     R = [hip.from_numpy(Rg[:, :, r * (nz - 2):r * (nz - 2) + nz]) for r in range(P)]
     p = hip.pt_params(Pr[0], g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, *bc)
+    if depth == 3:
+        for c in mg.contexts:
+            c.set_pt_depth(3)
     mg.slab_load(Pr, D, R, p)
-    mg.slab_plan()
+    planned = mg.slab_plan()
+    assert planned == min(depth, max(nz - 2, 1)) if depth != 2 else planned == 2
     mg.slab_iterate(n_iters)
     res = mg.slab_residual()
     mg.slab_store(Pr, D)

@@ -511,6 +511,90 @@ def test_pt_sweepn_plane_ranges_f32_fast_and_extremes(hip, oracle, nlev):
                 ctx.close()
 
 
+@pytest.mark.parametrize("sp", [dict(dx=1.0 / 64, dy=1.0 / 32, dz=1.0 / 128), dict(dx=0.5, dy=2.0, dz=1.0)])
+def test_pt_power_of_two_spacings_every_kernel_family(hip, oracle, sp):
+    """The fused PT kernels on power-of-two spacings (STRICT → the multiplication build, no range guard needed): single
+    sweeps of every family, the two-iteration kernel in every tile shape, the N-iteration kernel — against the oracle's plain
+    divisions, bit for bit, on ordinary and on extreme values."""
+    import torch
+    nx, ny, nz = 131, 21, 13
+    g = dict(geometry(nx, ny, nz)); g.update(sp)
+    for fieldset in ("plain", "dense", "sparse0"):
+        if fieldset == "plain":
+            Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 61)
+        else:
+            Pr0, d0, rhs = _extreme_fields(nx, ny, nz, np.float64, 97, fieldset)
+        ref = {}
+        Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
+        for n in (1, 2, 3, 4):
+            _oracle_iters(oracle, Pr, d, rhs, g, 1, 0, True, 0.25)
+            ref[n] = (Pr.copy(order="F"), d.copy(order="F"))
+        ctx = hip.Context(0, "strict")
+        p = _params(hip, hip.from_numpy(Pr0), g, 0, True, 0.25)
+        for variant in (100, 200, 2200, 2700):
+            ctx.set_pt_variant(variant)
+            ctx.set_pt2_variant(-1)
+            dPr, dd = hip.from_numpy(Pr0), hip.from_numpy(d0)
+            hip.pt_iterate(dPr, dd, hip.from_numpy(rhs), p, 1, ctx=ctx)
+            torch.cuda.synchronize()
+            assert _bits_equal(hip.to_numpy(dPr), ref[1][0]) and _bits_equal(hip.to_numpy(dd), ref[1][1]), (fieldset, variant)
+        for shape in (100, 300, 703, 800, 1100, 1300, 1900):
+            ctx.set_pt2_variant(shape)
+            dPr, dout, dd = hip.from_numpy(Pr0), hip.from_numpy(np.full_like(Pr0, 555.0)), hip.from_numpy(d0)
+            ddout = hip.from_numpy(np.full_like(d0, 444.0))
+            hip.pt_sweep2(dPr, dout, dd, ddout, hip.from_numpy(rhs), p, ctx=ctx)
+            torch.cuda.synchronize()
+            assert _bits_equal(hip.to_numpy(ddout), ref[2][1]) and _bits_equal(hip.to_numpy(dout), ref[2][0]), (fieldset, shape)
+        for nlev in (3, 4):
+            _sweepn_all_shapes(hip, ctx, nlev, Pr0, d0, rhs, p, ref[nlev][0], ref[nlev][1], "pow2 " + fieldset, cmp=_bits_equal)
+        if fieldset == "plain":
+            assert hip.residual_max(hip.from_numpy(ref[2][0]), hip.from_numpy(rhs), p, ctx=ctx) == _res_max(oracle, ref[2][0], rhs, g)
+        ctx.close()
+
+
+def _res_max(oracle, Pr, rhs, g):
+    Rp = np.zeros(tuple(n - 2 for n in Pr.shape), order="F")
+    oracle.compute_res(Rp, Pr, rhs, g["rho"], g["dt"], g["dx"], g["dy"], g["dz"])
+    return oracle.max_abs(Rp)
+
+
+@pytest.mark.parametrize("depth", [3, 4])
+@pytest.mark.parametrize("grid", [(24, 15, 15), (70, 6, 7), (63, 38, 38)])
+def test_pt_iterate_and_solve_with_deep_temporal_blocking(hip, oracle, grid, depth):
+    """pt_iterate / pt_solve with three and four iterations per pass forced (ns3d_set_pt_depth): every remainder pattern
+    (3+1 → 2+2, 3+2, 4+3, …), residual checks on nchk not divisible by the depth, early exits, HIP-graph replay of the
+    check blocks — identical counts, err history and fields."""
+    import torch
+    nx, ny, nz = grid
+    g = geometry(*grid)
+    Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 73)
+    rhs *= 1e-3
+    ctx = hip.Context(0, "strict")
+    ctx.set_pt_depth(depth)
+    for n in (1, 2, 3, 4, 5, 7, 8, 11, 13):
+        Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
+        _oracle_iters(oracle, Pr, d, rhs, g, n, 0, True, 0.0)
+        dPr, dd = hip.from_numpy(Pr0), hip.from_numpy(d0)
+        hip.pt_iterate(dPr, dd, hip.from_numpy(rhs), _params(hip, dPr, g, 0, True, 0.0), n, ctx=ctx)
+        torch.cuda.synchronize()
+        assert np.array_equal(hip.to_numpy(dPr), Pr) and np.array_equal(hip.to_numpy(dd), d), n
+        assert n < 2 or ctx.last_pt_depth() in (2, 3, 4)
+    Rp = np.zeros((nx - 2, ny - 2, nz - 2), order="F")
+    for graph in (0, 1):
+        ctx.set_graph_mode(graph)
+        for eps, niter, nchk in ((-1.0, 57, 14), (5e4, 400, 13), (1e-30, 45, 7), (-1.0, 30, 1), (-1.0, 40, 5)):
+            Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
+            it_ref, errs_ref = oracle.pt_solve(Pr, d, rhs, Rp, g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"],
+                                               g["dz"], 0, True, 0.0, g["g"], eps, niter, nchk, 0.36, 1000.0)
+            dPr, dd = hip.from_numpy(Pr0), hip.from_numpy(d0)
+            it, errs = hip.pt_solve(dPr, dd, hip.from_numpy(rhs), _params(hip, dPr, g, 0, True, 0.0), eps, niter, nchk,
+                                    0.36, 1000.0, ctx=ctx)
+            torch.cuda.synchronize()
+            assert it == it_ref and errs == errs_ref, (graph, eps, niter, nchk)
+            assert np.array_equal(hip.to_numpy(dPr), Pr) and np.array_equal(hip.to_numpy(dd), d)
+    ctx.close()
+
+
 def _full_size_properties(hip, oracle, n, dtype):
     """A full-size BASELINE grid (n³ cells), where the oracle cannot sweep the whole grid in test time: (a) the planned
     two-iteration kernel (ns3d_plan_pt times the tile shapes on these very arguments), two launches of the

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""SQ counters of the k_pt_sweep2 launches of one bench run (one rocprofv3 --pmc pass, kernel-trace only).
+"""SQ counters of the k_pt_sweep2 / k_pt_sweepN launches of one bench run (one rocprofv3 --pmc pass, kernel-trace only).
 
-    python tools/collect_sq.py --out gpurun_out/sq.json [--variant2 1392] [--modes strict,fast]
+    python tools/collect_sq.py --out gpurun_out/sq.json [--runs 2:1392,3:100] [--modes strict,fast]      (runs = depth:variant)
 
 WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ≈ WAVE_CYCLES (MI355X_MICROARCH.md, counter table).
 """
@@ -22,30 +22,31 @@ COUNTERS = ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", required=True)
-    ap.add_argument("--variant2", default="1392")
+    ap.add_argument("--runs", default="2:1392", help="depth:variant[,depth:variant…]")
     ap.add_argument("--modes", default="strict,fast")
     ap.add_argument("--dtype", default="f64")
     a = ap.parse_args()
     res = {}
-    for mode in a.modes.split(","):
+    for mode, run in [(m, r) for m in a.modes.split(",") for r in a.runs.split(",")]:
+        depth, variant = run.split(":")
         wd = "/tmp/ns3d_sq"
         shutil.rmtree(wd, ignore_errors=True)
         cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + COUNTERS + ["-f", "csv", "-d", wd, "-o", "p", "--", sys.executable,
                os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "2", "--no-cpu-baseline", "--mode", mode,
-               "--dtype", a.dtype, "--variant2", a.variant2]
+               "--dtype", a.dtype, "--depth", depth, "--variant2" if depth == "2" else "--variantn", variant]
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
         acc = {}
         for f in glob.glob(os.path.join(wd, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
-                if "k_pt_sweep2" not in row["Kernel_Name"]:
+                if "k_pt_sweep2" not in row["Kernel_Name"] and "k_pt_sweepN" not in row["Kernel_Name"]:
                     continue
                 s, n = acc.get(row["Counter_Name"], (0.0, 0))
                 acc[row["Counter_Name"]] = (s + float(row["Counter_Value"]), n + 1)
         m = {k: s / n for k, (s, n) in acc.items()}
         wc = m.get("SQ_WAVE_CYCLES", 0.0) or 1.0
         m["fractions_of_wave_cycles"] = {k: round(v / wc, 4) for k, v in m.items() if k.startswith("SQ_") and k != "SQ_WAVE_CYCLES"}
-        res["%s_v%s_%s" % (mode, a.variant2, a.dtype)] = m
-        print(mode, m["fractions_of_wave_cycles"], flush=True)
+        res["%s_x%s_v%s_%s" % (mode, depth, variant, a.dtype)] = m
+        print(mode, run, m["fractions_of_wave_cycles"], flush=True)
     json.dump(res, open(a.out, "w"), indent=1)
 
 
