@@ -267,7 +267,8 @@ int ns3d_mgpu_pass_depth(const ns3d_mgpu *m);
 /* The pseudo-transient state of a z-slab rank lives in library-owned buffers extended by the ghost planes temporal
  * blocking needs: load → iterate / residual → store; ns3d_pt_solve_slab is the whole inner loop multi.jl:458-471
  * (load, plan, iterate with a global residual check every nchk iterations, store).  Iterates are bit-identical to the
- * single-device solve of the global grid.  divV's halo planes must be current (update_halo!(∇V), multi.jl:455). */
+ * single-device solve of the global grid.  (The seam planes of divV are exchanged at load: multi.jl:455's update_halo!(∇V)
+ * may but need not have run.) */
 int ns3d_slab_iterate(ns3d_mgpu *m, int n_iters);
 int ns3d_slab_plan(ns3d_mgpu *m);
 int ns3d_slab_residual(ns3d_mgpu *m, double *out);

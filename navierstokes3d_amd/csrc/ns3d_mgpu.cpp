@@ -447,7 +447,19 @@ int slab_load(ns3d_mgpu *m, const T *const *Pr, const T *const *D, const T *cons
         }
     }
     m->loaded = true;
-    return slab_exchange<T>(m, 0, 0, true);       // deep ghosts of the incoming state
+    // deep ghosts of the incoming state — and of the right-hand side: level 1 on a ghost plane needs ∇V there, one or two
+    // planes beyond the one-plane halo the caller's update_halo!(∇V) filled (that plane is re-sent too: same value)
+    std::vector<std::vector<Block>> blocks;
+    for (MRank &r : m->loc) {
+        const Ext<T> e(m, r);
+        const int np = m->G + 1;
+        std::vector<Block> v = ghost_blocks<T>(m, r, 0, 0);
+        T *Rq = (T *)r.st.R;
+        v.push_back({Rq + e.plane * e.k0, Rq, Rq + e.plane * (e.k1 - np), Rq + e.plane * (e.nze - np), e.plane * np * sizeof(T)});
+        blocks.push_back(v);
+    }
+    int rc2 = exchange_begin(m, blocks);
+    return rc2 ? rc2 : exchange_end(m);
 }
 
 template <class T>
