@@ -321,6 +321,7 @@ static Plan lookup_plan(const ns3d_ctx *c, int mode, const ns3d_pt_params *p, in
     const long long cells = (long long)p->nx * p->ny * nk;
     if (!c->autotune || cells < NS3D_TWO_MIN_CELLS) return pl;
     if (c->pt2_variant > 0 && (c->pt_depth > 0 || cells < NS3D_DEEP_MIN_CELLS)) return pl;      // nothing left to decide
+    if (c->pt_depth >= 3 && c->ptn_variant > 0) return pl;                                      // deep passes, shape given
     std::lock_guard<std::mutex> lock(g_tuned_mutex);
     for (const auto &t : g_tuned)
         if (t.device == c->device && t.nx == p->nx && t.ny == p->ny && t.nz == p->nz && t.nk == nk &&

@@ -682,6 +682,29 @@ __global__ __launch_bounds__(256) void k_advect(T *__restrict__ Vx, const T *__r
 #define VYO(i_, j_, k_) Vy_o[IX3((i_)-1, (j_)-1, (k_)-1, nx, ny + 1)]
 #define VZO(i_, j_, k_) Vz_o[IX3((i_)-1, (j_)-1, (k_)-1, nx, ny)]
     T vxc, vyc, vzc;
+    // Interior threads take all four branches: straight-line code, so that the four independent
+    // load → δ → gather → lerp chains overlap instead of queueing behind each other's guards (same values, same stores;
+    // the second Vy store — the reference's own quirk, multi.jl:234 — still comes after the first in program order).
+    if (ix > 1 && iy > 1 && iz > 1 && ix <= nx && iy <= ny && iz <= nz) {
+        const T vx000 = VXO(ix, iy, iz), vx100 = VXO(ix + 1, iy, iz), vy000 = VYO(ix, iy, iz), vy010 = VYO(ix, iy + 1, iz);
+        const T vz000 = VZO(ix, iy, iz), vz001 = VZO(ix, iy, iz + 1);
+        const T ax = vx000;                                                                                        // :219
+        const T ay = (T)0.25 * (((VYO(ix - 1, iy, iz) + VYO(ix - 1, iy + 1, iz)) + vy000) + vy010);                // :220
+        const T az = (T)0.25 * (((VZO(ix - 1, iy, iz) + VZO(ix - 1, iy, iz + 1)) + vz000) + vz001);                // :221
+        const T bx = (T)0.25 * (((VXO(ix, iy - 1, iz) + VXO(ix + 1, iy - 1, iz)) + vx000) + vx100);                // :225
+        const T by = vy000;                                                                                        // :226
+        const T bz = (T)0.25 * (((VZO(ix, iy - 1, iz) + VZO(ix, iy - 1, iz + 1)) + vz000) + vz001);                // :227
+        const T cx = (T)0.25 * (((VXO(ix, iy, iz - 1) + VXO(ix + 1, iy, iz - 1)) + vx000) + vx100);                // :231
+        const T cy = (T)0.25 * (((VYO(ix, iy, iz - 1) + VYO(ix, iy + 1, iz - 1)) + vy000) + vy010);                // :232
+        const T cz = vz000;                                                                                        // :233
+        const T ex = (T)0.5 * (vx000 + vx100), ey = (T)0.5 * (vy000 + vy010), ez = (T)0.5 * (vz000 + vz001);      // :237-239
+        backtrack<T>(Vx, Vx_o, ax, ay, az, dt, g, ix, iy, iz, nx + 1, ny, nz);
+        backtrack<T>(Vy, Vy_o, bx, by, bz, dt, g, ix, iy, iz, nx, ny + 1, nz);
+        if (faithful) backtrack<T>(Vy, Vy_o, cx, cy, cz, dt, g, ix, iy, iz, nx, ny + 1, nz);
+        else backtrack<T>(Vz, Vz_o, cx, cy, cz, dt, g, ix, iy, iz, nx, ny, nz + 1);
+        backtrack<T>(C, C_o, ex, ey, ez, dt, g, ix, iy, iz, nx, ny, nz);
+        return;
+    }
     if (ix > 1 && ix < nx + 1 && iy <= ny && iz <= nz) { // multi.jl:218-223
         vxc = VXO(ix, iy, iz);
         vyc = (T)0.25 * (((VYO(ix - 1, iy, iz) + VYO(ix - 1, iy + 1, iz)) + VYO(ix, iy, iz)) + VYO(ix, iy + 1, iz));
@@ -1854,7 +1877,8 @@ static hipError_t launch_sweepN(hipStream_t s, SweepArgs<T> &a, int kz)
 
 // `nlev` fused PT iterations (Pin,Din) → (Pout,Dout) for the output planes [k0,k1).  variant = shape*100 + kz:
 // shape 1: 64×32 columns (one wave wide, 8 high, 4 rows per thread), 2: 128×16, 3: 256×8, 4: 64×48 (6 rows per thread),
-// 5: 128×24; +10: loads of the next step issued before level 1 (EARLY); kz as in pt_sweep2.  0 = built-in choice.
+// 5: 128×24, 6/7/8: 64×16 / 64×20 / 64×24 with 256-thread workgroups (several per CU); +10: loads of the next step issued
+// before level 1 (EARLY); kz as in pt_sweep2.  0 = built-in choice.
 template <class T>
 hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout, const T *Din, T *Dout, const T *RHS,
                      const ns3d_pt_params &p, int k0, int k1)
@@ -1878,6 +1902,11 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
     case 3: NS3D_SWN(NLV, 4, 2, 4, false);                                                                  \
     case 4: NS3D_SWN(NLV, 1, 8, 6, false);                                                                  \
     case 5: NS3D_SWN(NLV, 2, 4, 6, false);                                                                  \
+    case 6: NS3D_SWN(NLV, 1, 4, 4, false);   /* 256-thread workgroups: two (or three) per CU */             \
+    case 7: NS3D_SWN(NLV, 1, 4, 5, false);                                                                  \
+    case 8: NS3D_SWN(NLV, 1, 4, 6, false);                                                                  \
+    case 16: NS3D_SWN(NLV, 1, 4, 4, true);                                                                  \
+    case 17: NS3D_SWN(NLV, 1, 4, 5, true);                                                                  \
     case 11: NS3D_SWN(NLV, 1, 8, 4, true);                                                                  \
     case 12: NS3D_SWN(NLV, 2, 4, 4, true);                                                                  \
     case 13: NS3D_SWN(NLV, 4, 2, 4, true);                                                                  \

@@ -38,7 +38,7 @@ def main():
         acc = {}
         for f in glob.glob(os.path.join(wd, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
-                if "k_pt_sweep2" not in row["Kernel_Name"] and "k_pt_sweepN" not in row["Kernel_Name"]:
+                if ("k_pt_sweep2" if depth == "2" else "k_pt_sweepN") not in row["Kernel_Name"]:
                     continue
                 s, n = acc.get(row["Counter_Name"], (0.0, 0))
                 acc[row["Counter_Name"]] = (s + float(row["Counter_Value"]), n + 1)

@@ -54,7 +54,8 @@ def main():
             fetch = write = 0.0
             names = []
             for k in per["FETCH_SIZE"]:
-                if "k_pt_sweep2" in k or "k_pt_sweepN" in k or "k_pt_faces" in k:
+                main = "k_pt_sweep2" if depth == "2" else "k_pt_sweepN<%s, %s," % ("double" if a.dtype == "f64" else "float", depth)
+                if main in k or "k_pt_faces" in k:
                     fetch += 2.0 * 1024.0 * per["FETCH_SIZE"][k]
                     write += 1024.0 * per["WRITE_SIZE"].get(k, 0.0)
                     names.append(k.replace("void ", ""))
