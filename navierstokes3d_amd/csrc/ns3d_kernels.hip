@@ -13,6 +13,8 @@
 // scripts/NavierStokes3D_gpu.jl:175-368 ("gpu.jl"); macro meanings per SURVEY.md Appendix A.
 // Layout: packed column-major, x fastest — a wave64 spans 64 consecutive x (512 B of fp64 per row).
 // All of these are HBM-bound 7-point-class stencils: no MFMA anywhere.
+#include <cstdlib>
+
 #include "ns3d_launch.h"
 
 #if defined(NS3D_MODE_FAST)
@@ -736,12 +738,176 @@ __global__ __launch_bounds__(256) void k_advect(T *__restrict__ Vx, const T *__r
 #undef VYO
 #undef VZO
 }
+// ---- advect!, LDS-windowed ------------------------------------------------------------------------------------
+// k_advect reads 68 values per cell through L1/L2 (8-point gathers of four arrays plus the staggered velocity averages):
+// at 512³ that is ≈70 GB of cache traffic for 7.5 GB of algorithmic bytes.  Here a workgroup owns 64×8 columns and marches in
+// z; a ring of six xy-planes of the four OLD fields (window 67×11: one column/row below, two above — what |δ| < 1 can reach,
+// multi.jl:190-195) lives in LDS, the plane three steps ahead is fetched into registers while the current one is computed, and
+// every gather and every velocity average reads LDS.  A lane whose departure point leaves the window (|δ| ≥ 1 in some
+// direction: CFL_adv = 1 allows it where |v| > vin) takes the global gather instead — same values, same arithmetic, same
+// stores in the same order, so the result is bit-identical to k_advect for every δ.
+template <class T>
+struct AdvWin {
+    static constexpr int TX = 64, TY = 8, WX = TX + 3, WY = TY + 3, NSLOT = 6, PLANE = WX * WY;
+    const T *L;          // [4 arrays][NSLOT][PLANE]
+    int x0, y0, iz;      // 1-based first column/row of the tile, current plane
+    __device__ __forceinline__ T get(int a, int i, int j, int k) const
+    {
+        const int slot = k % NSLOT;
+        return L[(a * NSLOT + slot) * PLANE + (j - (y0 - 1)) * WX + (i - (x0 - 1))];
+    }
+    __device__ __forceinline__ bool holds(int i1, int i2, int j1, int j2, int k1, int k2) const
+    {
+        return (i1 >= x0 - 1) & (i2 <= x0 + TX + 1) & (j1 >= y0 - 1) & (j2 <= y0 + TY + 1) & (k1 >= iz - 1) & (k2 <= iz + 2);
+    }
+};
+template <class T>
+__device__ __forceinline__ void backtrack_win(T *__restrict__ A, const T *__restrict__ A_o, const AdvWin<T> &w, int a, T vxc, T vyc,
+                                              T vzc, T dt, const Geo<T> &g, int ix, int iy, int iz, int sx, int sy, int sz)
+{
+#if NS3D_FASTMATH
+    const T ddx = dt * vxc * g.rdx, ddy = dt * vyc * g.rdy, ddz = dt * vzc * g.rdz;
+#else
+    const T ddx = DIV_X(dt * vxc), ddy = DIV_Y(dt * vyc), ddz = DIV_Z(dt * vzc);
+#endif
+    const int ix1 = clampi((long long)floor_((T)ix - ddx), 1, sx);
+    const int iy1 = clampi((long long)floor_((T)iy - ddy), 1, sy);
+    const int iz1 = clampi((long long)floor_((T)iz - ddz), 1, sz);
+    const int ix2 = clampi(ix1 + 1, 1, sx), iy2 = clampi(iy1 + 1, 1, sy), iz2 = clampi(iz1 + 1, 1, sz);
+    const T wx = (ddx > (T)0 ? (T)1 : (T)0) - fmod1(ddx);
+    const T wy = (ddy > (T)0 ? (T)1 : (T)0) - fmod1(ddy);
+    const T wz = (ddz > (T)0 ? (T)1 : (T)0) - fmod1(ddz);
+    T v111, v211, v112, v212, v121, v221, v122, v222;      // A_o[ix·, iy·, iz·]
+    if (w.holds(ix1, ix2, iy1, iy2, iz1, iz2)) {
+        v111 = w.get(a, ix1, iy1, iz1); v211 = w.get(a, ix2, iy1, iz1); v112 = w.get(a, ix1, iy1, iz2); v212 = w.get(a, ix2, iy1, iz2);
+        v121 = w.get(a, ix1, iy2, iz1); v221 = w.get(a, ix2, iy2, iz1); v122 = w.get(a, ix1, iy2, iz2); v222 = w.get(a, ix2, iy2, iz2);
+    } else {
+#define AO(i_, j_, k_) A_o[IX3((i_)-1, (j_)-1, (k_)-1, sx, sy)]
+        v111 = AO(ix1, iy1, iz1); v211 = AO(ix2, iy1, iz1); v112 = AO(ix1, iy1, iz2); v212 = AO(ix2, iy1, iz2);
+        v121 = AO(ix1, iy2, iz1); v221 = AO(ix2, iy2, iz1); v122 = AO(ix1, iy2, iz2); v222 = AO(ix2, iy2, iz2);
+#undef AO
+    }
+    const T fy1z1 = lerp_<T>(v111, v211, wx);
+    const T fy1z2 = lerp_<T>(v112, v212, wx);
+    const T fy2z1 = lerp_<T>(v121, v221, wx);
+    const T fy2z2 = lerp_<T>(v122, v222, wx);
+    const T fz1 = lerp_<T>(fy1z1, fy2z1, wy);
+    const T fz2 = lerp_<T>(fy1z2, fy2z2, wy);
+    A[IX3(ix - 1, iy - 1, iz - 1, sx, sy)] = lerp_<T>(fz1, fz2, wz);
+}
+
+template <class T>
+__global__ __launch_bounds__(512) void k_advect_win(T *__restrict__ Vx, const T *__restrict__ Vx_o, T *__restrict__ Vy,
+                                                    const T *__restrict__ Vy_o, T *__restrict__ Vz, const T *__restrict__ Vz_o,
+                                                    T *__restrict__ C, const T *__restrict__ C_o, T dt, Geo<T> g, int nx, int ny,
+                                                    int nz, int faithful, int kz)
+{
+    typedef AdvWin<T> W;
+    extern __shared__ __align__(16) unsigned char advect_lds_raw[];
+    T *L = reinterpret_cast<T *>(advect_lds_raw);
+    const int tid = threadIdx.y * W::TX + threadIdx.x;
+    const int x0 = blockIdx.x * W::TX + 1, y0 = blockIdx.y * W::TY + 1;
+    const int zb = blockIdx.z * kz + 1, ze = min(zb + kz, nz + 2);          // planes iz ∈ [zb, ze) of the (nz+1)-plane range
+    const int ix = x0 + threadIdx.x, iy = y0 + threadIdx.y;
+    const T *const src[4] = {Vx_o, Vy_o, Vz_o, C_o};
+    const int sxs[4] = {nx + 1, nx, nx, nx}, sys[4] = {ny, ny + 1, ny, ny}, szs[4] = {nz, nz, nz + 1, nz};
+    // window positions this thread fills (two per array and plane: 737 positions, 512 threads)
+    int q[2], gi[2], gj[2];
+    bool has[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        q[h] = tid + h * 512;
+        has[h] = q[h] < W::PLANE;
+        const int qq = has[h] ? q[h] : 0;
+        gi[h] = x0 - 1 + qq % W::WX;
+        gj[h] = y0 - 1 + qq / W::WX;
+    }
+    auto fetch = [&](int plane, T (&v)[4][2]) {            // plane: 1-based, may lie outside the arrays (clamped like the gathers)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ci = min(max(gi[h], 1), sxs[a]), cj = min(max(gj[h], 1), sys[a]), ck = min(max(plane, 1), szs[a]);
+                v[a][h] = has[h] ? src[a][IX3(ci - 1, cj - 1, ck - 1, sxs[a], sys[a])] : (T)0;
+            }
+    };
+    auto publish = [&](int plane, const T (&v)[4][2]) {
+        const int slot = ((plane % W::NSLOT) + W::NSLOT) % W::NSLOT;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (has[h]) L[(a * W::NSLOT + slot) * W::PLANE + q[h]] = v[a][h];
+    };
+    {
+        T v[4][2];
+        for (int pl = zb - 1; pl <= zb + 2; ++pl) { fetch(pl, v); publish(pl, v); }
+    }
+    __syncthreads();
+    W w{L, x0, y0, zb};
+#define VXO(i_, j_, k_) w.get(0, (i_), (j_), (k_))
+#define VYO(i_, j_, k_) w.get(1, (i_), (j_), (k_))
+#define VZO(i_, j_, k_) w.get(2, (i_), (j_), (k_))
+    for (int iz = zb; iz < ze; ++iz) {
+        T nxt[4][2];
+        fetch(iz + 3, nxt);                                 // in flight behind this plane's arithmetic
+        w.iz = iz;
+        if (ix <= nx + 1 && iy <= ny + 1) {
+            T vxc, vyc, vzc;
+            if (ix > 1 && ix < nx + 1 && iy <= ny && iz <= nz) { // multi.jl:218-223
+                vxc = VXO(ix, iy, iz);
+                vyc = (T)0.25 * (((VYO(ix - 1, iy, iz) + VYO(ix - 1, iy + 1, iz)) + VYO(ix, iy, iz)) + VYO(ix, iy + 1, iz));
+                vzc = (T)0.25 * (((VZO(ix - 1, iy, iz) + VZO(ix - 1, iy, iz + 1)) + VZO(ix, iy, iz)) + VZO(ix, iy, iz + 1));
+                backtrack_win<T>(Vx, Vx_o, w, 0, vxc, vyc, vzc, dt, g, ix, iy, iz, nx + 1, ny, nz);
+            }
+            if (iy > 1 && iy < ny + 1 && ix <= nx && iz <= nz) { // multi.jl:224-229
+                vxc = (T)0.25 * (((VXO(ix, iy - 1, iz) + VXO(ix + 1, iy - 1, iz)) + VXO(ix, iy, iz)) + VXO(ix + 1, iy, iz));
+                vyc = VYO(ix, iy, iz);
+                vzc = (T)0.25 * (((VZO(ix, iy - 1, iz) + VZO(ix, iy - 1, iz + 1)) + VZO(ix, iy, iz)) + VZO(ix, iy, iz + 1));
+                backtrack_win<T>(Vy, Vy_o, w, 1, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny + 1, nz);
+            }
+            if (iz > 1 && iz < nz + 1 && ix <= nx && iy <= ny) { // multi.jl:230-235 (sic: back-tracks Vy again in the reference)
+                vxc = (T)0.25 * (((VXO(ix, iy, iz - 1) + VXO(ix + 1, iy, iz - 1)) + VXO(ix, iy, iz)) + VXO(ix + 1, iy, iz));
+                vyc = (T)0.25 * (((VYO(ix, iy, iz - 1) + VYO(ix, iy + 1, iz - 1)) + VYO(ix, iy, iz)) + VYO(ix, iy + 1, iz));
+                vzc = VZO(ix, iy, iz);
+                if (faithful) backtrack_win<T>(Vy, Vy_o, w, 1, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny + 1, nz);
+                else backtrack_win<T>(Vz, Vz_o, w, 2, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny, nz + 1);
+            }
+            if (ix <= nx && iy <= ny && iz <= nz) { // multi.jl:236-241
+                vxc = (T)0.5 * (VXO(ix, iy, iz) + VXO(ix + 1, iy, iz));
+                vyc = (T)0.5 * (VYO(ix, iy, iz) + VYO(ix, iy + 1, iz));
+                vzc = (T)0.5 * (VZO(ix, iy, iz) + VZO(ix, iy, iz + 1));
+                backtrack_win<T>(C, C_o, w, 3, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny, nz);
+            }
+        }
+        publish(iz + 3, nxt);
+        __syncthreads();
+    }
+#undef VXO
+#undef VYO
+#undef VZO
+}
+
 template <class T>
 hipError_t advect(hipStream_t s, T *Vx, const T *Vx_o, T *Vy, const T *Vy_o, T *Vz, const T *Vz_o, T *C,
                   const T *C_o, double dt, double dx, double dy, double dz, int nx, int ny, int nz, int faithful)
 {
-    hipLaunchKernelGGL(k_advect<T>, grid3(nx + 1, ny + 1, nz + 1, BLK3), BLK3, 0, s, Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, C,
-                       C_o, (T)dt, make_geo<T>(dx, dy, dz), nx, ny, nz, faithful);
+    static const bool windowed = !(std::getenv("NS3D_ADVECT_GLOBAL") && *std::getenv("NS3D_ADVECT_GLOBAL") == '1');
+    if (!windowed) {                                        // the one-thread-per-cell global gather (A/B, fallback)
+        hipLaunchKernelGGL(k_advect<T>, grid3(nx + 1, ny + 1, nz + 1, BLK3), BLK3, 0, s, Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, C,
+                           C_o, (T)dt, make_geo<T>(dx, dy, dz), nx, ny, nz, faithful);
+        return hipGetLastError();
+    }
+    typedef AdvWin<T> W;
+    const size_t lds = (size_t)4 * W::NSLOT * W::PLANE * sizeof(T);
+    // > 64 KB of dynamic LDS needs the opt-in (per device: a process may drive several)
+    hipError_t ea = hipFuncSetAttribute((const void *)k_advect_win<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ea != hipSuccess) return ea;
+    const int kz = 32;
+    const dim3 blk(W::TX, W::TY, 1);
+    const dim3 grd((unsigned)((nx + 1 + W::TX - 1) / W::TX), (unsigned)((ny + 1 + W::TY - 1) / W::TY), (unsigned)((nz + 1 + kz - 1) / kz));
+    hipLaunchKernelGGL(k_advect_win<T>, grd, blk, lds, s, Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, C, C_o, (T)dt, make_geo<T>(dx, dy, dz), nx,
+                       ny, nz, faithful, kz);
     return hipGetLastError();
 }
 
@@ -987,7 +1153,7 @@ template <class T, bool NT> __device__ __forceinline__ T ld_stream(const T *p)
 }
 template <class T, bool NT> __device__ __forceinline__ void st_stream(T *p, T v)
 {
-#ifdef NS3D_NONTEMPORAL
+#if defined(NS3D_NONTEMPORAL) || defined(NS3D_NT_STORES)
     if (NT) { __builtin_nontemporal_store(v, p); return; }
 #endif
     *p = v;
@@ -1877,7 +2043,8 @@ static hipError_t launch_sweepN(hipStream_t s, SweepArgs<T> &a, int kz)
 
 // `nlev` fused PT iterations (Pin,Din) → (Pout,Dout) for the output planes [k0,k1).  variant = shape*100 + kz:
 // shape 1: 64×32 columns (one wave wide, 8 high, 4 rows per thread), 2: 128×16, 3: 256×8, 4: 64×48 (6 rows per thread),
-// 5: 128×24, 6/7/8: 64×16 / 64×20 / 64×24 with 256-thread workgroups (several per CU); +10: loads of the next step issued
+// 5: 128×24, 6/7/8: 64×16 / 64×20 / 64×24 with 256-thread workgroups (several per CU), 9: 64×32 with 256 threads (one wave
+// per SIMD, 8 rows per thread; measured slower: 0.58 against 0.45 ms per iteration at 512³); +10: loads of the next step issued
 // before level 1 (EARLY); kz as in pt_sweep2.  0 = built-in choice.
 template <class T>
 hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout, const T *Din, T *Dout, const T *RHS,
@@ -1905,6 +2072,8 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
     case 6: NS3D_SWN(NLV, 1, 4, 4, false);   /* 256-thread workgroups: two (or three) per CU */             \
     case 7: NS3D_SWN(NLV, 1, 4, 5, false);                                                                  \
     case 8: NS3D_SWN(NLV, 1, 4, 6, false);                                                                  \
+    case 9: NS3D_SWN(NLV, 1, 4, 8, false);   /* one wave per SIMD, up to 512 registers: 64×32 */            \
+    case 19: NS3D_SWN(NLV, 1, 4, 8, true);                                                                  \
     case 16: NS3D_SWN(NLV, 1, 4, 4, true);                                                                  \
     case 17: NS3D_SWN(NLV, 1, 4, 5, true);                                                                  \
     case 11: NS3D_SWN(NLV, 1, 8, 4, true);                                                                  \

@@ -166,6 +166,35 @@ def test_advect(hip, oracle, grid, cfl, faithful, mode):
     ctx.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("grid,cfl", [((150, 21, 70), 0.9), ((150, 21, 70), 2.7), ((64, 8, 33), 0.5), ((63, 7, 31), 1.0),
+                                       ((131, 19, 38), 1.6), ((3, 3, 3), 0.8)])
+def test_advect_windowed_tiles(hip, oracle, grid, cfl, dtype):
+    """The LDS-windowed advect! (64×8-column workgroups marching in z, 67×11×6-plane ring of the four old fields): grids of
+    several tiles in x, y and z-chunks, tile-aligned and ragged extents, departure points inside the window (cfl < 1), on
+    its edge and far outside it (cfl 2.7: those lanes take the global gather) — bit-identical to the oracle either way,
+    both advection modes."""
+    import torch
+    nx, ny, nz = grid
+    g = geometry(*grid)
+    Vx_o, Vy_o, Vz_o, C_o = fields(nx, ny, nz, ["vx", "vy", "vz", "c"], 21, dtype)
+    dt = cfl * min(g["dx"], g["dy"], g["dz"])
+    ctx = hip.Context(0, "strict")
+    do = [hip.from_numpy(a) for a in (Vx_o, Vy_o, Vz_o, C_o)]
+    for faithful in (True, False):
+        outs = fields(nx, ny, nz, ["vx", "vy", "vz", "c"], 31, dtype)
+        ref = [a.copy(order="F") for a in outs]
+        oracle.advect(ref[0], Vx_o, ref[1], Vy_o, ref[2], Vz_o, ref[3], C_o, dt, g["dx"], g["dy"], g["dz"], faithful)
+        d = [hip.from_numpy(a) for a in outs]
+        hip.advect(d[0], do[0], d[1], do[1], d[2], do[2], d[3], do[3], dt, g["dx"], g["dy"], g["dz"], faithful, ctx=ctx)
+        torch.cuda.synchronize()
+        for q in range(4):
+            assert np.array_equal(hip.to_numpy(d[q]), ref[q]), "advect output %d (faithful=%s)" % (q, faithful)
+        for a, b in zip(do, (Vx_o, Vy_o, Vz_o, C_o)):
+            assert np.array_equal(hip.to_numpy(a), b)
+    ctx.close()
+
+
 def test_advect_integer_cfl_edge(hip, oracle):
     """Positive integer δ: weight 1 with base floor(i−δ) (SURVEY App. A backtrack! edge case)."""
     import torch
