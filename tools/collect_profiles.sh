@@ -1,0 +1,32 @@
+#!/bin/bash
+# Everything profiles/ holds for one round, on ONE GPU box (box-to-box spread is ±5 %):
+#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r2'
+# Outputs land in gpurun_out/<tag>_*; copy the ones to be judged into profiles/.
+# The profiler gets `python3 bench.py …` itself after `--` (no shell / env hop); PMC passes are kernel-trace only.
+set -u
+TAG=${1:-r2}
+cd $GRAFT_REPO_ROOT
+O=gpurun_out
+b() { name=$1; shift; python3 bench.py "$@" > $O/${TAG}_bench_$name.json 2> $O/${TAG}_bench_$name.err; echo "$name: $(python3 -c "import json,sys; d=json.loads(open('$O/${TAG}_bench_$name.json').read().strip().splitlines()[-1]); r=d['roofline']; print(round(d['value']), 'Mcells*it/s', 'depth', d['config']['pt_depth'], 'frac', round(r['frac'],3), 'eff', round(r['effective_frac'],3), 'kernel_ms', round(r['kernel_ms'],4))" 2>&1)"; }
+b strict
+b fast --mode fast --no-cpu-baseline
+b f32_strict --dtype f32 --no-cpu-baseline
+b strict_depth2 --depth 2 --no-cpu-baseline
+b 1024cubed_strict --grid 1024 --steps 60 --warmup 6 --no-cpu-baseline
+b 1024cubed_f32_strict --grid 1024 --dtype f32 --steps 60 --warmup 6 --no-cpu-baseline
+b 255x153x153_strict --grid 255 --grid-nz 153 --no-cpu-baseline
+b 2ranks_one_gpu --gpus 2 --grid 256 --steps 40 --warmup 4
+# kernel trace + stats of the default bench command
+rm -rf /tmp/ns3d_kt; rocprofv3 --kernel-trace --stats -f csv -d /tmp/ns3d_kt -o kt -- python3 bench.py --no-cpu-baseline > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_rocprof.err
+f=$(find /tmp/ns3d_kt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/${TAG}_kernel_stats_strict_512.csv && head -6 $O/${TAG}_kernel_stats_strict_512.csv | cut -c1-220
+rm -rf /tmp/ns3d_kt; rocprofv3 --kernel-trace --stats -f csv -d /tmp/ns3d_kt -o kt -- python3 bench.py --no-cpu-baseline --mode fast > $O/${TAG}_bench_under_rocprof_fast.json 2>> $O/${TAG}_rocprof.err
+f=$(find /tmp/ns3d_kt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/${TAG}_kernel_stats_fast_512.csv
+rm -rf /tmp/ns3d_kt; rocprofv3 --kernel-trace --stats -f csv -d /tmp/ns3d_kt -o kt -- python3 bench.py --no-cpu-baseline --dtype f32 > $O/${TAG}_bench_under_rocprof_f32.json 2>> $O/${TAG}_rocprof.err
+f=$(find /tmp/ns3d_kt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/${TAG}_kernel_stats_f32_512.csv
+python3 tools/collect_sq.py --out $O/${TAG}_pmc_sq_512.json --runs 3:100,2:1392 --modes strict,fast 2>&1 | tail -4
+python3 tools/collect_traffic.py --out $O/${TAG}_traffic_512.json --runs 3:100,2:1392 --modes strict,fast 2>&1 | tail -4
+python3 tools/collect_traffic.py --out $O/${TAG}_traffic_512_f32.json --runs 3:100,2:1100 --modes strict --dtype f32 2>&1 | tail -2
+python3 tools/kernel_rates.py > $O/${TAG}_kernel_rates_512.jsonl 2>/dev/null; grep -c kernel $O/${TAG}_kernel_rates_512.jsonl
+python3 tools/run_config.py --script multi --nx 63 --nt 20 > $O/${TAG}_config_a_63x38x38.json 2>/dev/null; tail -c 300 $O/${TAG}_config_a_63x38x38.json; echo
+python3 tools/run_config.py --script multi --nx 255 --nt 3 --compare-fast > $O/${TAG}_config_b_multi_255x153x153.json 2>/dev/null; tail -c 300 $O/${TAG}_config_b_multi_255x153x153.json; echo
+python3 tools/run_config.py --script gpu --nx 255 --nt 3 > $O/${TAG}_config_b_gpujl_255x153x153.json 2>/dev/null; tail -c 300 $O/${TAG}_config_b_gpujl_255x153x153.json; echo
