@@ -746,19 +746,37 @@ __global__ __launch_bounds__(256) void k_advect(T *__restrict__ Vx, const T *__r
 // every gather and every velocity average reads LDS.  A lane whose departure point leaves the window (|δ| ≥ 1 in some
 // direction: CFL_adv = 1 allows it where |v| > vin) takes the global gather instead — same values, same arithmetic, same
 // stores in the same order, so the result is bit-identical to k_advect for every δ.
+// clamp(floor(·) as Int, 1, hi) of multi.jl:192-194 with the clamp applied BEFORE the conversion: the same integer for every
+// finite value (the conversion is exact inside [1, hi]), the saturating behaviour of the device's float→int64 conversion for
+// huge values (→ hi / 1), and 1 for NaN (fmax drops it) — what clampi((long long)floor(·)) gives on this device, without the
+// multi-instruction 64-bit conversion
+__device__ __forceinline__ int clampf_i(double t, int hi) { return (int)__builtin_fmin(__builtin_fmax(t, 1.0), (double)hi); }
+__device__ __forceinline__ int clampf_i(float t, int hi) { return (int)__builtin_fminf(__builtin_fmaxf(t, 1.0f), (float)hi); }
+
 template <class T>
 struct AdvWin {
-    static constexpr int TX = 64, TY = 8, WX = TX + 3, WY = TY + 3, NSLOT = 6, PLANE = WX * WY;
-    const T *L;          // [4 arrays][NSLOT][PLANE]
+    static constexpr int TX = 64, TY = 8, WX = TX + 4, WY = TY + 3, NSLOT = 6, PLANE = WX * WY;   // 67 columns used; pitch 68
+    // explicitly an LDS pointer: through a generic one the gathers below become flat_load (the compiler merges the LDS and the
+    // global branch of backtrack_win into one generic access), which is what the first version of this kernel measured
+    typedef const T __attribute__((address_space(3))) *lds_ptr;
+    lds_ptr L;           // [4 arrays][NSLOT][PLANE]
     int x0, y0, iz;      // 1-based first column/row of the tile, current plane
+    int so[4];           // ring offsets (slot·PLANE) of the planes iz-1 … iz+2 (workgroup-uniform, set once per step)
+    __device__ __forceinline__ void set_plane(int iz_)
+    {
+        iz = iz_;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) so[d] = ((iz_ - 1 + d) % NSLOT) * PLANE;     // iz_ ≥ 1: never negative
+    }
     __device__ __forceinline__ T get(int a, int i, int j, int k) const
     {
-        const int slot = k % NSLOT;
-        return L[(a * NSLOT + slot) * PLANE + (j - (y0 - 1)) * WX + (i - (x0 - 1))];
+        const int d = k - (iz - 1);                         // 0 … 3 for every plane the window holds
+        const int off = d == 0 ? so[0] : d == 1 ? so[1] : d == 2 ? so[2] : so[3];
+        return L[a * (NSLOT * PLANE) + off + (j - (y0 - 1)) * WX + (i - (x0 - 1))];
     }
     __device__ __forceinline__ bool holds(int i1, int i2, int j1, int j2, int k1, int k2) const
     {
-        return (i1 >= x0 - 1) & (i2 <= x0 + TX + 1) & (j1 >= y0 - 1) & (j2 <= y0 + TY + 1) & (k1 >= iz - 1) & (k2 <= iz + 2);
+        return (i1 >= x0 - 1) & (i2 <= x0 + TX + 1) & (j1 >= y0 - 1) & (j2 <= y0 + TY + 1) & (k1 >= iz - 1) & (k2 <= iz + 2);   // 67 × 11 × 4
     }
 };
 template <class T>
@@ -770,10 +788,10 @@ __device__ __forceinline__ void backtrack_win(T *__restrict__ A, const T *__rest
 #else
     const T ddx = DIV_X(dt * vxc), ddy = DIV_Y(dt * vyc), ddz = DIV_Z(dt * vzc);
 #endif
-    const int ix1 = clampi((long long)floor_((T)ix - ddx), 1, sx);
-    const int iy1 = clampi((long long)floor_((T)iy - ddy), 1, sy);
-    const int iz1 = clampi((long long)floor_((T)iz - ddz), 1, sz);
-    const int ix2 = clampi(ix1 + 1, 1, sx), iy2 = clampi(iy1 + 1, 1, sy), iz2 = clampi(iz1 + 1, 1, sz);
+    const int ix1 = clampf_i(floor_((T)ix - ddx), sx);
+    const int iy1 = clampf_i(floor_((T)iy - ddy), sy);
+    const int iz1 = clampf_i(floor_((T)iz - ddz), sz);
+    const int ix2 = min(ix1 + 1, sx), iy2 = min(iy1 + 1, sy), iz2 = min(iz1 + 1, sz);
     const T wx = (ddx > (T)0 ? (T)1 : (T)0) - fmod1(ddx);
     const T wy = (ddy > (T)0 ? (T)1 : (T)0) - fmod1(ddy);
     const T wz = (ddz > (T)0 ? (T)1 : (T)0) - fmod1(ddz);
@@ -819,7 +837,7 @@ __global__ __launch_bounds__(512) void k_advect_win(T *__restrict__ Vx, const T 
         q[h] = tid + h * 512;
         has[h] = q[h] < W::PLANE;
         const int qq = has[h] ? q[h] : 0;
-        gi[h] = x0 - 1 + qq % W::WX;
+        gi[h] = x0 - 1 + qq % W::WX;                        // (the 68th column of the pitch is loaded too: never looked up)
         gj[h] = y0 - 1 + qq / W::WX;
     }
     auto fetch = [&](int plane, T (&v)[4][2]) {            // plane: 1-based, may lie outside the arrays (clamped like the gathers)
@@ -844,14 +862,14 @@ __global__ __launch_bounds__(512) void k_advect_win(T *__restrict__ Vx, const T 
         for (int pl = zb - 1; pl <= zb + 2; ++pl) { fetch(pl, v); publish(pl, v); }
     }
     __syncthreads();
-    W w{L, x0, y0, zb};
+    W w{(typename W::lds_ptr)L, x0, y0, zb, {0, 0, 0, 0}};
 #define VXO(i_, j_, k_) w.get(0, (i_), (j_), (k_))
 #define VYO(i_, j_, k_) w.get(1, (i_), (j_), (k_))
 #define VZO(i_, j_, k_) w.get(2, (i_), (j_), (k_))
     for (int iz = zb; iz < ze; ++iz) {
         T nxt[4][2];
         fetch(iz + 3, nxt);                                 // in flight behind this plane's arithmetic
-        w.iz = iz;
+        w.set_plane(iz);
         if (ix <= nx + 1 && iy <= ny + 1) {
             T vxc, vyc, vzc;
             if (ix > 1 && ix < nx + 1 && iy <= ny && iz <= nz) { // multi.jl:218-223
