@@ -410,7 +410,7 @@ static Plan tune_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
     // a clear per-ITERATION gain, head to head.
     const long long cells = (long long)p->nx * p->ny * nk;
     if (c->pt_depth <= 0 && cells >= NS3D_DEEP_MIN_CELLS && nk >= 12) {
-        static const int cand[] = {100, 1100, 600, 1600, 200, 132};   // the first one is the built-in shape: it wins near-ties
+        static const int cand[] = {1100, 100, 1600, 600, 2200, 1132};   // the first one is the built-in shape: it wins near-ties
         int bestn = c->ptn_variant;
         float best3 = 0.f, ms = 0.f;
         if (c->ptn_variant > 0) { if (!time_launch(3, bestn, best3)) best3 = 0.f; }
@@ -427,7 +427,7 @@ static Plan tune_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
             }
         }
     } else if (c->pt_depth >= 3 && c->ptn_variant <= 0 && cells >= NS3D_TWO_MIN_CELLS) {
-        static const int cand[] = {100, 1100, 600, 1600, 200, 132};
+        static const int cand[] = {1100, 100, 1600, 600, 2200, 1132};
         float bestd = 0.f, ms = 0.f;
         for (int v : cand) {
             if (!time_launch(c->pt_depth, v, ms)) continue;

@@ -2109,7 +2109,7 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
     a.k0 = k0; a.k1 = k1; a.kz = 1;
     if (k1 <= k0) return hipSuccess;
     int shape = variant / 100, kz = variant % 100;
-    if (variant == 0) { shape = 1; kz = 0; }
+    if (variant == 0) { shape = 11; kz = 0; }     // 64×32 columns, next step's loads issued before level 1 (measured best at 512³)
 #define NS3D_SWN(NLV, WXV, WYV, CPTV, PFV) return launch_sweepN<T, NLV, WXV, WYV, CPTV, PFV>(s, a, kz)
 #define NS3D_SWN_SHAPES(NLV)                                                                                \
     switch (shape) {                                                                                        \
@@ -2124,6 +2124,7 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
     case 9: NS3D_SWN(NLV, 1, 4, 8, false);   /* one wave per SIMD, up to 512 registers: 64×32 */            \
     case 19: NS3D_SWN(NLV, 1, 4, 8, true);                                                                  \
     case 16: NS3D_SWN(NLV, 1, 4, 4, true);                                                                  \
+    case 22: if constexpr (sizeof(T) == 4) { NS3D_SWN(NLV, 1, 12, 4, true); } else return hipErrorInvalidValue; /* fp32: 64×48, 768 threads = three waves per SIMD */ \
     case 17: NS3D_SWN(NLV, 1, 4, 5, true);                                                                  \
     case 11: NS3D_SWN(NLV, 1, 8, 4, true);                                                                  \
     case 21: NS3D_SWN(NLV, 1, 8, 4, 2);      /* +20: loads two steps ahead */                               \
