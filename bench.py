@@ -265,7 +265,7 @@ def main():
     use2 = (world == 1) and depth >= 2
     slab = None
     if mg is not None:                              # the whole schedule inside libns3d: ns3d_slab_load / _plan / _iterate
-        mg.set_temporal(1 if a.no_temporal_blocking else 3)
+        mg.set_temporal(1 if a.no_temporal_blocking else 4)
         mg.update_halo(rhs)                         # update_halo!(∇V), multi.jl:455: the seam planes of the RHS agree
         mg.slab_load(Pr, D, rhs, pt)
         depth = mg.slab_plan()                      # plan phase, untimed: tile shapes and iterations per pass (all ranks agree)

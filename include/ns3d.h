@@ -259,9 +259,9 @@ const char *ns3d_mgpu_transport(const ns3d_mgpu *m);   /* "peer" | "rccl" */
 int ns3d_mgpu_rccl_ranks(const ns3d_mgpu *m);          /* ncclCommCount of the communicator (0 in the one-process form) */
 int ns3d_mgpu_sync(ns3d_mgpu *m);
 int ns3d_max_g(ns3d_mgpu *m, const double *local_max, double *out);    /* NaN-propagating */
-/* Most PT iterations a pass over memory may advance in ns3d_slab_* / ns3d_pt_solve_slab = ghost planes per seam: 3 (default),
- * 2 or 1 (plain one-plane halo, single sweeps).  Passes run two iterations until ns3d_slab_plan has measured whether three
- * pay on this grid; every rank uses the same depth. */
+/* Most PT iterations a pass over memory may advance in ns3d_slab_* / ns3d_pt_solve_slab = ghost planes per seam + 1: 4 (default),
+ * 3, 2 or 1 (plain one-plane halo, single sweeps).  Passes run two iterations until ns3d_slab_plan has measured whether three
+ * (fp32: four) pay on this grid; every rank uses the same depth. */
 int ns3d_mgpu_set_temporal(ns3d_mgpu *m, int depth);
 int ns3d_mgpu_pass_depth(const ns3d_mgpu *m);
 /* The pseudo-transient state of a z-slab rank lives in library-owned buffers extended by the ghost planes temporal

@@ -426,6 +426,26 @@ static Plan tune_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
                 pl.vn = bestn;
             }
         }
+        // four iterations per pass: only fp32 has the registers for it (64×48 columns with 768 threads = three waves per SIMD)
+        if (sizeof(T) == 4 && nk >= 16) {
+            static const int cand4[] = {2200, 1100};
+            const float cur_per_it = pl.depth == 3 ? best3 / 3.f : ms2 / 2.f;
+            int best4v = 0;
+            float best4 = 0.f;
+            for (int v : cand4) {
+                if (c->ptn_variant > 0 && v != c->ptn_variant) continue;
+                if (!time_launch(4, v, ms)) continue;
+                if (best4 == 0.f || ms < 0.98f * best4) { best4 = ms; best4v = v; }
+            }
+            if (best4 > 0.f && best4 / 4.f < 0.98f * cur_per_it) {
+                float a = 0.f, b4 = 0.f;
+                const bool ok = (pl.depth == 3 ? time_launch(3, pl.vn, a, 6) : time_launch(2, pl.v2, a, 6)) && time_launch(4, best4v, b4, 6);
+                if (ok && b4 / 4.f < 0.97f * a / (float)pl.depth) {
+                    pl.depth = 4;
+                    pl.vn = best4v;
+                }
+            }
+        }
     } else if (c->pt_depth >= 3 && c->ptn_variant <= 0 && cells >= NS3D_TWO_MIN_CELLS) {
         static const int cand[] = {1100, 100, 1600, 600, 2200, 1132};
         float bestd = 0.f, ms = 0.f;

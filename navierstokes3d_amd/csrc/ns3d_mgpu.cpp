@@ -23,7 +23,7 @@
 // Pseudo-transient loop of a slab rank (ns3d_slab_*, ns3d_pt_solve_slab): the single-GPU fast path advances `depth` PT
 // iterations per pass over memory.  Level 2 of a rank's first own plane needs level 1 of the seam halo plane, which needs
 // the previous iterate one plane further out: the solve state therefore lives in library-owned buffers EXTENDED by
-// G = depth−1 ghost planes per seam (depth = the most iterations a pass may advance, 3 by default).  Every pass recomputes the lower levels on the ghost planes (bit-identical on both
+// G = depth−1 ghost planes per seam (depth = the most iterations a pass may advance, 4 by default).  Every pass recomputes the lower levels on the ghost planes (bit-identical on both
 // ranks: same inputs, same arithmetic), afterwards the depth outermost own planes of Pr and the G outermost own planes of
 // dPrdτ travel to the neighbour (depth=2: 3 planes per two iterations instead of the reference's ≥2 exchanges per single
 // iteration, multi.jl:460-463,182).  The seam-adjacent output planes are swept first, their exchange is posted on the
@@ -122,7 +122,7 @@ struct ns3d_mgpu {
     bool rccl = false;
     ncclComm_t comm = nullptr;
     int rccl_ranks = 0;
-    int depth = 3;                // most PT iterations a pass may advance = ghost depth + 1 (1: single sweeps, plain one-plane halo)
+    int depth = 4;                // most PT iterations a pass may advance = ghost depth + 1 (1: single sweeps, plain one-plane halo)
     int pass_depth = 2;           // iterations per pass actually used (ns3d_slab_plan may raise it to `depth`; same on every rank)
     // loaded solve
     bool loaded = false;
@@ -251,7 +251,7 @@ ns3d_mgpu *new_mgpu(int P, int nx, int ny, int nz, int flags, const char *fn)
     if (nx < 3 || ny < 3 || nz < 3) { fail(NS3D_ERR_ARG, "%s: local grid %dx%dx%d too small (need >= 3)", fn, nx, ny, nz); return nullptr; }
     ns3d_mgpu *m = new ns3d_mgpu();
     m->P = P; m->nx = nx; m->ny = ny; m->nz = nz; m->flags = flags;
-    if (const char *ev = std::getenv("NS3D_SLAB_DEPTH")) m->depth = std::max(1, std::min(3, std::atoi(ev)));
+    if (const char *ev = std::getenv("NS3D_SLAB_DEPTH")) m->depth = std::max(1, std::min(4, std::atoi(ev)));
     m->pass_depth = std::min(2, m->depth);
     return m;
 }
@@ -737,7 +737,7 @@ int ns3d_mgpu_pass_depth(const ns3d_mgpu *m) { return m ? m->pass_depth : -1; }
 int ns3d_mgpu_set_temporal(ns3d_mgpu *m, int depth)
 {
     CHECK_M(m);
-    if (depth < 1 || depth > 3) return fail(NS3D_ERR_ARG, "ns3d_mgpu_set_temporal: depth %d (1 … 3)", depth);
+    if (depth < 1 || depth > 4) return fail(NS3D_ERR_ARG, "ns3d_mgpu_set_temporal: depth %d (1 … 4)", depth);
     if (m->loaded && depth != m->depth) m->loaded = false;      // ghost depth changes: the state must be loaded again
     m->depth = depth;
     m->pass_depth = std::min(2, depth);                         // until ns3d_slab_plan measures

@@ -187,7 +187,7 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
             c.set_pt2_variant(-1)
     mg = getattr(grid, "mg", None)
     if mg is not None:
-        mg.set_temporal(3 if (temporal and nz >= 4) else 1)
+        mg.set_temporal(4 if (temporal and nz >= 4) else 1)
     slab = None
     if fused and P > 1 and mg is None and temporal and nz >= 4:
         slab = SlabPTSolver(ctxs[0], grid, fs[0].Pr, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, L.NS3D_BC_MULTI,

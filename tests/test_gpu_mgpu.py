@@ -77,7 +77,8 @@ def _global_solve(hip, Pg, Dg, Rg, g, n_iters, bc, dtype):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("P,depth,shape,n_iters", [(2, 2, (40, 21, 10), 7), (3, 2, (70, 12, 6), 5), (3, 1, (24, 15, 9), 4),
                                                    (2, 2, (200, 160, 66), 7), (4, 2, (33, 9, 4), 6), (2, 3, (40, 21, 10), 8),
-                                                   (3, 3, (70, 12, 6), 11), (4, 3, (33, 9, 4), 7), (3, 3, (33, 9, 5), 10),
+                                                   (3, 3, (70, 12, 6), 11), (4, 3, (33, 9, 4), 7), (3, 3, (33, 9, 5), 10), (2, 4, (40, 21, 10), 9), (3, 4, (70, 12, 6), 11),
+                                                   (3, 4, (33, 9, 5), 10),
                                                    (2, 3, (200, 160, 66), 7)])
 def test_slab_state_equals_global_solve(hip, P, depth, shape, n_iters, dtype):
     """Decomposition independence of the C++ deep-ghost schedule (ns3d_slab_load / iterate / store): P virtual ranks leave
@@ -93,13 +94,14 @@ def test_slab_state_equals_global_solve(hip, P, depth, shape, n_iters, dtype):
     Pref, Dref = _global_solve(hip, Pg, Dg, Rg, g, n_iters, bc, dtype)
     mg = _mg(P, nx, ny, nz)
     mg.set_temporal(depth)
+    assert mg.pass_depth() == min(depth, 2)
     Pr = [hip.from_numpy(Pg[:, :, r * (nz - 2):r * (nz - 2) + nz]) for r in range(P)]
     D = [hip.from_numpy(Dg[:, :, r * (nz - 2):r * (nz - 2) + nz - 2]) for r in range(P)]
     R = [hip.from_numpy(Rg[:, :, r * (nz - 2):r * (nz - 2) + nz]) for r in range(P)]
     p = hip.pt_params(Pr[0], g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, *bc)
-    if depth == 3:
+    if depth >= 3:
         for c in mg.contexts:
-            c.set_pt_depth(3)
+            c.set_pt_depth(depth)
     mg.slab_load(Pr, D, R, p)
     planned = mg.slab_plan()
     assert planned == min(depth, max(nz - 2, 1)) if depth != 2 else planned == 2
