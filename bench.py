@@ -366,8 +366,8 @@ def main():
             try:
                 tj = json.load(open(tfile))
                 key = "%dx%dx%d_%s_%s_x%d" % (nx, ny, nz, a.dtype, a.mode, its_per_launch)
-                if its_per_launch == 2:
-                    key += "_v%d" % ctx.last_pt2_variant()      # measured per tile shape (tools/collect_traffic.py)
+                if its_per_launch >= 2:                         # measured per tile shape (tools/collect_traffic.py)
+                    key += "_v%d" % (ctx.last_pt2_variant() if its_per_launch == 2 else ctx.last_ptn_variant())
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
