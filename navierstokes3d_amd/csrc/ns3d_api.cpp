@@ -55,10 +55,10 @@ static bool recip_ok(double d)
     if (!(f > 0x1p-20f && f < 0x1p20f) || (fb & 0x007FFFFFu) == 0x007FFFFFu) return false;
     return true;
 }
-// d = 2^e exactly, with 1/d representable in double and float alike
+// d = 2^e exactly with -30 ≤ e ≤ 0: 1/d and 1/d² are exact powers of two ≥ 1 in double and float alike (ns3d_strictp)
 static bool pow2_ok(double d)
 {
-    if (!(d > 0x1p-100 && d < 0x1p100)) return false;
+    if (!(d >= 0x1p-30 && d <= 1.0)) return false;
     int e;
     return std::frexp(d, &e) == 0.5;
 }
@@ -407,7 +407,7 @@ static Plan tune_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
     }
     // ---- three iterations per pass (k_pt_sweepN): fewer bytes per iteration, more arithmetic per byte — pays where the
     // two-iteration pass is bandwidth-bound (FAST mode, power-of-two spacings), not where it is VALU-bound.  Taken only for
-    // a clear per-ITERATION gain, head to head.
+    // a clear per-ITERATION gain (≥ 2 %), head to head.
     const long long cells = (long long)p->nx * p->ny * nk;
     if (c->pt_depth <= 0 && cells >= NS3D_DEEP_MIN_CELLS && nk >= 12) {
         static const int cand[] = {1100, 100, 1600, 600, 2200, 1132};   // the first one is the built-in shape: it wins near-ties
@@ -419,9 +419,9 @@ static Plan tune_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
                 if (!time_launch(3, v, ms)) continue;      // a shape that cannot run here (LDS / tile size)
                 if (best3 == 0.f || ms < 0.98f * best3) { best3 = ms; bestn = v; }
             }
-        if (best3 > 0.f && best3 / 3.f < 0.98f * ms2 / 2.f) {
+        if (best3 > 0.f && best3 / 3.f < 0.99f * ms2 / 2.f) {
             float a2 = 0.f, a3 = 0.f;
-            if (time_launch(2, pl.v2, a2, 6) && time_launch(3, bestn, a3, 6) && a3 / 3.f < 0.97f * a2 / 2.f) {
+            if (time_launch(2, pl.v2, a2, 6) && time_launch(3, bestn, a3, 6) && a3 / 3.f < 0.98f * a2 / 2.f) {
                 pl.depth = 3;
                 pl.vn = bestn;
             }

@@ -96,14 +96,17 @@ __device__ __forceinline__ float div_by_known(float x, float d, float r)
 #define DIV_ZZ(v) ((v)*g.rdz2)
 #define DIV_3(v) ((v) * (T)(1.0 / 3.0))
 #elif defined(NS3D_POW2_RECIP)
-// Every spacing is a power of two (checked on the host): r = 1/d is exact, so x·r and x/d are the SAME real number and
-// round identically — always, overflow and subnormal results included; x/d/d is two such steps.  No guard, no fall-back.
+// Every spacing is a power of two 2^-30 … 1 (checked on the host): r = 1/d = 2^k, k ≥ 0, is exact, so x·r and x/d are the SAME
+// real number and round identically — always, overflow included, and scaling UP never rounds (subnormal x too).  Hence
+// x/d/d = (x·r)·r = x·r² with ONE multiplication: if x·r is finite it is exact and x·r² is the one rounding the reference's
+// second division makes; if x·r overflows, so does x·r².  No guard, no fall-back.  (Fusing the products into the sums with
+// FMAs would be exact too EXCEPT where a product overflows and the sum does not — not taken.)
 #define DIV_X(v) ((v)*g.rdx)
 #define DIV_Y(v) ((v)*g.rdy)
 #define DIV_Z(v) ((v)*g.rdz)
-#define DIV_XX(v) (((v)*g.rdx) * g.rdx)
-#define DIV_YY(v) (((v)*g.rdy) * g.rdy)
-#define DIV_ZZ(v) (((v)*g.rdz) * g.rdz)
+#define DIV_XX(v) ((v)*g.rdx2)
+#define DIV_YY(v) ((v)*g.rdy2)
+#define DIV_ZZ(v) ((v)*g.rdz2)
 #define DIV_3(v) ((v) / (T)3.0)
 #elif defined(NS3D_EXACT_RECIP)
 #define DIV_X(v) div_by_known((v), g.dx, g.rdx)

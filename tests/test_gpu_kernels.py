@@ -372,15 +372,16 @@ def test_full_size_512_cubed_substeps_against_oracle_subslab(hip, oracle):
     ctx.close()
 
 
-POW2 = [dict(dx=1.0 / 64, dy=1.0 / 32, dz=1.0 / 128), dict(dx=0.5, dy=2.0, dz=1.0), dict(dx=2.0 ** -20, dy=2.0 ** -3, dz=4.0)]
+POW2 = [dict(dx=1.0 / 64, dy=1.0 / 32, dz=1.0 / 128), dict(dx=0.5, dy=1.0, dz=0.25), dict(dx=2.0 ** -20, dy=2.0 ** -3, dz=2.0 ** -30),
+        dict(dx=0.5, dy=2.0, dz=1.0)]     # the last one has a spacing > 1: not the power-of-two build, same bits all the same
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("sp", POW2)
 def test_power_of_two_spacings_strict_bitexact(hip, oracle, sp, dtype):
-    """Grids whose spacings are powers of two (512³ with lx = 1: dx = 2⁻⁹) run STRICT mode in the `ns3d_strictp` build, where
-    x/dx is x·(1/dx) — the same real number, hence the same rounding, always (d > 1 and d < 1, overflow and subnormal
-    results included).  Every kernel with a division against the oracle's plain divisions, bit for bit, including values
+    """Grids whose spacings are powers of two 2⁻³⁰…1 (512³ with lx = 1: dx = 2⁻⁹) run STRICT mode in the `ns3d_strictp` build,
+    where x/dx is x·(1/dx) and x/dx/dx is x·(1/dx²) — the same real numbers, hence the same roundings, always (overflow and
+    subnormal operands included).  Every kernel with a division against the oracle's plain divisions, bit for bit, including values
     that under/overflow when scaled."""
     import torch
     grid = (70, 9, 7)

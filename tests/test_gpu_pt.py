@@ -511,7 +511,8 @@ def test_pt_sweepn_plane_ranges_f32_fast_and_extremes(hip, oracle, nlev):
                 ctx.close()
 
 
-@pytest.mark.parametrize("sp", [dict(dx=1.0 / 64, dy=1.0 / 32, dz=1.0 / 128), dict(dx=0.5, dy=2.0, dz=1.0)])
+@pytest.mark.parametrize("sp", [dict(dx=1.0 / 64, dy=1.0 / 32, dz=1.0 / 128), dict(dx=0.5, dy=1.0, dz=2.0 ** -30),
+                                dict(dx=0.5, dy=2.0, dz=1.0)])
 def test_pt_power_of_two_spacings_every_kernel_family(hip, oracle, sp):
     """The fused PT kernels on power-of-two spacings (STRICT → the multiplication build, no range guard needed): single
     sweeps of every family, the two-iteration kernel in every tile shape, the N-iteration kernel — against the oracle's plain
