@@ -87,3 +87,24 @@ def test_product_never_imports_the_oracle():
     uses = [m.start() for m in re.finditer(r"from oracle", bench)]
     body = bench[bench.index("def cpu_baseline"):bench.index("def main")]
     assert len(uses) == 1 and "from oracle" in body
+
+
+def test_multi_gpu_layer_fails_loudly_without_gpu(L):
+    """ns3d_mgpu_create on a machine without a GPU: a NULL handle and a message, never a crash or a CPU path; the RCCL
+    loader either finds librccl (this image ships it) or reports NS3D_ERR_RCCL — also without a GPU."""
+    import ctypes as C
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-side check")
+    lib = L.load()
+    devs = (C.c_int * 2)(0, 0)
+    assert not lib.ns3d_mgpu_create(2, devs, 16, 16, 8, 0)
+    assert b"no HIP device" in lib.ns3d_last_error() or b"HIP" in lib.ns3d_last_error()
+    assert not lib.ns3d_mgpu_create(0, devs, 16, 16, 8, 0) and b"P = 0" in lib.ns3d_last_error()
+    buf = C.create_string_buffer(L.NS3D_UNIQUE_ID_BYTES)
+    rc = lib.ns3d_mgpu_unique_id(buf)
+    assert rc in (L.NS3D_OK, L.NS3D_ERR_RCCL)
+    assert lib.ns3d_mgpu_unique_id(None) == L.NS3D_ERR_ARG
+    for fn in ("ns3d_mgpu_world", "ns3d_mgpu_nlocal", "ns3d_mgpu_nz_g", "ns3d_mgpu_pass_depth"):
+        assert getattr(lib, fn)(None) == -1
+    assert lib.ns3d_slab_iterate(None, 1) == L.NS3D_ERR_ARG and lib.ns3d_mgpu_sync(None) == L.NS3D_ERR_ARG
