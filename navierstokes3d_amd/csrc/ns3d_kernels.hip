@@ -988,7 +988,6 @@ struct SweepArgs {
     int bc_kind, owns_outlet, zlo_halo, zhi_halo;
     int k0, k1; // interior planes [k0,k1) handled by this launch
     int kz;     // planes per block
-    int sched_L, sched_H; // k_pt_sweepN balanced mode: planes per workgroup (0: chunk mode) and band height
 };
 
 // value stored on the x planes for target plane kk (0-based)
@@ -1772,12 +1771,14 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
     const int nb = gridDim.x, b = blockIdx.x;
     const int q = nb >> 3, rem = nb & 7, xcd = b & 7, loc = b >> 3;
     const int tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
+    const int tx_t = tile % ntx, ty_t = (tile / ntx) % nty, tz_t = tile / (ntx * nty);
+    const int ox = 1 + tx_t * (TX - OV), oy = 1 + ty_t * (TY - OV);
+    const int kb = a.k0 + tz_t * a.kz;
+    const int ke = min(kb + a.kz, a.k1);
+    if (kb >= ke) return; // workgroup-uniform, before any barrier
+
     const int lx = threadIdx.x, wy = threadIdx.y;
     const int tid = wy * TX + lx;
-    // one SEGMENT = the planes [kb,ke) of one xy-tile, marched with the NL-level pipeline (workgroup-uniform arguments)
-    auto segment = [&](const int tx_t, const int ty_t, const int kb, const int ke) {
-    const int ox = 1 + tx_t * (TX - OV), oy = 1 + ty_t * (TY - OV);
-    if (kb >= ke) return; // workgroup-uniform, before any barrier
     const int gi = ox + lx;
     const int ci = min(gi, nx - 1), cii = min(gi, nx - 2);
     const idx_t sz = (idx_t)nx * ny;
@@ -2052,34 +2053,6 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
         __syncthreads();
         cur ^= 1;
     }
-    };   // segment
-
-    if (a.sched_L <= 0) {                        // chunk mode: one tile × one z-chunk of a.kz planes per workgroup
-        const int tz_t = tile / (ntx * nty);
-        const int kb = a.k0 + tz_t * a.kz;
-        segment(tile % ntx, (tile / ntx) % nty, kb, min(kb + a.kz, a.k1));
-        return;
-    }
-    // Balanced mode: the launch has exactly as many workgroups as the chip holds at once, and every workgroup marches the same
-    // number of planes: the (band, tile, plane) space — bands of a.sched_H planes, band-major, so that at any time the
-    // workgroups of an XCD sweep neighbouring tiles at about the same z and share their overlap rows in its L2 — is cut into
-    // gridDim.x equal consecutive pieces.  A piece that crosses a tile boundary costs one more pipeline fill; no workgroup idles
-    // in a ragged last round.
-    const int ntiles = ntx * nty, nk = a.k1 - a.k0, H = a.sched_H;
-    const long long total = (long long)ntiles * nk;
-    long long f0 = (long long)tile * a.sched_L;
-    const long long f1 = min(f0 + a.sched_L, total);
-    while (f0 < f1) {
-        const long long band_sz = (long long)ntiles * H;
-        const int band = (int)(f0 / band_sz);
-        const int Hb = min(H, nk - band * H);                  // the last band may be shorter
-        const int r = (int)(f0 - (long long)band * band_sz);
-        const int t = r / Hb, pl = r - t * Hb;
-        const int len = (int)min((long long)(Hb - pl), f1 - f0);
-        const int kb = a.k0 + band * H + pl;
-        segment(t % ntx, t / ntx, kb, kb + len);
-        f0 += len;
-    }
 }
 
 template <class T, int NL, int WX, int WY, int CPT, int PF, int MINW = 1>
@@ -2092,27 +2065,28 @@ static hipError_t launch_sweepN(hipStream_t s, SweepArgs<T> &a, int kz)
     } else {
     const int nk = a.k1 - a.k0;
     const int ntx = max(1, (a.nx - 2 - OV + (TX - OV) - 1) / (TX - OV)), nty = max(1, (a.ny - 2 - OV + (TY - OV) - 1) / (TY - OV));
-    static const int per_cu = workgroups_per_cu((const void *)k_pt_sweepN<T, NL, WX, WY, CPT, PF, MINW>, 64 * WX * WY);
-    const long slots = (long)device_cus() * per_cu, tiles = (long)ntx * nty;
-    unsigned nwg;
     if (kz <= 0 || kz > 90) {
-        // balanced schedule (k_pt_sweepN, "Balanced mode"): as many workgroups as the chip holds, equal plane counts; pieces
-        // shorter than ≈3 pipeline fills are not worth a workgroup of their own
-        const long long total = (long long)tiles * nk;
-        const int rounds = kz > 90 ? kz - 90 : 1;                    // 9m: m workgroups per slot (shorter pieces, more fills)
-        long long wgs = min((long long)slots * rounds, max(1ll, total / (3 * OV + 2)));
-        const int L = (int)((total + wgs - 1) / wgs);
-        wgs = (total + L - 1) / L;
-        a.sched_L = L;
-        a.sched_H = min(nk, L);
-        a.kz = nk;
-        nwg = (unsigned)wgs;
-    } else {
-        a.sched_L = 0; a.sched_H = 0;
-        a.kz = kz;
-        nwg = (unsigned)(tiles * ((nk + kz - 1) / kz));
+        static const int per_cu = workgroups_per_cu((const void *)k_pt_sweepN<T, NL, WX, WY, CPT, PF, MINW>, 64 * WX * WY);
+        const long slots = (long)device_cus() * per_cu, tiles = (long)ntx * nty;
+        const int want = kz > 90 ? kz - 90 : 2;
+        const int cmax = max(1, nk / (6 * NL));              // short chunks are mostly pipeline fill (2(NL−1) steps each)
+        long best_c = 1;
+        double best_fill = 0.0;
+        for (int m = want; m <= want + 12; ++m) {
+            long c = m * slots / tiles;
+            c = c < 1 ? 1 : (c > cmax ? cmax : c);
+            const int kzc = (int)((nk + c - 1) / c);
+            const long wgs = tiles * ((nk + kzc - 1) / kzc);
+            const double fill = (double)wgs / (double)(((wgs + slots - 1) / slots) * slots);
+            if (fill > best_fill + 1e-9) { best_fill = fill; best_c = c; }
+            if (fill >= 0.95 || c == cmax) break;
+        }
+        kz = (int)((nk + best_c - 1) / best_c);
     }
-    hipLaunchKernelGGL((k_pt_sweepN<T, NL, WX, WY, CPT, PF, MINW>), dim3(nwg), dim3(TX, WY, 1), 0, s, a, ntx, nty);
+    a.kz = kz;
+    const int ntz = (nk + kz - 1) / kz;
+    hipLaunchKernelGGL((k_pt_sweepN<T, NL, WX, WY, CPT, PF, MINW>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX, WY, 1), 0, s, a,
+                       ntx, nty);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = launch_faces<T>(s, a);
     return e;
@@ -2135,7 +2109,7 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
     a.outlet_val = (T)p.outlet_val; a.rho_g = (T)p.rho * (T)p.g;
     a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
     a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = 0; a.zhi_halo = 0;
-    a.k0 = k0; a.k1 = k1; a.kz = 1; a.sched_L = 0; a.sched_H = 0;
+    a.k0 = k0; a.k1 = k1; a.kz = 1;
     if (k1 <= k0) return hipSuccess;
     int shape = variant / 100, kz = variant % 100;
     if (variant == 0) { shape = 11; kz = 0; }     // 64×32 columns, next step's loads issued before level 1 (measured best at 512³)
@@ -2184,7 +2158,7 @@ hipError_t pt_sweep2(hipStream_t s, int variant, const T *Pin, T *Pout, const T 
     a.outlet_val = (T)p.outlet_val; a.rho_g = (T)p.rho * (T)p.g;
     a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
     a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = 0; a.zhi_halo = 0;
-    a.k0 = k0; a.k1 = k1; a.kz = 1; a.sched_L = 0; a.sched_H = 0;
+    a.k0 = k0; a.k1 = k1; a.kz = 1;
     if (k1 <= k0) return hipSuccess;
     int shape = variant / 100;
     int kz = variant % 100;
@@ -2233,7 +2207,7 @@ hipError_t pt_sweep(hipStream_t s, int variant, const T *Pin, T *Pout, T *D, con
     a.outlet_val = (T)p.outlet_val; a.rho_g = (T)p.rho * (T)p.g;
     a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
     a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = p.z_lo_is_halo; a.zhi_halo = p.z_hi_is_halo;
-    a.k0 = k0; a.k1 = k1; a.kz = 1; a.sched_L = 0; a.sched_H = 0;
+    a.k0 = k0; a.k1 = k1; a.kz = 1;
     if (k1 <= k0) return hipSuccess;
     // variant = family*100 + kz  (kz = planes marched per block; 0 → default); variant 0 = choose by grid size:
     // grids whose four PT arrays stay resident in L2 / Infinity Cache run best with one thread per cell (neighbours are
