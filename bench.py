@@ -391,6 +391,10 @@ def main():
                          "frac": physical / HBM_PEAK_GBPS,
                          "definition": "bytes one launch must move (one pass: itemsize*(N+4*N_inner)) / launch time / peak",
                          "traffic": traffic, "traffic_source": "profiles lookup" if traffic is not None else "none",
+                         # what the memory system actually delivered: PMC bytes of a launch / launch time (the overlap rows of
+                         # neighbouring tiles are read more than once, so this exceeds `achieved`)
+                         "hbm_gbps_measured": (traffic / (kern_ms * 1e-3) / 1e9) if traffic is not None else None,
+                         "hbm_frac_measured": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic is not None else None,
                          "kernel": {1: "k_pt_sweep", 2: "k_pt_sweep2"}.get(its_per_launch, "k_pt_sweepN<%d levels>" % its_per_launch),
                          "kernel_ms": kern_ms,
                          "pt_iterations_per_launch": its_per_launch, "bytes_per_launch": must_move,
