@@ -264,14 +264,28 @@ def gpu_initial_fields(p):
     return Vx, Pr
 
 
+def _save_mat(path, f, p, step0):
+    """matwrite("out_save/step_$it.mat", Dict("Pr","Vx","Vy","Vz","C","dx","dy","dz")) (gpu.jl:168-170); the step-0 dictionary
+    of gpu.jl:89 repeats the key "Vy" — the later pair wins in a Julia Dict literal, so it holds Vz's array under "Vy" and has
+    no "Vz" — reproduced.  Written as MAT v5 (scipy.io.savemat; MAT.jl writes v7.3/HDF5 by default and reads both, as do MATLAB
+    and Octave): same variable names, shapes and Float64 values, different container version."""
+    from scipy.io import savemat
+    d = {"Pr": K.to_numpy(f.Pr), "Vx": K.to_numpy(f.Vx), "C": K.to_numpy(f.C), "dx": p.dx, "dy": p.dy, "dz": p.dz}
+    if step0:
+        d["Vy"] = K.to_numpy(f.Vz)
+    else:
+        d["Vy"] = K.to_numpy(f.Vy)
+        d["Vz"] = K.to_numpy(f.Vz)
+    savemat(path, d, format="5", do_compression=False, oned_as="column")
+
+
 def runme(do_vis=False, do_save=False, *, nx=255, nt=10000, mode="strict", fused=True, dtype=torch.float64,
           faithful=True, device=None, niter_cap=None, do_print=False, initial=None):
     """runme (gpu.jl:12-173): single device, gravity, hydrostatic x-planes.  Returns (fields, info).
-    nx/nt are literals in the reference (gpu.jl:44,51: 255, 10000) and keyword options here."""
+    nx/nt are literals in the reference (gpu.jl:44,51: 255, 10000) and keyword options here.  do_save writes the MAT files
+    of gpu.jl:89,168-170 (step 0 and every nsave = 10 steps)."""
     if do_vis:
         raise NotImplementedError("plotting (gpu.jl:90-117, 143-167) is out of scope of this build")
-    if do_save:
-        raise NotImplementedError("MAT-file output (gpu.jl:89,168-170) is out of scope of this build")
     if device is None:
         device = torch.cuda.current_device()
     dev = torch.device("cuda", device)
@@ -286,6 +300,11 @@ def runme(do_vis=False, do_save=False, *, nx=255, nt=10000, mode="strict", fused
     cyl = (p.a2, p.b2, p.ox, p.oy, p.sinb, p.cosb, p.lx, p.ly, p.lz, p.dx, p.dy, p.dz)
     pt = K.pt_params(f.Pr, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, L.NS3D_BC_GPU, False, 0.0, p.g)
     info = SimpleNamespace(iters=[], errs=[], params=p)
+    nsave = 10                                                                                # :52
+    if do_save:                                                                               # :89
+        os.makedirs("./out_save", exist_ok=True)
+        ctx.sync()
+        _save_mat("out_save/step_0.mat", f, p, True)
     for it in range(1, nt + 1):                                                               # :119
         K.update_tau(f.txx, f.tyy, f.tzz, f.txy, f.txz, f.tyz, f.Vx, f.Vy, f.Vz, p.mu, p.dx, p.dy, p.dz, ctx=ctx)  # :121
         K.predict_V(f.Vx, f.Vy, f.Vz, f.txx, f.tyy, f.tzz, f.txy, f.txz, f.tyz, p.rho, p.g, p.dt, p.dx, p.dy, p.dz,
@@ -319,6 +338,9 @@ def runme(do_vis=False, do_save=False, *, nx=255, nt=10000, mode="strict", fused
         K.copy(f.Vx_o, f.Vx, ctx=ctx); K.copy(f.Vy_o, f.Vy, ctx=ctx)                          # :141
         K.copy(f.Vz_o, f.Vz, ctx=ctx); K.copy(f.C_o, f.C, ctx=ctx)
         K.advect(f.Vx, f.Vx_o, f.Vy, f.Vy_o, f.Vz, f.Vz_o, f.C, f.C_o, p.dt, p.dx, p.dy, p.dz, faithful, ctx=ctx)  # :142
+        if do_save and it % nsave == 0:                                                       # :168-170
+            ctx.sync()
+            _save_mat("out_save/step_%d.mat" % it, f, p, False)
     ctx.sync()
     info.ctx = ctx
     return f, info
