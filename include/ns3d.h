@@ -227,15 +227,20 @@ NS3D_DECL(float, f32)
 #undef NS3D_DECL
 
 /* =====================================================================================================================
- * Multi-GPU: z-slab implicit global grid.  Replaces what multi.jl gets from ImplicitGlobalGrid.jl + MPI.jl:
- *     init_global_grid(nx,ny,nz)   multi.jl:325      →  ns3d_mgpu_create / ns3d_mgpu_create_rank   (dims = (1,1,P))
+ * Multi-GPU: the implicit global grid.  Replaces what multi.jl gets from ImplicitGlobalGrid.jl + MPI.jl:
+ *     init_global_grid(nx,ny,nz)   multi.jl:325      →  ns3d_mgpu_create / ns3d_mgpu_create_rank   (dims = (1,1,P): z-slabs)
+ *                                                       ns3d_mgpu_create_cart / _create_rank_cart  (any dims; ns3d_dims_create =
+ *                                                       the MPI_Dims_create default of init_global_grid)
  *     update_halo!(A…)             multi.jl:371,373,450,453,455,460,462,182,167,477  →  ns3d_update_halo
  *     max_g(A)                     multi.jl:21,466   →  ns3d_max_g
  *     gather!(A_inn, A_v)          multi.jl:399-403,528-532  →  ns3d_gather
  *     nz_g()                       multi.jl:328,338  →  ns3d_mgpu_nz_g            finalize_global_grid() :534 → ns3d_mgpu_destroy
  * ImplicitGlobalGrid's indexing is kept: overlap 2, halo width 1, nz_g = P·(nz−2)+2; an array with nz+s planes has overlap
  * 2+s (sends plane 2+s / size−(1+s), receives into 1 / size, 1-based); arrays with overlap < 2 have no halo; physical ends
- * are left untouched.  Column-major xy-planes are contiguous, so every message is one block (no packing).
+ * are left untouched; the same rule per dimension for a Cartesian topology, dimensions in the order x, y, z so that edge and
+ * corner values arrive in two / three hops.  Column-major xy-planes are contiguous, so a z message is one block as it lies;
+ * x and y faces are packed / unpacked by a kernel on both ends.  The fused path (ns3d_slab_*, ns3d_pt_solve_slab) takes
+ * z-slab topologies only: on a grid decomposed in x or y the loop multi.jl:458-471 runs kernel by kernel with ns3d_update_halo.
  *
  * An ns3d_mgpu holds `nlocal` of the P ranks: all P in the one-process form (ns3d_mgpu_create; planes move by
  * hipMemcpyPeerAsync over xGMI; a device may appear several times — virtual ranks), exactly one in the one-process-per-GPU
@@ -248,14 +253,24 @@ typedef struct ns3d_mgpu ns3d_mgpu;
 #define NS3D_UNIQUE_ID_BYTES 128
 
 ns3d_mgpu *ns3d_mgpu_create(int P, const int *devices, int nx, int ny, int nz_local, int flags);
+/* dims[3] = ranks per dimension; rank order is MPI_Cart's (rank = (cx·dims[1] + cy)·dims[2] + cz); devices[rank] */
+ns3d_mgpu *ns3d_mgpu_create_cart(const int *dims, const int *devices, int nx, int ny, int nz, int flags);
+/* MPI_Dims_create: entries > 0 of dims[3] are kept, zeros are filled with the most balanced factorisation, non-increasing
+ * (P = 8 → 2,2,2; 4 → 2,2,1; 2 → 2,1,1; 12 → 3,2,2) — what init_global_grid(nx,ny,nz) uses when dimx/dimy/dimz are not given */
+int ns3d_dims_create(int P, int *dims);
 /* One process per GPU: rank 0 calls ns3d_mgpu_unique_id and distributes the NS3D_UNIQUE_ID_BYTES bytes (MPI.Bcast in the
  * reference's setting), then every rank calls ns3d_mgpu_create_rank (collective).  RCCL is loaded at run time. */
 int ns3d_mgpu_unique_id(void *id_out);
 ns3d_mgpu *ns3d_mgpu_create_rank(int P, int rank, int device, const void *unique_id, int nx, int ny, int nz_local, int flags);
+ns3d_mgpu *ns3d_mgpu_create_rank_cart(const int *dims, int rank, int device, const void *unique_id, int nx, int ny, int nz,
+                                      int flags);
 void ns3d_mgpu_destroy(ns3d_mgpu *m);
 int ns3d_mgpu_world(const ns3d_mgpu *m);               /* P */
 int ns3d_mgpu_nlocal(const ns3d_mgpu *m);
-int ns3d_mgpu_rank(const ns3d_mgpu *m, int local);     /* z coordinate ("me") of a local rank */
+int ns3d_mgpu_rank(const ns3d_mgpu *m, int local);     /* "me" of a local rank (= its z coordinate for z-slabs) */
+int ns3d_mgpu_dims(const ns3d_mgpu *m, int *dims_out);                 /* 3 ints */
+int ns3d_mgpu_coords(const ns3d_mgpu *m, int local, int *coords_out);  /* 3 ints: MPI_Cart_coords of a local rank */
+int ns3d_mgpu_n_g(const ns3d_mgpu *m, int *n_g_out);                   /* nx_g(), ny_g(), nz_g(): dims·(n−2)+2 */
 ns3d_ctx *ns3d_mgpu_ctx(ns3d_mgpu *m, int local);
 int ns3d_mgpu_nz_g(const ns3d_mgpu *m);
 const char *ns3d_mgpu_transport(const ns3d_mgpu *m);   /* "peer" | "rccl" */
@@ -279,8 +294,9 @@ int ns3d_slab_residual(ns3d_mgpu *m, double *out);
 #define NS3D_MGPU_DECL(T, S)                                                                                \
     /* extents: 3 ints (sx,sy,sz) per field */                                                              \
     int ns3d_update_halo_##S(ns3d_mgpu *m, T *const *fields, const int *extents, int nfields);              \
-    /* halo-stripped blocks A[2:end-1,2:end-1,2:end-1] of every rank, concatenated along z, into out_host   \
-     * ((sx-2)·(sy-2)·P·(sz-2) elements; rank 0's process only in the one-process-per-GPU form) */           \
+    /* halo-stripped blocks A[2:end-1,2:end-1,2:end-1] of every rank, placed side by side in rank-coordinate \
+     * order, into the column-major out_host (dims[0]·(sx-2) × dims[1]·(sy-2) × dims[2]·(sz-2) elements;     \
+     * rank 0's process only in the one-process-per-GPU form) */                                             \
     int ns3d_gather_##S(ns3d_mgpu *m, const T *const *A, int sx, int sy, int sz, T *out_host);              \
     int ns3d_slab_load_##S(ns3d_mgpu *m, const T *const *Pr, const T *const *dPrdtau, const T *const *divV, \
                            const ns3d_pt_params *p);                                                        \

@@ -7,7 +7,8 @@
 #                             (gpu.jl:2-8, multi.jl:2-8, :343-360, :370; every `@parallel kernel!(…)` call site)
 #   the 14/16 kernel bodies   multi.jl:36-281 / gpu.jl:177-368 — same names, same positional arguments, each one `ccall`
 #   ImplicitGlobalGrid.jl     init_global_grid, nx_g/ny_g/nz_g, x_g/y_g/z_g, update_halo!, gather!, finalize_global_grid
-#                             (multi.jl:9, :325, :328-338, :363-367, :371…, :399-403, :534) for dims = (1,1,P): z-slabs
+#                             (multi.jl:9, :325, :328-338, :363-367, :371…, :399-403, :534); the topology is
+#                             MPI_Dims_create's unless dimx/dimy/dimz are given, as in ImplicitGlobalGrid
 #
 # What changes in a script: ONLY its header.  Lines multi.jl:1-13 (resp. gpu.jl:1-10) become
 #
@@ -26,7 +27,9 @@
 # STATUS: NOT EXECUTED.  There is no Julia toolchain in the build container or on the GPU box (SURVEY.md §8c), so this
 # file has been checked on paper only, against multi.jl:1-13,36-102,325-373 and gpu.jl:1-10,175-368.  Every C entry point
 # it binds is exercised through the identical C ABI by the Python/ctypes host layer (navierstokes3d_amd/kernels.py,
-# mgpu.py) and its GPU parity tests.  Deviation from ImplicitGlobalGrid: the topology is always (1,1,P) — z-slabs.
+# mgpu.py) and its GPU parity tests.  `init_global_grid(nx,ny,nz; dimx=1, dimy=1)` gives the z-slabs the fused
+# `pt_solve_slab!` needs; without keywords the topology is ImplicitGlobalGrid's default (results depend on it: damp uses the
+# local nx, multi.jl:340, and advect! clamps at local array ends).
 # Arrays are AMDGPU.jl `ROCArray{T,3}` (packed, column-major: the layout ns3d.h requires), passed as device pointers.
 module NS3DShim
 
@@ -263,7 +266,7 @@ end
 """
     pt_solve_slab!(Pr, dPrdτ, ∇V, ρ, dt, dτ, damp, dx, dy, dz; …) -> (iters, errs)
 
-The same loop on a z-slab rank after `init_global_grid` (`ns3d_pt_solve_slab_f64`): two ghost planes per seam, seam planes
+The same loop on a z-slab rank after `init_global_grid(…; dimx=1, dimy=1)` (`ns3d_pt_solve_slab_f64`): two ghost planes per seam, seam planes
 swept first, their RCCL exchange behind the interior sweep, global residual by ncclAllReduce.  Collective over the ranks.
 """
 function pt_solve_slab!(Pr, dPrdτ, ∇V, ρ, dt, dτ, damp, dx, dy, dz; owns_outlet = true, g = 0.0, εit = 1e-3, niter, nchk, ly, psc)
@@ -280,31 +283,39 @@ function pt_solve_slab!(Pr, dPrdτ, ∇V, ρ, dt, dτ, damp, dx, dy, dz; owns_ou
     return Int(it[]), hist[1:nchecks[]]
 end
 
-# ---- ImplicitGlobalGrid's surface for dims = (1,1,P) (multi.jl:325-373, 399-403, 528-534) ---------------------------
+# ---- ImplicitGlobalGrid's surface (multi.jl:325-373, 399-403, 528-534) ----------------------------------------------
 """
-    me, dims = init_global_grid(nx, ny, nz)
+    me, dims = init_global_grid(nx, ny, nz; dimx=0, dimy=0, dimz=0)
 
-multi.jl:325.  One MPI rank per GPU, z-slabs: MPI is initialised, rank 0 makes an RCCL unique id (`ns3d_mgpu_unique_id`)
-and broadcasts it, every rank joins the communicator (`ns3d_mgpu_create_rank`, collective) and takes its kernel context
-from it.  With one rank this is `ns3d_create` and every halo call below is a no-op, as in the reference's own test.
+multi.jl:325.  One MPI rank per GPU.  The topology is ImplicitGlobalGrid's: `MPI.Dims_create!` over the entries left 0
+(`ns3d_dims_create`), ranks in `MPI.Cart_create` order (last dimension fastest); `dimx=1, dimy=1` gives z-slabs.  MPI is
+initialised, rank 0 makes an RCCL unique id (`ns3d_mgpu_unique_id`) and broadcasts it, every rank joins the communicator
+(`ns3d_mgpu_create_rank_cart`, collective) and takes its kernel context from it.  With one rank every halo call below is
+a no-op, as in the reference's own test.
 """
-function init_global_grid(nx::Integer, ny::Integer, nz::Integer; quiet::Bool = true)
+function init_global_grid(nx::Integer, ny::Integer, nz::Integer; dimx::Integer = 0, dimy::Integer = 0, dimz::Integer = 0,
+                          quiet::Bool = true)
     MPI.Initialized() || MPI.Init()
     comm = MPI.COMM_WORLD
     me, P = MPI.Comm_rank(comm), MPI.Comm_size(comm)
     device = me % length(AMDGPU.devices())
     AMDGPU.device!(AMDGPU.devices()[device + 1])
+    dims = Cint[dimx, dimy, dimz]
+    check(ccall((:ns3d_dims_create, libns3d), Cint, (Cint, Ptr{Cint}), P, dims))
     id = Vector{UInt8}(undef, NS3D_UNIQUE_ID_BYTES)
     me == 0 && check(ccall((:ns3d_mgpu_unique_id, libns3d), Cint, (Ptr{UInt8},), id))
     MPI.Bcast!(id, 0, comm)
-    MGPU[] = ccall((:ns3d_mgpu_create_rank, libns3d), Ptr{Cvoid}, (Cint, Cint, Cint, Ptr{UInt8}, Cint, Cint, Cint, Cint),
-                   P, me, device, id, nx, ny, nz, MODE[])
-    MGPU[] == C_NULL && throw(Ns3dError("ns3d_mgpu_create_rank failed: $(lasterror())"))
+    MGPU[] = ccall((:ns3d_mgpu_create_rank_cart, libns3d), Ptr{Cvoid},
+                   (Ptr{Cint}, Cint, Cint, Ptr{UInt8}, Cint, Cint, Cint, Cint), dims, me, device, id, nx, ny, nz, MODE[])
+    MGPU[] == C_NULL && throw(Ns3dError("ns3d_mgpu_create_rank_cart failed: $(lasterror())"))
     OWNS_CTX[] && CTX[] != C_NULL && ccall((:ns3d_destroy, libns3d), Cvoid, (Ptr{Cvoid},), CTX[])
     CTX[] = ccall((:ns3d_mgpu_ctx, libns3d), Ptr{Cvoid}, (Ptr{Cvoid}, Cint), MGPU[], 0)     # owned by the ns3d_mgpu
     OWNS_CTX[] = false
-    GRID[] = (nx = Int(nx), ny = Int(ny), nz = Int(nz), me = me, dims = (1, 1, P), coords = (0, 0, me))
-    return me, [1, 1, P]
+    coords = Cint[0, 0, 0]
+    check(ccall((:ns3d_mgpu_coords, libns3d), Cint, (Ptr{Cvoid}, Cint, Ptr{Cint}), MGPU[], 0, coords))
+    GRID[] = (nx = Int(nx), ny = Int(ny), nz = Int(nz), me = me, dims = (Int(dims[1]), Int(dims[2]), Int(dims[3])),
+              coords = (Int(coords[1]), Int(coords[2]), Int(coords[3])))
+    return me, Int.(dims)
 end
 "finalize_global_grid()  multi.jl:534"
 function finalize_global_grid(; finalize_MPI::Bool = true)
@@ -326,9 +337,9 @@ x_g(ix::Integer, dx, A) = _g(ix, dx, size(A, 1), GRID[].nx, GRID[].coords[1])
 y_g(iy::Integer, dy, A) = _g(iy, dy, size(A, 2), GRID[].ny, GRID[].coords[2])
 z_g(iz::Integer, dz, A) = _g(iz, dz, size(A, 3), GRID[].nz, GRID[].coords[3])
 
-"update_halo!(A…)  multi.jl:371,373,450,453,455,460,462,182,167,477 → ns3d_update_halo_f64 (one contiguous plane per side and field)"
+"update_halo!(A…)  multi.jl:371,373,450,453,455,460,462,182,167,477 → ns3d_update_halo_f64 (x, y, z in turn; z planes as they lie, x / y faces packed by a kernel)"
 function update_halo!(A...)
-    (MGPU[] == C_NULL || GRID[].dims[3] == 1) && return nothing
+    (MGPU[] == C_NULL || prod(GRID[].dims) == 1) && return nothing
     ptrs = PF[ptr(a) for a in A]
     ext = Cint[]
     for a in A
@@ -344,21 +355,35 @@ end
     gather!(A_inn, A_v)
 
 multi.jl:399-403,528-532: the script passes HOST arrays (`Array(A)[2:end-1,2:end-1,2:end-1]`), so this is ImplicitGlobalGrid's
-host gather: rank blocks concatenated along z are contiguous in a column-major array, hence one `MPI.Gather!`.
-(For device arrays `ns3d_gather_f64` strips the halo and gathers over RCCL; see mgpu.py for its use.)
+host gather: one `MPI.Gather!` of the rank blocks, which the root then places by rank coordinates (z-slab blocks of a
+column-major array are already in place).  (For device arrays `ns3d_gather_f64` strips the halo and gathers over RCCL;
+see mgpu.py for its use.)
 """
 function gather!(A_inn::Array, A_v; root::Integer = 0)
-    if GRID[].dims[3] == 1
+    dims = GRID[].dims
+    P = prod(dims)
+    if P == 1
         A_v .= A_inn
         return nothing
     end
     # ImplicitGlobalGrid requires size(A_v) == dims .* size(A_inn) and errors otherwise; multi.jl's Vz pair (nz-1 planes per
-    # rank into P(nz-2)+1) violates that for P > 1 in z — the reference itself cannot gather Vz on more than one z rank
-    if GRID[].me == root
-        length(A_v) == GRID[].dims[3] * length(A_inn) || error("gather!: size(A_v) must be dims .* size(A_inn)")
-        MPI.Gather!(A_inn, MPI.UBuffer(vec(A_v), length(A_inn)), root, MPI.COMM_WORLD)
-    else
+    # rank into dims[3]·(nz-2)+1) violates that for more than one z rank — the reference itself cannot gather Vz there
+    if GRID[].me != root
         MPI.Gather!(A_inn, nothing, root, MPI.COMM_WORLD)
+        return nothing
+    end
+    size(A_v) == dims .* size(A_inn) || error("gather!: size(A_v) must be dims .* size(A_inn)")
+    n = length(A_inn)
+    if dims[1] == 1 && dims[2] == 1
+        MPI.Gather!(A_inn, MPI.UBuffer(vec(A_v), n), root, MPI.COMM_WORLD)
+        return nothing
+    end
+    blocks = Vector{eltype(A_inn)}(undef, n * P)
+    MPI.Gather!(A_inn, MPI.UBuffer(blocks, n), root, MPI.COMM_WORLD)
+    bx, by, bz = size(A_inn)
+    for q in 0:P-1                                    # MPI_Cart_coords: last dimension fastest
+        cx, cy, cz = q ÷ (dims[2] * dims[3]), (q ÷ dims[3]) % dims[2], q % dims[3]
+        A_v[cx*bx+1:(cx+1)*bx, cy*by+1:(cy+1)*by, cz*bz+1:(cz+1)*bz] .= reshape(view(blocks, q*n+1:(q+1)*n), bx, by, bz)
     end
     return nothing
 end

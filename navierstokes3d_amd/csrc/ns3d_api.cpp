@@ -536,6 +536,11 @@ hipError_t ns3d_enqueue_strip_inner(ns3d_ctx *c, hipStream_t s, const T *A, T *o
 {
     return DISPATCH(c, strip_inner<T>(s, A, out, sx, sy, sz));
 }
+template <class T>
+hipError_t ns3d_enqueue_face_copy(ns3d_ctx *c, hipStream_t s, T *A, T *buf, int sx, int sy, int sz, int dim, int idx, int unpack)
+{
+    return DISPATCH(c, face_copy<T>(s, A, buf, sx, sy, sz, dim, idx, unpack));
+}
 #define NS3D_INST_INTERNAL(T)                                                                                       \
     template hipError_t ns3d_enqueue_pt2<T>(ns3d_ctx *, hipStream_t, const T *, T *, const T *, T *, const T *,      \
                                             const ns3d_pt_params *, int, int);                                      \
@@ -547,7 +552,8 @@ hipError_t ns3d_enqueue_strip_inner(ns3d_ctx *c, hipStream_t s, const T *A, T *o
                                             const ns3d_pt_params *, int, int);                                      \
     template hipError_t ns3d_enqueue_residual_key<T>(ns3d_ctx *, hipStream_t, const T *, const T *,                  \
                                                      const ns3d_pt_params *, unsigned long long *);                 \
-    template hipError_t ns3d_enqueue_strip_inner<T>(ns3d_ctx *, hipStream_t, const T *, T *, int, int, int);
+    template hipError_t ns3d_enqueue_strip_inner<T>(ns3d_ctx *, hipStream_t, const T *, T *, int, int, int);         \
+    template hipError_t ns3d_enqueue_face_copy<T>(ns3d_ctx *, hipStream_t, T *, T *, int, int, int, int, int, int);
 NS3D_INST_INTERNAL(double)
 NS3D_INST_INTERNAL(float)
 #undef NS3D_INST_INTERNAL

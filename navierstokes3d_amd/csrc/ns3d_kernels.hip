@@ -950,6 +950,34 @@ hipError_t strip_inner(hipStream_t s, const T *A, T *out, int sx, int sy, int sz
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// One x- or y-face of a packed column-major array ↔ a packed message buffer (update_halo! of a 3-D Cartesian topology:
+// z faces are contiguous planes and travel as they lie, x / y faces are strided and go through this kernel on both ends).
+// dim 0: the face A[idx,:,:] (sy·sz elements, stride sx) ; dim 1: A[:,idx,:] (sx·sz, rows of sx contiguous elements).
+// ---------------------------------------------------------------------------------------------------------
+template <class T, bool UNPACK>
+__global__ __launch_bounds__(256) void k_face_copy(T *__restrict__ A, T *__restrict__ buf, int sx, int sy, int sz, int dim, int idx)
+{
+    const int na = dim == 0 ? sy : sx;
+    const long n = (long)na * sz, t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int a = (int)(t % na), k = (int)(t / na);
+    const size_t ia = dim == 0 ? IX3(idx, a, k, sx, sy) : IX3(a, idx, k, sx, sy);
+    if (UNPACK) A[ia] = buf[t];
+    else buf[t] = A[ia];
+}
+template <class T>
+hipError_t face_copy(hipStream_t s, T *A, T *buf, int sx, int sy, int sz, int dim, int idx, int unpack)
+{
+    const long n = (long)(dim == 0 ? sy : sx) * sz;
+    if (n <= 0) return hipSuccess;
+    if (dim < 0 || dim > 1 || idx < 0 || idx >= (dim == 0 ? sx : sy)) return hipErrorInvalidValue;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (unpack) hipLaunchKernelGGL((k_face_copy<T, true>), dim3(nb), dim3(256), 0, s, A, buf, sx, sy, sz, dim, idx);
+    else hipLaunchKernelGGL((k_face_copy<T, false>), dim3(nb), dim3(256), 0, s, A, buf, sx, sy, sz, dim, idx);
+    return hipGetLastError();
+}
+
 // =========================================================================================================
 // The fused pseudo-transient sweep  —  THE hot kernel (≥98 % of all bytes moved).
 //
@@ -2373,7 +2401,8 @@ hipError_t divtest(hipStream_t s, double d, long n, unsigned long long seed, uns
     template hipError_t residual_max_key<T>(hipStream_t, const T *, const T *, const ns3d_pt_params &,       \
                                             unsigned long long *);                                           \
     template hipError_t divtest<T>(hipStream_t, double, long, unsigned long long, unsigned long long *);   \
-    template hipError_t strip_inner<T>(hipStream_t, const T *, T *, int, int, int);
+    template hipError_t strip_inner<T>(hipStream_t, const T *, T *, int, int, int);                          \
+    template hipError_t face_copy<T>(hipStream_t, T *, T *, int, int, int, int, int, int);
 INST(double)
 INST(float)
 #undef INST

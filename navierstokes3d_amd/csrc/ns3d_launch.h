@@ -54,6 +54,8 @@
     hipError_t divtest(hipStream_t, double d, long n, unsigned long long seed, unsigned long long *bad_dev); \
     template <class T>                                                                                       \
     hipError_t strip_inner(hipStream_t, const T *A, T *out, int sx, int sy, int sz);                         \
+    template <class T>                                                                                       \
+    hipError_t face_copy(hipStream_t, T *A, T *buf, int sx, int sy, int sz, int dim, int idx, int unpack);   \
     }
 
 NS3D_LAUNCHER_DECLS(ns3d_strict)

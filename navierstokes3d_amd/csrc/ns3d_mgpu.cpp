@@ -102,6 +102,10 @@ struct SlabState {                // deep-ghost pseudo-transient state (library-
 };
 struct MRank {
     int rank = 0, device = 0;
+    int coords[3] = {0, 0, 0};                     // Cartesian coordinates (MPI_Cart_coords order: last dimension fastest)
+    int nbr[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}}; // neighbour ranks per dimension (lower, upper), −1 at a physical end
+    void *hbuf = nullptr;                          // update_halo!: packed x / y faces (send lo, send hi, recv lo, recv hi per field)
+    size_t hbuf_bytes = 0;
     ns3d_ctx *ctx = nullptr;
     hipStream_t comm = nullptr;                    // halo traffic (high priority)
     hipEvent_t ev_ready = nullptr, ev_landed = nullptr;
@@ -118,6 +122,8 @@ struct Block {                    // one contiguous piece that travels to both n
 
 struct ns3d_mgpu {
     int P = 1, nx = 0, ny = 0, nz = 0, flags = 0;
+    int dims[3] = {1, 1, 1};      // process topology; (1,1,P) = z-slabs (the only one the fused ns3d_slab_* path takes)
+    std::vector<char> hstage;     // gather! of an x/y-decomposed grid: rank blocks on the host before they are placed
     std::vector<MRank> loc;
     bool rccl = false;
     ncclComm_t comm = nullptr;
@@ -134,13 +140,20 @@ struct ns3d_mgpu {
 
 namespace {
 
-bool has_lower(const ns3d_mgpu *m, const MRank &r) { (void)m; return r.rank > 0; }
-bool has_upper(const ns3d_mgpu *m, const MRank &r) { return r.rank < m->P - 1; }
+bool has_lower(const ns3d_mgpu *m, const MRank &r) { (void)m; return r.nbr[2][0] >= 0; }     // z neighbours (slab code)
+bool has_upper(const ns3d_mgpu *m, const MRank &r) { (void)m; return r.nbr[2][1] >= 0; }
 hipStream_t compute(const MRank &r) { return r.ctx->stream; }
+bool z_slabs(const ns3d_mgpu *m) { return m->dims[0] == 1 && m->dims[1] == 1; }
+
+void cart_coords(int rank, const int dims[3], int c[3])
+{
+    c[0] = rank / (dims[1] * dims[2]); c[1] = (rank / dims[2]) % dims[1]; c[2] = rank % dims[2];
+}
+int cart_rank(const int c[3], const int dims[3]) { return (c[0] * dims[1] + c[1]) * dims[2] + c[2]; }
 
 // Post the exchange of `blocks[l]` (same count and sizes on every rank): everything up to "the ghosts have landed" is
 // enqueued on the communication streams, ordered after what the compute streams hold NOW.
-int exchange_begin(ns3d_mgpu *m, const std::vector<std::vector<Block>> &blocks)
+int exchange_begin(ns3d_mgpu *m, const std::vector<std::vector<Block>> &blocks, int dim = 2)
 {
     const int n = (int)m->loc.size();
     if (m->P == 1) return NS3D_OK;
@@ -154,40 +167,43 @@ int exchange_begin(ns3d_mgpu *m, const std::vector<std::vector<Block>> &blocks)
         ns3d_device_guard g(r.device);
         HIPCHK(0, hipStreamWaitEvent(r.comm, r.ev_ready, 0));
         NCCLCHK(g_rccl.GroupStart());
+        const int lo = r.nbr[dim][0], hi = r.nbr[dim][1];
         for (const Block &b : blocks[0]) {
-            if (has_lower(m, r)) {
-                NCCLCHK(g_rccl.Send(b.send_lo, b.bytes, ncclUint8, r.rank - 1, m->comm, r.comm));
-                NCCLCHK(g_rccl.Recv(b.recv_lo, b.bytes, ncclUint8, r.rank - 1, m->comm, r.comm));
+            if (lo >= 0) {
+                NCCLCHK(g_rccl.Send(b.send_lo, b.bytes, ncclUint8, lo, m->comm, r.comm));
+                NCCLCHK(g_rccl.Recv(b.recv_lo, b.bytes, ncclUint8, lo, m->comm, r.comm));
             }
-            if (has_upper(m, r)) {
-                NCCLCHK(g_rccl.Send(b.send_hi, b.bytes, ncclUint8, r.rank + 1, m->comm, r.comm));
-                NCCLCHK(g_rccl.Recv(b.recv_hi, b.bytes, ncclUint8, r.rank + 1, m->comm, r.comm));
+            if (hi >= 0) {
+                NCCLCHK(g_rccl.Send(b.send_hi, b.bytes, ncclUint8, hi, m->comm, r.comm));
+                NCCLCHK(g_rccl.Recv(b.recv_hi, b.bytes, ncclUint8, hi, m->comm, r.comm));
             }
         }
         NCCLCHK(g_rccl.GroupEnd());
         HIPCHK(0, hipEventRecord(r.ev_landed, r.comm));
         return NS3D_OK;
     }
-    // one process, P devices: every receiver pulls its ghost planes from its neighbours once BOTH sides are ready
+    // one process, P devices (local index == rank): every receiver pulls its ghost planes from its neighbours once BOTH
+    // sides are ready
     for (int l = 0; l < n; ++l) {
         MRank &r = m->loc[l];
+        const int lo = r.nbr[dim][0], hi = r.nbr[dim][1];
         ns3d_device_guard g(r.device);
         HIPCHK(0, hipStreamWaitEvent(r.comm, r.ev_ready, 0));
-        if (l > 0) HIPCHK(0, hipStreamWaitEvent(r.comm, m->loc[l - 1].ev_ready, 0));
-        if (l < n - 1) HIPCHK(0, hipStreamWaitEvent(r.comm, m->loc[l + 1].ev_ready, 0));
+        if (lo >= 0) HIPCHK(0, hipStreamWaitEvent(r.comm, m->loc[lo].ev_ready, 0));
+        if (hi >= 0) HIPCHK(0, hipStreamWaitEvent(r.comm, m->loc[hi].ev_ready, 0));
         for (size_t q = 0; q < blocks[l].size(); ++q) {
             const Block &b = blocks[l][q];
-            if (l > 0)
-                HIPCHK(0, hipMemcpyPeerAsync(b.recv_lo, r.device, blocks[l - 1][q].send_hi, m->loc[l - 1].device, b.bytes, r.comm));
-            if (l < n - 1)
-                HIPCHK(0, hipMemcpyPeerAsync(b.recv_hi, r.device, blocks[l + 1][q].send_lo, m->loc[l + 1].device, b.bytes, r.comm));
+            if (lo >= 0)
+                HIPCHK(0, hipMemcpyPeerAsync(b.recv_lo, r.device, blocks[lo][q].send_hi, m->loc[lo].device, b.bytes, r.comm));
+            if (hi >= 0)
+                HIPCHK(0, hipMemcpyPeerAsync(b.recv_hi, r.device, blocks[hi][q].send_lo, m->loc[hi].device, b.bytes, r.comm));
         }
         HIPCHK(0, hipEventRecord(r.ev_landed, r.comm));
     }
     return NS3D_OK;
 }
 // What the compute streams enqueue from now on sees the ghosts — and does not overwrite a plane a neighbour still reads.
-int exchange_end(ns3d_mgpu *m)
+int exchange_end(ns3d_mgpu *m, int dim = 2)
 {
     const int n = (int)m->loc.size();
     if (m->P == 1) return NS3D_OK;
@@ -196,8 +212,8 @@ int exchange_end(ns3d_mgpu *m)
         ns3d_device_guard g(r.device);
         HIPCHK(0, hipStreamWaitEvent(compute(r), r.ev_landed, 0));
         if (!m->rccl) {
-            if (l > 0) HIPCHK(0, hipStreamWaitEvent(compute(r), m->loc[l - 1].ev_landed, 0));
-            if (l < n - 1) HIPCHK(0, hipStreamWaitEvent(compute(r), m->loc[l + 1].ev_landed, 0));
+            if (r.nbr[dim][0] >= 0) HIPCHK(0, hipStreamWaitEvent(compute(r), m->loc[r.nbr[dim][0]].ev_landed, 0));
+            if (r.nbr[dim][1] >= 0) HIPCHK(0, hipStreamWaitEvent(compute(r), m->loc[r.nbr[dim][1]].ev_landed, 0));
         }
     }
     return NS3D_OK;
@@ -233,6 +249,13 @@ int init_rank(ns3d_mgpu *m, MRank &r, int rank, int device, int flags)
 {
     r.rank = rank;
     r.device = device;
+    cart_coords(rank, m->dims, r.coords);
+    for (int d = 0; d < 3; ++d)
+        for (int side = 0; side < 2; ++side) {
+            int c[3] = {r.coords[0], r.coords[1], r.coords[2]};
+            c[d] += side ? 1 : -1;
+            r.nbr[d][side] = (c[d] < 0 || c[d] >= m->dims[d]) ? -1 : cart_rank(c, m->dims);
+        }
     r.ctx = ns3d_create(device, flags);
     if (!r.ctx) return NS3D_ERR_HIP;          // message already recorded
     ns3d_device_guard g(device);
@@ -241,16 +264,21 @@ int init_rank(ns3d_mgpu *m, MRank &r, int rank, int device, int flags)
     HIPCHK(0, hipStreamCreateWithPriority(&r.comm, hipStreamNonBlocking, hi));
     HIPCHK(0, hipEventCreateWithFlags(&r.ev_ready, hipEventDisableTiming));
     HIPCHK(0, hipEventCreateWithFlags(&r.ev_landed, hipEventDisableTiming));
-    (void)m;
     return NS3D_OK;
 }
 
-ns3d_mgpu *new_mgpu(int P, int nx, int ny, int nz, int flags, const char *fn)
+ns3d_mgpu *new_mgpu(const int *dims, int nx, int ny, int nz, int flags, const char *fn)
 {
-    if (P < 1) { fail(NS3D_ERR_ARG, "%s: P = %d", fn, P); return nullptr; }
+    if (!dims) { fail(NS3D_ERR_ARG, "%s: null dims", fn); return nullptr; }
+    if (dims[0] < 1 || dims[1] < 1 || dims[2] < 1 || (long)dims[0] * dims[1] * dims[2] > (1 << 20)) {
+        fail(NS3D_ERR_ARG, "%s: dims = (%d,%d,%d)", fn, dims[0], dims[1], dims[2]);
+        return nullptr;
+    }
     if (nx < 3 || ny < 3 || nz < 3) { fail(NS3D_ERR_ARG, "%s: local grid %dx%dx%d too small (need >= 3)", fn, nx, ny, nz); return nullptr; }
     ns3d_mgpu *m = new ns3d_mgpu();
-    m->P = P; m->nx = nx; m->ny = ny; m->nz = nz; m->flags = flags;
+    m->P = dims[0] * dims[1] * dims[2];
+    for (int d = 0; d < 3; ++d) m->dims[d] = dims[d];
+    m->nx = nx; m->ny = ny; m->nz = nz; m->flags = flags;
     if (const char *ev = std::getenv("NS3D_SLAB_DEPTH")) m->depth = std::max(1, std::min(4, std::atoi(ev)));
     m->pass_depth = std::min(2, m->depth);
     return m;
@@ -403,6 +431,10 @@ int slab_residual(ns3d_mgpu *m, double *out)
 template <class T>
 int slab_load(ns3d_mgpu *m, const T *const *Pr, const T *const *D, const T *const *divV, const ns3d_pt_params *p)
 {
+    if (!z_slabs(m))
+        return fail(NS3D_ERR_STATE, "the fused pseudo-transient path takes z-slab topologies only (dims = (1,1,P)); this grid is "
+                    "(%d,%d,%d): run the loop multi.jl:458-471 with the kernel entry points and ns3d_update_halo", m->dims[0],
+                    m->dims[1], m->dims[2]);
     int rc = ns3d_check_pt_params(p, "ns3d_slab_load");
     if (rc) return rc;
     if (p->nx != m->nx || p->ny != m->ny || p->nz != m->nz)
@@ -543,29 +575,117 @@ int solve_slab(ns3d_mgpu *m, T *const *Pr, T *const *D, const T *const *divV, co
     return NS3D_OK;
 }
 
+// update_halo!(A…) of ImplicitGlobalGrid: dimension by dimension (x, y, z — corner and edge values travel in two / three
+// hops), all fields of the call in one exchange per dimension.  z faces are contiguous planes and travel as they lie; x and
+// y faces are packed into / unpacked from the rank's message buffer by k_face_copy on the compute stream.
 template <class T>
 int update_halo_impl(ns3d_mgpu *m, T *const *fields, const int *extents, int nfields)
 {
     const int n = (int)m->loc.size();
-    std::vector<std::vector<Block>> blocks(n);
+    const int ncell[3] = {m->nx, m->ny, m->nz};
     for (int f = 0; f < nfields; ++f) {
-        const int sx = extents[3 * f], sy = extents[3 * f + 1], sz = extents[3 * f + 2];
-        if (sx < 1 || sy < 1 || sz < 2) return fail(NS3D_ERR_ARG, "ns3d_update_halo: field %d has extents %dx%dx%d", f, sx, sy, sz);
-        const int ol = 2 + (sz - m->nz);                  // ImplicitGlobalGrid: overlap of an array with nz+s planes
-        if (ol < 2) continue;                             // no halo in z (τxy…, dPrdτ, Rp)
-        if (sz < 2 * ol - 1) return fail(NS3D_ERR_ARG, "ns3d_update_halo: field %d too thin in z for overlap %d", f, ol);
-        const size_t plane = (size_t)sx * sy;
-        for (int l = 0; l < n; ++l) {
-            T *A = fields[(size_t)f * n + l];
-            if (!A) return fail(NS3D_ERR_ARG, "ns3d_update_halo: null pointer (field %d, local rank %d)", f, l);
-            // sends plane ol (1-based) to the lower / size−(ol−1) to the upper neighbour, receives into 1 / size
-            blocks[l].push_back({A + plane * (ol - 1), A, A + plane * (sz - ol), A + plane * (sz - 1), plane * sizeof(T)});
+        const int *e = extents + 3 * f;
+        if (e[0] < 1 || e[1] < 1 || e[2] < 1) return fail(NS3D_ERR_ARG, "ns3d_update_halo: field %d has extents %dx%dx%d", f, e[0], e[1], e[2]);
+        for (int l = 0; l < n; ++l)
+            if (!fields[(size_t)f * n + l]) return fail(NS3D_ERR_ARG, "ns3d_update_halo: null pointer (field %d, local rank %d)", f, l);
+        for (int d = 0; d < 3; ++d) {
+            const int ol = 2 + (e[d] - ncell[d]);           // ImplicitGlobalGrid: overlap of an array with n+s entries
+            if (m->dims[d] > 1 && ol >= 2 && e[d] < 2 * ol - 1)
+                return fail(NS3D_ERR_ARG, "ns3d_update_halo: field %d too thin in dimension %d for overlap %d", f, d, ol);
         }
     }
-    int rc = exchange_begin(m, blocks);
-    if (rc) return rc;
-    if ((rc = exchange_end(m))) return rc;
+    // message buffer for the strided faces: per (dimension, field) four faces [send lo | send hi | recv lo | recv hi]
+    size_t need = 0;
+    for (int d = 0; d < 2; ++d) {
+        if (m->dims[d] == 1) continue;
+        for (int f = 0; f < nfields; ++f) {
+            const int *e = extents + 3 * f;
+            if (2 + (e[d] - ncell[d]) < 2) continue;
+            need += 4 * (size_t)(d == 0 ? e[1] : e[0]) * e[2] * sizeof(T);
+        }
+    }
+    for (int l = 0; l < n && need; ++l) {
+        MRank &r = m->loc[l];
+        if (r.hbuf_bytes >= need) continue;
+        ns3d_device_guard g(r.device);
+        if (r.hbuf) {
+            // a neighbour may still be pulling from the old buffer: drain every stream of this grid first
+            int rc = sync_all(m);
+            if (rc) return rc;
+            HIPCHK(0, hipFree(r.hbuf));
+            r.hbuf = nullptr; r.hbuf_bytes = 0;
+        }
+        HIPCHK(0, hipMalloc(&r.hbuf, need));
+        r.hbuf_bytes = need;
+    }
+    for (int d = 0; d < 3; ++d) {
+        if (m->dims[d] == 1) continue;
+        std::vector<std::vector<Block>> blocks(n);
+        std::vector<int> fld;                                // fields that have a halo in this dimension
+        for (int f = 0; f < nfields; ++f)
+            if (2 + (extents[3 * f + d] - ncell[d]) >= 2) fld.push_back(f);
+        if (fld.empty()) continue;
+        size_t off0 = 0;                                     // dimension 1's faces follow dimension 0's in the buffer
+        if (d == 1 && m->dims[0] > 1)
+            for (int f = 0; f < nfields; ++f)
+                if (2 + (extents[3 * f] - ncell[0]) >= 2) off0 += 4 * (size_t)extents[3 * f + 1] * extents[3 * f + 2] * sizeof(T);
+        for (int l = 0; l < n; ++l) {
+            MRank &r = m->loc[l];
+            ns3d_device_guard g(r.device);
+            size_t off = off0;
+            for (int f : fld) {
+                const int sx = extents[3 * f], sy = extents[3 * f + 1], sz = extents[3 * f + 2];
+                const int sd = extents[3 * f + d], ol = 2 + (sd - ncell[d]);
+                T *A = fields[(size_t)f * n + l];
+                // sends entry ol (1-based) to the lower / size−(ol−1) to the upper neighbour, receives into 1 / size
+                if (d == 2) {
+                    const size_t plane = (size_t)sx * sy;
+                    blocks[l].push_back({A + plane * (ol - 1), A, A + plane * (sd - ol), A + plane * (sd - 1), plane * sizeof(T)});
+                    continue;
+                }
+                const size_t face = (size_t)(d == 0 ? sy : sx) * sz;
+                T *b0 = (T *)((char *)r.hbuf + off);
+                off += 4 * face * sizeof(T);
+                blocks[l].push_back({b0, b0 + 2 * face, b0 + face, b0 + 3 * face, face * sizeof(T)});
+                hipError_t e1 = hipSuccess, e2 = hipSuccess;
+                if (r.nbr[d][0] >= 0) e1 = ns3d_enqueue_face_copy<T>(r.ctx, compute(r), A, b0, sx, sy, sz, d, ol - 1, 0);
+                if (r.nbr[d][1] >= 0) e2 = ns3d_enqueue_face_copy<T>(r.ctx, compute(r), A, b0 + face, sx, sy, sz, d, sd - ol, 0);
+                if (e1 != hipSuccess || e2 != hipSuccess)
+                    return fail(NS3D_ERR_HIP, "face pack launch: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+            }
+        }
+        int rc = exchange_begin(m, blocks, d);
+        if (rc) return rc;
+        if ((rc = exchange_end(m, d))) return rc;
+        if (d == 2) continue;
+        for (int l = 0; l < n; ++l) {
+            MRank &r = m->loc[l];
+            ns3d_device_guard g(r.device);
+            for (size_t q = 0; q < fld.size(); ++q) {
+                const int f = fld[q];
+                const int sx = extents[3 * f], sy = extents[3 * f + 1], sz = extents[3 * f + 2], sd = extents[3 * f + d];
+                T *A = fields[(size_t)f * n + l];
+                const Block &b = blocks[l][q];
+                hipError_t e1 = hipSuccess, e2 = hipSuccess;
+                if (r.nbr[d][0] >= 0) e1 = ns3d_enqueue_face_copy<T>(r.ctx, compute(r), A, (T *)b.recv_lo, sx, sy, sz, d, 0, 1);
+                if (r.nbr[d][1] >= 0) e2 = ns3d_enqueue_face_copy<T>(r.ctx, compute(r), A, (T *)b.recv_hi, sx, sy, sz, d, sd - 1, 1);
+                if (e1 != hipSuccess || e2 != hipSuccess)
+                    return fail(NS3D_ERR_HIP, "face unpack launch: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+            }
+        }
+    }
     return finish_m(m);
+}
+
+// rank block (bx×by×bz, packed) → its place in the global halo-stripped array (column-major, dims·block entries per side)
+template <class T>
+void place_block(const T *blk, T *out, const int c[3], int bx, int by, int bz, const int dims[3])
+{
+    const size_t gx = (size_t)bx * dims[0], gy = (size_t)by * dims[1];
+    for (int k = 0; k < bz; ++k)
+        for (int j = 0; j < by; ++j)
+            std::memcpy(out + ((size_t)(c[2] * bz + k) * gy + (size_t)(c[1] * by + j)) * gx + (size_t)c[0] * bx,
+                        blk + ((size_t)k * by + j) * bx, (size_t)bx * sizeof(T));
 }
 
 template <class T>
@@ -573,6 +693,7 @@ int gather_impl(ns3d_mgpu *m, const T *const *A, int sx, int sy, int sz, T *out_
 {
     if (sx < 3 || sy < 3 || sz < 3) return fail(NS3D_ERR_ARG, "ns3d_gather: extents %dx%dx%d too small", sx, sy, sz);
     const size_t blk = (size_t)(sx - 2) * (sy - 2) * (sz - 2), bytes = blk * sizeof(T);
+    const bool direct = z_slabs(m);                 // z blocks of a column-major array are contiguous: no host placement
     for (size_t l = 0; l < m->loc.size(); ++l) {
         MRank &r = m->loc[l];
         if (!A[l]) return fail(NS3D_ERR_ARG, "ns3d_gather: null pointer (local rank %zu)", l);
@@ -585,37 +706,50 @@ int gather_impl(ns3d_mgpu *m, const T *const *A, int sx, int sy, int sz, T *out_
         hipError_t e = ns3d_enqueue_strip_inner<T>(r.ctx, compute(r), A[l], (T *)r.gbuf, sx, sy, sz);
         if (e != hipSuccess) return fail(NS3D_ERR_HIP, "strip_inner launch: %s", hipGetErrorString(e));
     }
+    const bool root = !m->rccl || m->loc[0].rank == 0;
+    if (root && !out_host) return fail(NS3D_ERR_ARG, "ns3d_gather: null output on the process that holds rank 0");
+    T *land = out_host;                             // where the rank blocks arrive in rank order
+    if (root && !direct) {
+        m->hstage.resize(bytes * m->P);
+        land = (T *)m->hstage.data();
+    }
     if (!m->rccl) {
-        if (!out_host) return fail(NS3D_ERR_ARG, "ns3d_gather: null output");
         for (size_t l = 0; l < m->loc.size(); ++l) {
             MRank &r = m->loc[l];
             ns3d_device_guard g(r.device);
-            HIPCHK(0, hipMemcpyAsync(out_host + blk * r.rank, r.gbuf, bytes, hipMemcpyDeviceToHost, compute(r)));
+            HIPCHK(0, hipMemcpyAsync(land + blk * r.rank, r.gbuf, bytes, hipMemcpyDeviceToHost, compute(r)));
         }
-        return sync_all(m);
-    }
-    MRank &r = m->loc[0];
-    ns3d_device_guard g(r.device);
-    hipStream_t s = compute(r);
-    if (r.rank != 0) {
-        if (m->P > 1) NCCLCHK(g_rccl.Send(r.gbuf, bytes, ncclUint8, 0, m->comm, s));
+        int rc = sync_all(m);
+        if (rc) return rc;
+    } else {
+        MRank &r = m->loc[0];
+        ns3d_device_guard g(r.device);
+        hipStream_t s = compute(r);
+        if (r.rank != 0) {
+            if (m->P > 1) NCCLCHK(g_rccl.Send(r.gbuf, bytes, ncclUint8, 0, m->comm, s));
+            HIPCHK(0, hipStreamSynchronize(s));
+            return NS3D_OK;
+        }
+        if (m->stage_bytes < bytes * m->P) {
+            if (m->stage) { HIPCHK(0, hipStreamSynchronize(s)); HIPCHK(0, hipFree(m->stage)); m->stage = nullptr; m->stage_bytes = 0; }
+            HIPCHK(0, hipMalloc(&m->stage, bytes * m->P));
+            m->stage_bytes = bytes * m->P;
+        }
+        HIPCHK(0, hipMemcpyAsync(m->stage, r.gbuf, bytes, hipMemcpyDeviceToDevice, s));
+        if (m->P > 1) {
+            NCCLCHK(g_rccl.GroupStart());
+            for (int q = 1; q < m->P; ++q) NCCLCHK(g_rccl.Recv((char *)m->stage + bytes * q, bytes, ncclUint8, q, m->comm, s));
+            NCCLCHK(g_rccl.GroupEnd());
+        }
+        HIPCHK(0, hipMemcpyAsync(land, m->stage, bytes * m->P, hipMemcpyDeviceToHost, s));
         HIPCHK(0, hipStreamSynchronize(s));
-        return NS3D_OK;
     }
-    if (!out_host) return fail(NS3D_ERR_ARG, "ns3d_gather: null output on rank 0");
-    if (m->stage_bytes < bytes * m->P) {
-        if (m->stage) { HIPCHK(0, hipStreamSynchronize(s)); HIPCHK(0, hipFree(m->stage)); m->stage = nullptr; m->stage_bytes = 0; }
-        HIPCHK(0, hipMalloc(&m->stage, bytes * m->P));
-        m->stage_bytes = bytes * m->P;
-    }
-    HIPCHK(0, hipMemcpyAsync(m->stage, r.gbuf, bytes, hipMemcpyDeviceToDevice, s));
-    if (m->P > 1) {
-        NCCLCHK(g_rccl.GroupStart());
-        for (int q = 1; q < m->P; ++q) NCCLCHK(g_rccl.Recv((char *)m->stage + bytes * q, bytes, ncclUint8, q, m->comm, s));
-        NCCLCHK(g_rccl.GroupEnd());
-    }
-    HIPCHK(0, hipMemcpyAsync(out_host, m->stage, bytes * m->P, hipMemcpyDeviceToHost, s));
-    HIPCHK(0, hipStreamSynchronize(s));
+    if (!direct)
+        for (int q = 0; q < m->P; ++q) {
+            int c[3];
+            cart_coords(q, m->dims, c);
+            place_block<T>(land + blk * q, out_host, c, sx - 2, sy - 2, sz - 2, m->dims);
+        }
     return NS3D_OK;
 }
 
@@ -628,37 +762,80 @@ int gather_impl(ns3d_mgpu *m, const T *const *A, int sx, int sy, int sz, T *out_
 
 extern "C" {
 
-// init_global_grid(nx,ny,nz) (multi.jl:325) with dims = (1,1,P), one process driving P devices
-ns3d_mgpu *ns3d_mgpu_create(int P, const int *devices, int nx, int ny, int nz_local, int flags)
+// MPI_Dims_create as ImplicitGlobalGrid calls it (init_global_grid's dimx=dimy=dimz=0 default, multi.jl:325): entries > 0
+// are kept, the zeros are filled with a factorisation of P / (product of the fixed entries) that is as balanced as possible,
+// in non-increasing order.
+int ns3d_dims_create(int P, int *dims)
 {
-    ns3d_mgpu *m = new_mgpu(P, nx, ny, nz_local, flags, "ns3d_mgpu_create");
+    if (!dims || P < 1) return fail(NS3D_ERR_ARG, "ns3d_dims_create: P = %d, dims %p", P, (void *)dims);
+    long fixed = 1;
+    int nfree = 0;
+    for (int d = 0; d < 3; ++d) {
+        if (dims[d] < 0) return fail(NS3D_ERR_ARG, "ns3d_dims_create: dims[%d] = %d", d, dims[d]);
+        if (dims[d] > 0) fixed *= dims[d]; else ++nfree;
+    }
+    if (P % fixed) return fail(NS3D_ERR_ARG, "ns3d_dims_create: %d ranks are not a multiple of the fixed dimensions (%ld)", P, fixed);
+    const int Q = (int)(P / fixed);
+    if (nfree == 0) return Q == 1 ? NS3D_OK : fail(NS3D_ERR_ARG, "ns3d_dims_create: fixed dims hold %ld ranks, not %d", fixed, P);
+    int best[3] = {Q, 1, 1};
+    for (int a = 1; a <= Q; ++a) {                     // a ≥ b ≥ c, a·b·c = Q, the trailing factors 1 when fewer are free
+        if (Q % a) continue;
+        for (int b = 1; b <= a; ++b) {
+            if ((Q / a) % b) continue;
+            const int c = Q / a / b;
+            if (c > b) continue;
+            if ((nfree < 3 && c != 1) || (nfree < 2 && b != 1)) continue;
+            if (a < best[0] || (a == best[0] && b < best[1])) { best[0] = a; best[1] = b; best[2] = c; }
+        }
+    }
+    for (int d = 0, q = 0; d < 3; ++d)
+        if (dims[d] == 0) dims[d] = best[q++];
+    return NS3D_OK;
+}
+
+// init_global_grid(nx,ny,nz; dimx,dimy,dimz) (multi.jl:325), one process driving every rank's device (rank order =
+// MPI_Cart: the last dimension varies fastest)
+ns3d_mgpu *ns3d_mgpu_create_cart(const int *dims, const int *devices, int nx, int ny, int nz, int flags)
+{
+    ns3d_mgpu *m = new_mgpu(dims, nx, ny, nz, flags, "ns3d_mgpu_create_cart");
     if (!m) return nullptr;
-    if (!devices) { fail(NS3D_ERR_ARG, "ns3d_mgpu_create: null device list"); delete m; return nullptr; }
+    const int P = m->P;
+    if (!devices) { fail(NS3D_ERR_ARG, "ns3d_mgpu_create_cart: null device list"); delete m; return nullptr; }
     m->loc.resize(P);
     for (int l = 0; l < P; ++l)
         if (init_rank(m, m->loc[l], l, devices[l], flags)) { ns3d_mgpu_destroy(m); return nullptr; }
-    for (int l = 0; l + 1 < P; ++l) {      // xGMI peer access between z neighbours on different devices
-        const int a = devices[l], b = devices[l + 1];
-        if (a == b) continue;
-        int can = 0;
-        if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) {
-            (void)hipGetLastError();
-            fail(NS3D_ERR_HIP, "ns3d_mgpu_create: devices %d and %d have no peer access", a, b);
-            ns3d_mgpu_destroy(m);
-            return nullptr;
-        }
-        for (int dir = 0; dir < 2; ++dir) {
-            ns3d_device_guard g(dir ? b : a);
-            hipError_t e = hipDeviceEnablePeerAccess(dir ? a : b, 0);
-            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
-                fail(NS3D_ERR_HIP, "hipDeviceEnablePeerAccess(%d→%d): %s", dir ? b : a, dir ? a : b, hipGetErrorString(e));
+    for (int l = 0; l < P; ++l)            // xGMI peer access between neighbours on different devices
+        for (int d = 0; d < 3; ++d) {
+            const int q = m->loc[l].nbr[d][1];
+            if (q < 0) continue;
+            const int a = devices[l], b = devices[q];
+            if (a == b) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) {
+                (void)hipGetLastError();
+                fail(NS3D_ERR_HIP, "ns3d_mgpu_create_cart: devices %d and %d have no peer access", a, b);
                 ns3d_mgpu_destroy(m);
                 return nullptr;
             }
-            (void)hipGetLastError();
+            for (int dir = 0; dir < 2; ++dir) {
+                ns3d_device_guard g(dir ? b : a);
+                hipError_t e = hipDeviceEnablePeerAccess(dir ? a : b, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                    fail(NS3D_ERR_HIP, "hipDeviceEnablePeerAccess(%d→%d): %s", dir ? b : a, dir ? a : b, hipGetErrorString(e));
+                    ns3d_mgpu_destroy(m);
+                    return nullptr;
+                }
+                (void)hipGetLastError();
+            }
         }
-    }
     return m;
+}
+// … with dims = (1,1,P): z-slabs
+ns3d_mgpu *ns3d_mgpu_create(int P, const int *devices, int nx, int ny, int nz_local, int flags)
+{
+    if (P < 1) { fail(NS3D_ERR_ARG, "ns3d_mgpu_create: P = %d", P); return nullptr; }
+    const int dims[3] = {1, 1, P};
+    return ns3d_mgpu_create_cart(dims, devices, nx, ny, nz_local, flags);
 }
 
 int ns3d_mgpu_unique_id(void *id_out)
@@ -672,13 +849,15 @@ int ns3d_mgpu_unique_id(void *id_out)
     return NS3D_OK;
 }
 
-// init_global_grid for one rank of P processes (one per GPU); collective over the P ranks
-ns3d_mgpu *ns3d_mgpu_create_rank(int P, int rank, int device, const void *unique_id, int nx, int ny, int nz_local, int flags)
+// init_global_grid for one rank of prod(dims) processes (one per GPU); collective over the ranks
+ns3d_mgpu *ns3d_mgpu_create_rank_cart(const int *dims, int rank, int device, const void *unique_id, int nx, int ny, int nz,
+                                      int flags)
 {
-    ns3d_mgpu *m = new_mgpu(P, nx, ny, nz_local, flags, "ns3d_mgpu_create_rank");
+    ns3d_mgpu *m = new_mgpu(dims, nx, ny, nz, flags, "ns3d_mgpu_create_rank_cart");
     if (!m) return nullptr;
+    const int P = m->P;
     if (rank < 0 || rank >= P || !unique_id) {
-        fail(NS3D_ERR_ARG, "ns3d_mgpu_create_rank: rank %d of %d, unique_id %p", rank, P, unique_id);
+        fail(NS3D_ERR_ARG, "ns3d_mgpu_create_rank_cart: rank %d of %d, unique_id %p", rank, P, unique_id);
         delete m;
         return nullptr;
     }
@@ -699,6 +878,12 @@ ns3d_mgpu *ns3d_mgpu_create_rank(int P, int rank, int device, const void *unique
     if (g_rccl.CommCount(m->comm, &m->rccl_ranks) != ncclSuccess) m->rccl_ranks = 0;
     return m;
 }
+ns3d_mgpu *ns3d_mgpu_create_rank(int P, int rank, int device, const void *unique_id, int nx, int ny, int nz_local, int flags)
+{
+    if (P < 1) { fail(NS3D_ERR_ARG, "ns3d_mgpu_create_rank: P = %d", P); return nullptr; }
+    const int dims[3] = {1, 1, P};
+    return ns3d_mgpu_create_rank_cart(dims, rank, device, unique_id, nx, ny, nz_local, flags);
+}
 
 // finalize_global_grid() (multi.jl:534)
 void ns3d_mgpu_destroy(ns3d_mgpu *m)
@@ -716,6 +901,7 @@ void ns3d_mgpu_destroy(ns3d_mgpu *m)
         ns3d_device_guard g(r.device);
         free_slab(r);
         if (r.gbuf) (void)hipFree(r.gbuf);
+        if (r.hbuf) (void)hipFree(r.hbuf);
         if (r.ev_ready) (void)hipEventDestroy(r.ev_ready);
         if (r.ev_landed) (void)hipEventDestroy(r.ev_landed);
         if (r.comm) (void)hipStreamDestroy(r.comm);
@@ -729,7 +915,29 @@ int ns3d_mgpu_world(const ns3d_mgpu *m) { return m ? m->P : -1; }
 int ns3d_mgpu_nlocal(const ns3d_mgpu *m) { return m ? (int)m->loc.size() : -1; }
 int ns3d_mgpu_rank(const ns3d_mgpu *m, int local) { return (m && local >= 0 && local < (int)m->loc.size()) ? m->loc[local].rank : -1; }
 ns3d_ctx *ns3d_mgpu_ctx(ns3d_mgpu *m, int local) { return (m && local >= 0 && local < (int)m->loc.size()) ? m->loc[local].ctx : nullptr; }
-int ns3d_mgpu_nz_g(const ns3d_mgpu *m) { return m ? m->P * (m->nz - 2) + 2 : -1; }
+int ns3d_mgpu_nz_g(const ns3d_mgpu *m) { return m ? m->dims[2] * (m->nz - 2) + 2 : -1; }
+int ns3d_mgpu_dims(const ns3d_mgpu *m, int *dims_out)
+{
+    CHECK_M(m);
+    if (!dims_out) return fail(NS3D_ERR_ARG, "ns3d_mgpu_dims: null output");
+    for (int d = 0; d < 3; ++d) dims_out[d] = m->dims[d];
+    return NS3D_OK;
+}
+int ns3d_mgpu_coords(const ns3d_mgpu *m, int local, int *coords_out)
+{
+    CHECK_M(m);
+    if (local < 0 || local >= (int)m->loc.size() || !coords_out) return fail(NS3D_ERR_ARG, "ns3d_mgpu_coords: local rank %d, output %p", local, (void *)coords_out);
+    for (int d = 0; d < 3; ++d) coords_out[d] = m->loc[local].coords[d];
+    return NS3D_OK;
+}
+// nx_g(), ny_g(), nz_g() (multi.jl:328-329,338): dims·(n−2)+2
+int ns3d_mgpu_n_g(const ns3d_mgpu *m, int *n_g_out)
+{
+    CHECK_M(m);
+    if (!n_g_out) return fail(NS3D_ERR_ARG, "ns3d_mgpu_n_g: null output");
+    n_g_out[0] = m->dims[0] * (m->nx - 2) + 2; n_g_out[1] = m->dims[1] * (m->ny - 2) + 2; n_g_out[2] = m->dims[2] * (m->nz - 2) + 2;
+    return NS3D_OK;
+}
 const char *ns3d_mgpu_transport(const ns3d_mgpu *m) { return !m ? "" : (m->rccl ? "rccl" : "peer"); }
 int ns3d_mgpu_rccl_ranks(const ns3d_mgpu *m) { return m ? m->rccl_ranks : -1; }
 int ns3d_mgpu_pass_depth(const ns3d_mgpu *m) { return m ? m->pass_depth : -1; }

@@ -138,7 +138,8 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
     """run_navierstokes3D (multi.jl:287-536).  nx is the LOCAL streamwise size (ny = nz = ceil(0.6 nx) local).
     `grid` decides the decomposition: None = one rank; a halo.ZSlabGrid = this process is one z-slab rank of an
     initialised torch.distributed group; a mgpu.MgpuGrid = the C-ABI grid (this process drives every local rank of an
-    ns3d_mgpu: all P of them in the one-process form, one under RCCL).
+    ns3d_mgpu: all P of them in the one-process form, one under RCCL) — z-slabs, or any Cartesian topology with
+    fused=False (ImplicitGlobalGrid's own default is MultiGpu.dims_create(P), e.g. (2,2,2) for 8 ranks).
     `shape` (dict: ny, nz, ly_lx, lz_lx) overrides the literals multi.jl:302-303,323-324 for grids the reference cannot
     produce without editing them (BASELINE configs[3]: 512×512×1024 global)."""
     if do_vis:
@@ -155,8 +156,13 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
         ctxs = list(grid.contexts)                         # contexts of the ns3d_mgpu's ranks (their devices)
     else:
         ctxs = [K.Context(device, mode, async_=True)]
-    ps = [multi_params(nx, P, me, **shape) for me in local_ranks]
+    dims = tuple(getattr(grid, "dims", (1, 1, P)))
+    coords = list(getattr(grid, "local_coords", [(0, 0, me) for me in local_ranks]))
+    ps = [multi_params(nx, dims=dims, coords=c3, **shape) for c3 in coords]
     p = ps[0]
+    if fused and (dims[0] > 1 or dims[1] > 1):
+        raise L.Ns3dError("the fused pseudo-transient loop takes z-slab topologies only (dims = (1,1,P)); dims = %r needs "
+                          "fused=False (the loop multi.jl:458-471 kernel by kernel)" % (dims,))
     nx, ny, nz = p.nx, p.ny, p.nz
     niter = p.niter if niter_cap is None else min(p.niter, niter_cap)
     fs = [_alloc(nx, ny, nz, dtype, torch.device("cuda", c.device)) for c in ctxs]             # :343-360
@@ -181,7 +187,7 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
         _save_frame(grid, _gather_all(grid, fs), iframe)
     iframe += 1
     pts = [K.pt_params(f.Pr, q.rho, q.dt, q.dtau, q.damp, q.dx, q.dy, q.dz, L.NS3D_BC_MULTI, q.owns_outlet, 0.0, q.g,
-                       me > 0, me < P - 1) for f, q, me in zip(fs, ps, local_ranks)]
+                       q.coords[2] > 0, q.coords[2] < dims[2] - 1) for f, q in zip(fs, ps)]
     if not temporal:
         for c in ctxs:
             c.set_pt2_variant(-1)

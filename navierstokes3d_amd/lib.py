@@ -72,14 +72,20 @@ _PP = C.POINTER(C.c_void_p)      # T *const *  — one device pointer per local 
 # multi-GPU layer (first argument ns3d_mgpu*): name → (restype, argtypes)
 MGPU_SYMBOLS = {
     "ns3d_mgpu_create": (_P, [_I, C.POINTER(_I), _I, _I, _I, _I]),
+    "ns3d_mgpu_create_cart": (_P, [C.POINTER(_I), C.POINTER(_I), _I, _I, _I, _I]),
+    "ns3d_dims_create": (_I, [_I, C.POINTER(_I)]),
     "ns3d_mgpu_unique_id": (_I, [C.c_char_p]),
     "ns3d_mgpu_create_rank": (_P, [_I, _I, _I, C.c_char_p, _I, _I, _I, _I]),
+    "ns3d_mgpu_create_rank_cart": (_P, [C.POINTER(_I), _I, _I, C.c_char_p, _I, _I, _I, _I]),
     "ns3d_mgpu_destroy": (None, [_P]),
     "ns3d_mgpu_world": (_I, [_P]),
     "ns3d_mgpu_nlocal": (_I, [_P]),
     "ns3d_mgpu_rank": (_I, [_P, _I]),
     "ns3d_mgpu_ctx": (_P, [_P, _I]),
     "ns3d_mgpu_nz_g": (_I, [_P]),
+    "ns3d_mgpu_dims": (_I, [_P, C.POINTER(_I)]),
+    "ns3d_mgpu_coords": (_I, [_P, _I, C.POINTER(_I)]),
+    "ns3d_mgpu_n_g": (_I, [_P, C.POINTER(_I)]),
     "ns3d_mgpu_transport": (C.c_char_p, [_P]),
     "ns3d_mgpu_rccl_ranks": (_I, [_P]),
     "ns3d_mgpu_pass_depth": (_I, [_P]),

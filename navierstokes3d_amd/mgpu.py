@@ -1,6 +1,7 @@
 """The multi-GPU half of the C ABI (include/ns3d.h, ns3d_mgpu_*): ImplicitGlobalGrid's init_global_grid / update_halo! /
-max_g / gather! / finalize_global_grid (scripts/NavierStokes3D_multi_gpu.jl:325, :371…, :21, :399-403, :534) for 1-D z-slabs,
-and the pseudo-transient loop of a z-slab rank (multi.jl:458-471) with its halo traffic behind the interior sweep.
+max_g / gather! / finalize_global_grid (scripts/NavierStokes3D_multi_gpu.jl:325, :371…, :21, :399-403, :534) for z-slabs
+(dims = (1,1,P), the default here) or any Cartesian topology (`dims=`; dims_create(P) = init_global_grid's own default), and
+the pseudo-transient loop of a z-slab rank (multi.jl:458-471) with its halo traffic behind the interior sweep.
 
 Two forms:
   MultiGpu.create(devices, …)          one process drives P devices (a device may repeat: virtual ranks on one GPU); planes
@@ -35,16 +36,37 @@ class MultiGpu:
         self.nlocal = self.lib.ns3d_mgpu_nlocal(handle)
         self.ranks = [self.lib.ns3d_mgpu_rank(handle, l) for l in range(self.nlocal)]
         self.transport = self.lib.ns3d_mgpu_transport(handle).decode()
+        d3 = (C.c_int * 3)()
+        L.check(self.lib.ns3d_mgpu_dims(handle, d3))
+        self.dims = tuple(d3)
+        self.coords = []
+        for l in range(self.nlocal):
+            L.check(self.lib.ns3d_mgpu_coords(handle, l, d3))
+            self.coords.append(tuple(d3))
         self.contexts = []
         self._devices = []
 
     # ---- init_global_grid (multi.jl:325) ---------------------------------------------------------------------
+    @staticmethod
+    def dims_create(P, dims=(0, 0, 0)):
+        """MPI.Dims_create!(nprocs, dims) as init_global_grid calls it: zeros are filled, balanced and non-increasing."""
+        d3 = (C.c_int * 3)(*[int(q) for q in dims])
+        L.check(L.load().ns3d_dims_create(int(P), d3))
+        return tuple(d3)
+
     @classmethod
-    def create(cls, devices, nx, ny, nz, mode="strict", async_=True):
+    def create(cls, devices, nx, ny, nz, mode="strict", async_=True, dims=None):
+        """dims=None: z-slabs over len(devices) ranks; dims=(Px,Py,Pz): a Cartesian topology, devices[rank] in MPI_Cart
+        rank order (last dimension fastest)."""
         lib = L.load()
         devs = (C.c_int * len(devices))(*[int(d) for d in devices])
         flags = _FLAGS[mode] | (L.NS3D_ASYNC if async_ else 0)
-        h = lib.ns3d_mgpu_create(len(devices), devs, int(nx), int(ny), int(nz), flags)
+        if dims is None:
+            h = lib.ns3d_mgpu_create(len(devices), devs, int(nx), int(ny), int(nz), flags)
+        else:
+            if len(dims) != 3 or int(dims[0]) * int(dims[1]) * int(dims[2]) != len(devices):
+                raise L.Ns3dError("dims %r do not hold %d ranks" % (tuple(dims), len(devices)))
+            h = lib.ns3d_mgpu_create_cart((C.c_int * 3)(*[int(q) for q in dims]), devs, int(nx), int(ny), int(nz), flags)
         if not h:
             raise L.Ns3dError("ns3d_mgpu_create failed: " + L.last_error())
         self = cls(h, mode)
@@ -59,12 +81,18 @@ class MultiGpu:
         return buf.raw
 
     @classmethod
-    def create_rank(cls, P, rank, device, unique_id, nx, ny, nz, mode="strict", async_=True):
+    def create_rank(cls, P, rank, device, unique_id, nx, ny, nz, mode="strict", async_=True, dims=None):
         lib = L.load()
         if len(unique_id) != L.NS3D_UNIQUE_ID_BYTES:
             raise L.Ns3dError("unique id must be %d bytes" % L.NS3D_UNIQUE_ID_BYTES)
         flags = _FLAGS[mode] | (L.NS3D_ASYNC if async_ else 0)
-        h = lib.ns3d_mgpu_create_rank(int(P), int(rank), int(device), bytes(unique_id), int(nx), int(ny), int(nz), flags)
+        if dims is None:
+            h = lib.ns3d_mgpu_create_rank(int(P), int(rank), int(device), bytes(unique_id), int(nx), int(ny), int(nz), flags)
+        else:
+            if len(dims) != 3 or int(dims[0]) * int(dims[1]) * int(dims[2]) != int(P):
+                raise L.Ns3dError("dims %r do not hold %d ranks" % (tuple(dims), P))
+            h = lib.ns3d_mgpu_create_rank_cart((C.c_int * 3)(*[int(q) for q in dims]), int(rank), int(device), bytes(unique_id),
+                                               int(nx), int(ny), int(nz), flags)
         if not h:
             raise L.Ns3dError("ns3d_mgpu_create_rank failed: " + L.last_error())
         self = cls(h, mode)
@@ -81,6 +109,11 @@ class MultiGpu:
 
     def nz_g(self):
         return int(self.lib.ns3d_mgpu_nz_g(self.handle))
+
+    def n_g(self):
+        d3 = (C.c_int * 3)()
+        L.check(self.lib.ns3d_mgpu_n_g(self.handle, d3))
+        return tuple(d3)
 
     # ---- finalize_global_grid (multi.jl:534) -----------------------------------------------------------------
     def close(self):
@@ -143,14 +176,15 @@ class MultiGpu:
 
     # ---- gather! (multi.jl:399-403, 528-532) ------------------------------------------------------------------
     def gather(self, A):
-        """Halo-stripped blocks of every rank, concatenated along z: a Fortran-ordered numpy array on the process that
-        holds rank 0, None elsewhere."""
+        """Halo-stripped blocks of every rank, side by side in rank-coordinate order: a Fortran-ordered numpy array on the
+        process that holds rank 0, None elsewhere."""
         self._follow_torch_streams()
         lst = _as_list(A)
         sx, sy, sz = lst[0].shape
         npdt = np.float64 if lst[0].dtype == torch.float64 else np.float32
         is_root = 0 in self.ranks
-        out = np.empty((sx - 2, sy - 2, self.P * (sz - 2)), dtype=npdt, order="F") if is_root else None
+        shp = (self.dims[0] * (sx - 2), self.dims[1] * (sy - 2), self.dims[2] * (sz - 2))
+        out = np.empty(shp, dtype=npdt, order="F") if is_root else None
         L.check(self._typed("gather", lst[0])(self.handle, self._ptrs([lst]), sx, sy, sz,
                                               out.ctypes.data_as(C.c_void_p) if is_root else None))
         return out
@@ -206,28 +240,32 @@ class MgpuGrid:
         self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
         self.P, self.nlocal, self.local_ranks = mg.P, mg.nlocal, list(mg.ranks)
         self.me = self.local_ranks[0]
-        self.dims = (1, 1, self.P)
-        self.coords = (0, 0, self.me)
+        self.dims = tuple(mg.dims)
+        self.local_coords = list(mg.coords)          # MPI_Cart_coords per local rank
+        self.coords = self.local_coords[0]
         self.transport = mg.transport
         self.contexts = mg.contexts
 
     def nx_g(self):
-        return self.nx
+        return self.dims[0] * (self.nx - 2) + 2
 
     def ny_g(self):
-        return self.ny
+        return self.dims[1] * (self.ny - 2) + 2
 
     def nz_g(self):
-        return self.P * (self.nz - 2) + 2
+        return self.dims[2] * (self.nz - 2) + 2
 
     def is_root(self):
         return 0 in self.local_ranks
 
+    def z_slabs(self):
+        return self.dims[0] == 1 and self.dims[1] == 1
+
     def z_lo_is_halo(self, l=0):
-        return self.local_ranks[l] > 0
+        return self.local_coords[l][2] > 0
 
     def z_hi_is_halo(self, l=0):
-        return self.local_ranks[l] < self.P - 1
+        return self.local_coords[l][2] < self.dims[2] - 1
 
     def update_halo(self, *fields):
         self.mg.update_halo(*fields)

@@ -1,7 +1,7 @@
 """Parameter derivation of the two reference drivers (host scalars only).
 
 multi_params  ↔ scripts/NavierStokes3D_multi_gpu.jl:290-341 (local grid nx×ny×nz per rank, global sizes through
-                ImplicitGlobalGrid's n_g = dims·(n−2)+2 with dims = (1,1,P): z-slabs)
+                ImplicitGlobalGrid's n_g = dims·(n−2)+2; dims = (1,1,P) z-slabs by default, any topology with dims=/coords=)
 gpu_params    ↔ scripts/NavierStokes3D_gpu.jl:15-61
 cavity_params ↔ the synthetic 512³ "lid-driven cavity, Poisson-only" benchmark configuration
                 (BASELINE.json configs[2]; SURVEY.md §8d Config 3 — not in the reference)
@@ -16,9 +16,10 @@ def _ceil_int(x):
     return int(math.ceil(x))
 
 
-def multi_params(nx, dims_z=1, coord_z=0, ny=None, nz=None, ly_lx=0.6, lz_lx=0.6):
+def multi_params(nx, dims_z=1, coord_z=0, ny=None, nz=None, ly_lx=0.6, lz_lx=0.6, dims=None, coords=None):
     """ny, nz, ly_lx, lz_lx: explicit-shape overrides of the literals multi.jl:302-303 and the ceil(0.6 nx) rule
-    multi.jl:323-324 (defaults = the reference)."""
+    multi.jl:323-324 (defaults = the reference).  dims / coords: a Cartesian topology and this rank's MPI_Cart coordinates
+    (override dims_z / coord_z)."""
     p = SimpleNamespace()
     p.lx, p.rho, p.vin, p.mu = 1.0, 1000.0, 1.0, 0.001                     # :290-293
     p.psc = p.rho * (p.vin * p.vin)                                        # :296
@@ -35,9 +36,10 @@ def multi_params(nx, dims_z=1, coord_z=0, ny=None, nz=None, ly_lx=0.6, lz_lx=0.6
     p.nx = int(nx)
     p.ny = _ceil_int(nx * ly_lx) if ny is None else int(ny)                # :323
     p.nz = _ceil_int(nx * lz_lx) if nz is None else int(nz)                # :324
-    p.dims = (1, 1, int(dims_z))                                           # :325 (z-slabs only)
-    p.coords = (0, 0, int(coord_z))
-    p.nx_g, p.ny_g = p.nx, p.ny
+    p.dims = (1, 1, int(dims_z)) if dims is None else tuple(int(q) for q in dims)        # :325
+    p.coords = (0, 0, int(coord_z)) if coords is None else tuple(int(q) for q in coords)
+    p.nx_g = p.dims[0] * (p.nx - 2) + 2
+    p.ny_g = p.dims[1] * (p.ny - 2) + 2
     p.nz_g = p.dims[2] * (p.nz - 2) + 2
     p.eps = 1e-3                                                           # :327
     p.niter = 50 * max(p.nx_g, p.ny_g, p.nz_g)                             # :328
@@ -53,11 +55,11 @@ def multi_params(nx, dims_z=1, coord_z=0, ny=None, nz=None, ly_lx=0.6, lz_lx=0.6
     #   x_g(ix,dx,A) = (coord*(n-2) + ix-1)*dx + 0.5*(n-size(A))*dx
     def x_g(i1, d, size_a, n, coord):
         return (coord * (n - 2) + (i1 - 1)) * d + 0.5 * (n - size_a) * d
-    p.xco_g = x_g(1, p.dx, p.nx, p.nx, 0) - (p.lx - p.dx) / 2
-    p.yco_g = x_g(1, p.dy, p.ny, p.ny, 0) - (p.ly - p.dy) / 2
+    p.xco_g = x_g(1, p.dx, p.nx, p.nx, p.coords[0]) - (p.lx - p.dx) / 2
+    p.yco_g = x_g(1, p.dy, p.ny, p.ny, p.coords[1]) - (p.ly - p.dy) / 2
     p.zco_g = x_g(1, p.dz, p.nz, p.nz, p.coords[2]) - (p.lz - p.dz) / 2
-    p.xvo_g = x_g(1, p.dx, p.nx + 1, p.nx, 0) - (p.lx - p.dx) / 2
-    p.xve_g = x_g(p.nx + 1, p.dx, p.nx + 1, p.nx, 0) - (p.lx - p.dx) / 2
+    p.xvo_g = x_g(1, p.dx, p.nx + 1, p.nx, p.coords[0]) - (p.lx - p.dx) / 2
+    p.xve_g = x_g(p.nx + 1, p.dx, p.nx + 1, p.nx, p.coords[0]) - (p.lx - p.dx) / 2
     p.owns_inlet = p.xvo_g == -p.lx / 2                                    # :164
     p.owns_outlet = p.xve_g == p.lx / 2                                    # :179
     return p

@@ -28,7 +28,7 @@ def _ceil_int(x):
 # ------------------------------------------------------------------------------------------------
 # multi.jl
 # ------------------------------------------------------------------------------------------------
-def multi_params(nx, dims_z=1, dtype=np.float64, ny=None, nz=None, ly_lx=0.6, lz_lx=0.6):
+def multi_params(nx, dims_z=1, dtype=np.float64, ny=None, nz=None, ly_lx=0.6, lz_lx=0.6, dims=None):
     """multi.jl:290-341 (local nx; ny,nz local; z decomposed over dims_z ranks).  ny, nz, ly_lx, lz_lx override the
     literals multi.jl:302-303,323-324 (defaults = the reference) for grids it cannot produce unedited."""
     p = Obj()
@@ -45,9 +45,9 @@ def multi_params(nx, dims_z=1, dtype=np.float64, ny=None, nz=None, ly_lx=0.6, lz
     p.nx = nx
     p.ny = _ceil_int(nx * ly_lx) if ny is None else int(ny)      # :323
     p.nz = _ceil_int(nx * lz_lx) if nz is None else int(nz)      # :324
-    p.dims = (1, 1, dims_z)
+    p.dims = (1, 1, dims_z) if dims is None else tuple(int(q) for q in dims)     # :325 (dims: a 3-D Cartesian topology)
     # ImplicitGlobalGrid: n_g = dims*(n-overlap)+overlap, overlap 2 [upstream]
-    p.nx_g, p.ny_g, p.nz_g = p.nx, p.ny, dims_z * (p.nz - 2) + 2
+    p.nx_g, p.ny_g, p.nz_g = (p.dims[0] * (p.nx - 2) + 2, p.dims[1] * (p.ny - 2) + 2, p.dims[2] * (p.nz - 2) + 2)
     p.eps = 1e-3                                                 # :327
     p.niter = 50 * max(p.nx_g, p.ny_g, p.nz_g)                   # :328
     p.nchk = 1 * (p.ny_g - 1)                                    # :329
@@ -86,53 +86,90 @@ def _alloc_multi(p):
     return f
 
 
-def update_halo_z(ranks, name, nz_cells):
-    """update_halo!(A) for a 1-D z decomposition, halo width 1, overlap 2 (+ stagger) [upstream IGG]:
-    an array with local z extent nz_cells+s has overlap ol=2+s; it sends plane `ol` (1-based) to the
-    lower neighbour and plane `size-(ol-1)` to the upper one, receives into planes 1 / size.
-    Arrays with ol<2 have no halo.  Physical (non-periodic) ends are left untouched."""
+def cart_coords(rank, dims):
+    """MPI_Cart_coords of a row-major Cartesian communicator (last dimension fastest), as ImplicitGlobalGrid creates it."""
+    return (rank // (dims[1] * dims[2]), (rank // dims[2]) % dims[1], rank % dims[2])
+
+
+def cart_rank(c, dims):
+    return (c[0] * dims[1] + c[1]) * dims[2] + c[2]
+
+
+def update_halo_3d(ranks, name, ncells, dims):
+    """update_halo!(A) of ImplicitGlobalGrid [upstream] for a Cartesian topology `dims`, halo width 1, overlap 2 (+ stagger):
+    dimension by dimension (x, then y, then z — so that edge and corner values travel in two / three hops); in dimension d an
+    array with local extent n_d+s has overlap ol=2+s, sends index `ol` (1-based) to the lower neighbour and `size-(ol-1)` to the
+    upper one and receives into 1 / size; arrays with ol<2 have no halo in that dimension; physical (non-periodic) ends are
+    left untouched.  ranks: list of field dicts in MPI rank order; ncells = (nx,ny,nz) local cell counts."""
     P = len(ranks)
     if P == 1:
         return
-    A0 = ranks[0][name]
-    sz = A0.shape[2]
-    ol = 2 + (sz - nz_cells)
-    if ol < 2:
-        return
-    # all sends are posted from the pre-exchange state (Isend/Irecv then wait)
-    to_lower = [r[name][:, :, ol - 1].copy() for r in ranks]
-    to_upper = [r[name][:, :, sz - ol].copy() for r in ranks]
-    for c, r in enumerate(ranks):
-        if c > 0:
-            r[name][:, :, 0] = to_upper[c - 1]
-        if c < P - 1:
-            r[name][:, :, sz - 1] = to_lower[c + 1]
+    for d in range(3):
+        if dims[d] == 1:
+            continue
+        size = ranks[0][name].shape[d]
+        ol = 2 + (size - ncells[d])
+        if ol < 2:
+            continue
+        take = lambda A, i: np.take(A, i, axis=d).copy()
+        # all sends are posted from the state BEFORE this dimension's exchange (Isend/Irecv then wait)
+        to_lower = [take(r[name], ol - 1) for r in ranks]
+        to_upper = [take(r[name], size - ol) for r in ranks]
+        for rk, r in enumerate(ranks):
+            c = cart_coords(rk, dims)
+            idx = [slice(None)] * 3
+            if c[d] > 0:
+                lo = list(c); lo[d] -= 1
+                idx[d] = 0
+                r[name][tuple(idx)] = to_upper[cart_rank(lo, dims)]
+            if c[d] < dims[d] - 1:
+                hi = list(c); hi[d] += 1
+                idx[d] = size - 1
+                r[name][tuple(idx)] = to_lower[cart_rank(hi, dims)]
+
+
+def update_halo_z(ranks, name, nz_cells):
+    """z-slab form kept for the tests written against it: dims = (1,1,P)."""
+    n = ranks[0][name].shape
+    # only the z extent enters for dims (1,1,P)
+    update_halo_3d(ranks, name, (n[0], n[1], nz_cells), (1, 1, len(ranks)))
+
+
+def gather_3d(ranks, name, dims):
+    """The *_inn / gather! contract of multi.jl:399-403,528-532 for a Cartesian topology: strip one cell on every side of
+    each local array and place the rank blocks side by side in rank-coordinate order (block extent = local inner extent)."""
+    blocks = [np.asarray(r[name][1:-1, 1:-1, 1:-1]) for r in ranks]
+    return np.concatenate([np.concatenate([np.concatenate([blocks[cart_rank((cx, cy, cz), dims)] for cz in range(dims[2])], axis=2)
+                                           for cy in range(dims[1])], axis=1) for cx in range(dims[0])], axis=0)
 
 
 def gather_z(ranks, name):
-    """The *_inn / gather! contract of multi.jl:399-403,528-532: strip one cell on every side of each
-    local array and concatenate the rank blocks along z (block extent = local inner extent)."""
-    return np.concatenate([np.asarray(r[name][1:-1, 1:-1, 1:-1]) for r in ranks], axis=2)
+    return gather_3d(ranks, name, (1, 1, len(ranks)))
 
 
 def run_navierstokes3D_ref(nx=63, nt=1, dims_z=1, dtype=np.float64, faithful=True, niter_cap=None,
-                           record=None, shape=None):
+                           record=None, shape=None, dims=None):
     """multi.jl:287-536 without vis/save.  Returns (C_v,Pr_v,Vx_v,Vy_v,Vz_v, info) where info holds the
     per-step PT iteration counts and err histories, and the final local states."""
-    p = multi_params(nx, dims_z, dtype, **(shape or {}))
+    p = multi_params(nx, dims_z, dtype, dims=dims, **(shape or {}))
     nx, ny, nz = p.nx, p.ny, p.nz
     niter = p.niter if niter_cap is None else min(p.niter, niter_cap)
-    P = dims_z
+    dims = p.dims
+    P = dims[0] * dims[1] * dims[2]
+    update_halo_z = lambda rks, name, _nz: update_halo_3d(rks, name, (nx, ny, nz), dims)      # noqa: F841 (shadows the z-only form)
+    gather_z = lambda rks, name: gather_3d(rks, name, dims)                                     # noqa: F841
     ranks = []
-    for c in range(P):
+    for rk in range(P):
+        cx, cy, c = cart_coords(rk, dims)
         f = _alloc_multi(p)
         f.coord = c
+        f.coords = (cx, cy, c)
         # multi.jl:363-367
-        f.xco_g = _x_g(1, p.dx, nx, nx, 0) - (p.lx - p.dx) / 2
-        f.yco_g = _x_g(1, p.dy, ny, ny, 0) - (p.ly - p.dy) / 2
+        f.xco_g = _x_g(1, p.dx, nx, nx, cx) - (p.lx - p.dx) / 2
+        f.yco_g = _x_g(1, p.dy, ny, ny, cy) - (p.ly - p.dy) / 2
         f.zco_g = _x_g(1, p.dz, nz, nz, c) - (p.lz - p.dz) / 2
-        f.xvo_g = _x_g(1, p.dx, nx + 1, nx, 0) - (p.lx - p.dx) / 2
-        f.xve_g = _x_g(nx + 1, p.dx, nx + 1, nx, 0) - (p.lx - p.dx) / 2
+        f.xvo_g = _x_g(1, p.dx, nx + 1, nx, cx) - (p.lx - p.dx) / 2
+        f.xve_g = _x_g(nx + 1, p.dx, nx + 1, nx, cx) - (p.lx - p.dx) / 2
         f.owns_inlet = f.xvo_g == -p.lx / 2          # :164  (App. B10)
         f.owns_outlet = f.xve_g == p.lx / 2          # :179
         f.Vy[0, :, :] = p.vin                        # :369  (sic — App. B3)

@@ -184,6 +184,88 @@ def test_driver_on_mgpu_grid_vs_oracle_virtual_ranks(hip, P, fused, temporal):
     mg.close()
 
 
+def test_dims_create_is_mpi_dims_create(hip):
+    """init_global_grid's default topology (multi.jl:325 passes no dimx/dimy/dimz): MPI_Dims_create — balanced, non-increasing,
+    fixed entries kept."""
+    from navierstokes3d_amd import lib as L
+    from navierstokes3d_amd.mgpu import MultiGpu
+    want = {1: (1, 1, 1), 2: (2, 1, 1), 3: (3, 1, 1), 4: (2, 2, 1), 6: (3, 2, 1), 8: (2, 2, 2), 12: (3, 2, 2), 16: (4, 2, 2),
+            18: (3, 3, 2), 24: (4, 3, 2), 36: (4, 3, 3), 64: (4, 4, 4), 7: (7, 1, 1)}
+    for P, d in want.items():
+        assert MultiGpu.dims_create(P) == d, P
+    assert MultiGpu.dims_create(8, (1, 1, 0)) == (1, 1, 8)            # the z-slab choice of this build
+    assert MultiGpu.dims_create(8, (0, 1, 0)) == (4, 1, 2) and MultiGpu.dims_create(12, (0, 3, 0)) == (2, 3, 2)
+    with pytest.raises(L.Ns3dError):
+        MultiGpu.dims_create(8, (3, 0, 0))
+
+
+@pytest.mark.parametrize("dims", [(2, 1, 1), (1, 2, 1), (2, 2, 1), (2, 2, 2), (3, 2, 1), (1, 3, 2)])
+def test_update_halo_and_gather_on_a_cartesian_topology(hip, dims):
+    """update_halo! / gather! with x and y decomposition (packed strided faces) against the oracle's virtual ranks
+    (oracle/driver_ref.py::update_halo_3d, pinned in tests/test_oracle.py): every stagger, arrays without a halo, several
+    fields per call, f64 and f32; edges and corners arrive through the x→y→z order."""
+    from navierstokes3d_amd.mgpu import MgpuGrid, MultiGpu
+    from oracle.driver_ref import cart_coords, gather_3d, update_halo_3d
+    P = dims[0] * dims[1] * dims[2]
+    nx, ny, nz = 13, 9, 7
+    kinds = ["c", "vx", "vy", "vz", "s", "i"]
+    mg = MultiGpu.create([0] * P, nx, ny, nz, "strict", dims=dims)
+    assert mg.dims == dims and mg.P == P and mg.coords == [cart_coords(r, dims) for r in range(P)]
+    assert mg.n_g() == tuple(dims[d] * ((nx, ny, nz)[d] - 2) + 2 for d in range(3))
+    grid = MgpuGrid(mg, nx, ny, nz)
+    assert (grid.nx_g(), grid.ny_g(), grid.nz_g()) == mg.n_g() and grid.z_slabs() == (dims[0] == 1 and dims[1] == 1)
+    for dtype in (np.float64, np.float32):
+        host = [dict(zip(kinds, fields(nx, ny, nz, kinds, 100 * (r + 1), dtype))) for r in range(P)]
+        dev = {k: [hip.from_numpy(h[k]) for h in host] for k in kinds}
+        mg.update_halo(*[dev[k] for k in kinds])              # one call, six fields
+        mg.update_halo(dev["vx"])                             # and again alone: idempotent, buffer reuse
+        mg.sync()
+        for k in kinds:
+            update_halo_3d(host, k, (nx, ny, nz), dims)
+            for r in range(P):
+                assert np.array_equal(hip.to_numpy(dev[k][r]), host[r][k]), (k, r, dtype)
+        for k in ("c", "vx", "vy", "vz"):
+            got = mg.gather(dev[k])
+            assert got.flags.f_contiguous and np.array_equal(got, gather_3d(host, k, dims)), k
+    mg.close()
+
+
+@pytest.mark.parametrize("dims,nx,shape", [((2, 1, 1), 14, dict(ny=16, nz=16)), ((2, 2, 1), 14, dict(ny=9, nz=16)),
+                                           ((2, 2, 2), 14, dict(ny=9, nz=9)), ((3, 2, 1), 10, dict(ny=9, nz=16))])
+def test_driver_on_a_cartesian_topology_vs_oracle_virtual_ranks(hip, dims, nx, shape):
+    """The driver on the topologies ImplicitGlobalGrid picks by default for 2, 4 and 8 ranks (multi.jl:325 →
+    MPI_Dims_create), inner loop kernel by kernel as written (multi.jl:458-471): iteration counts, residual histories, every
+    rank's fields and the gathered arrays against the oracle's virtual ranks, bit for bit.  Only the ranks on the inlet /
+    outlet planes apply those conditions (multi.jl:164,179).  The local sizes are chosen so that the GLOBAL grid is the same
+    near-isotropic 26×16×16 for every topology: dτ follows max(dx,dy,dz) (multi.jl:341), so the grids ceil(0.6 nx) gives
+    under an x-only decomposition (dx ≈ dy/2) make the reference's own iteration diverge."""
+    from navierstokes3d_amd import lib as L
+    from navierstokes3d_amd.driver import run_navierstokes3D
+    from navierstokes3d_amd.mgpu import MgpuGrid, MultiGpu
+    from navierstokes3d_amd.params import multi_params
+    from oracle.driver_ref import run_navierstokes3D_ref
+    P = dims[0] * dims[1] * dims[2]
+    assert MultiGpu.dims_create(P) == dims
+    nt, cap = 2, 300
+    p0 = multi_params(nx, dims=dims, **shape)
+    assert (p0.nx_g, p0.ny_g, p0.nz_g) == (26, 16, 16)
+    mg = MultiGpu.create([0] * P, p0.nx, p0.ny, p0.nz, "strict", dims=dims)
+    grid = MgpuGrid(mg, p0.nx, p0.ny, p0.nz)
+    with pytest.raises(L.Ns3dError):                          # the fused loop is z-slab only and says so
+        run_navierstokes3D(nx=nx, nt=1, grid=grid, niter_cap=cap, shape=shape)
+    out = run_navierstokes3D(nx=nx, nt=nt, mode="strict", fused=False, grid=grid, niter_cap=cap, return_info=True, shape=shape)
+    info = out[-1]
+    ref = run_navierstokes3D_ref(nx=nx, nt=nt, dims=dims, niter_cap=cap, shape=shape)
+    assert info.iters == ref[-1].iters and info.errs == ref[-1].errs and info.iters[-1] < cap
+    for r in range(P):
+        for n in ("C", "Pr", "Vx", "Vy", "Vz", "divV", "dPrdtau"):
+            assert np.array_equal(hip.to_numpy(getattr(info.local_fields[r], n)), ref[-1].ranks[r][n], equal_nan=True), (r, n)
+    for n, a, b in zip(("C", "Pr", "Vx", "Vy", "Vz"), out[:5], ref[:5]):
+        assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True), n
+    assert np.isfinite(out[1]).all() and 0 < np.abs(out[2]).max() < 1.0
+    mg.close()
+
+
 def test_rccl_communicator_of_one_rank(hip):
     """The one-process-per-GPU form as far as one GPU goes: RCCL is found by dlopen, a unique id is made, a communicator
     of one rank comes up, and the residual check / max_g run their ncclAllReduce on it; results equal the single-device
@@ -231,4 +313,13 @@ def test_mgpu_argument_errors(hip):
         mg.set_temporal(5)
     with pytest.raises(L.Ns3dError):
         mg.update_halo([hip.zeros((12, 8, 6))])               # one tensor for two local ranks
+    mg.close()
+    with pytest.raises(L.Ns3dError):
+        MultiGpu.create([0, 0], 8, 8, 8, dims=(2, 2, 1))      # dims hold four ranks
+    mg = MultiGpu.create([0, 0], 12, 8, 6, dims=(2, 1, 1))
+    z = [hip.zeros((12, 8, 6)), hip.zeros((12, 8, 6))]
+    d = [hip.zeros((10, 6, 4)), hip.zeros((10, 6, 4))]
+    p = hip.pt_params(z[0], 1000.0, 0.01, 0.01, 0.1, 0.1, 0.1, 0.1, 0, True, 0.0, 0.0)
+    with pytest.raises(L.Ns3dError, match="z-slab"):
+        mg.slab_load(z, d, z, p)                              # fused path: z-slabs only
     mg.close()

@@ -187,3 +187,56 @@ def test_virtual_zslab_ranks_pt_loop_is_decomposition_independent(oracle):
         assert np.array_equal(r0[n][:, :, -1], r1[n][:, :, 1]), n
         assert np.array_equal(r0[n][:, :, -2], r1[n][:, :, 0]), n
     assert np.array_equal(r0["Vz"][:, :, -1], r1["Vz"][:, :, 2]) and np.array_equal(r0["Vz"][:, :, -3], r1["Vz"][:, :, 0])
+
+
+def test_update_halo_3d_fills_faces_edges_and_corners():
+    """ImplicitGlobalGrid's update_halo! on a Cartesian topology (oracle/driver_ref.py::update_halo_3d): each rank's array
+    holds a code of the GLOBAL index everywhere except in the halo entries that have a neighbour, which hold garbage; after
+    the exchange every entry — faces, and through the x→y→z order edges and corners — holds the code of its global index
+    (a garbage corner that was forwarded, or a physical end that was overwritten, would show).  All staggers."""
+    from oracle.driver_ref import cart_coords, gather_3d, update_halo_3d
+    dims, n = (2, 3, 2), (6, 5, 7)
+    P = dims[0] * dims[1] * dims[2]
+    for stag in [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)]:
+        ext = tuple(n[d] + stag[d] for d in range(3))
+        code = lambda gi, gj, gk: gi + 1000.0 * gj + 1e6 * gk
+        ranks = []
+        for rk in range(P):
+            c = cart_coords(rk, dims)
+            gi = [c[d] * (n[d] - 2) + np.arange(ext[d]) for d in range(3)]
+            A = code(gi[0][:, None, None], gi[1][None, :, None], gi[2][None, None, :]).astype(np.float64)
+            want = A.copy()
+            for d in range(3):
+                for side, has in ((0, c[d] > 0), (-1, c[d] < dims[d] - 1)):
+                    idx = [slice(None)] * 3
+                    idx[d] = side
+                    if has:
+                        A[tuple(idx)] = -1.0 - rk            # garbage in every halo entry that has a neighbour
+            ranks.append(dict(a=A, want=want))
+        update_halo_3d(ranks, "a", n, dims)
+        for rk, r in enumerate(ranks):
+            assert np.array_equal(r["a"], r["want"]), (stag, rk)
+    # an array without overlap in x (τxy-like, n-1 entries) keeps its x faces, still exchanges nothing there
+    ranks = [dict(a=np.full((n[0] - 1, n[1] - 1, n[2] - 1), float(rk))) for rk in range(P)]
+    update_halo_3d(ranks, "a", n, dims)
+    assert all(np.all(r["a"] == rk) for rk, r in enumerate(ranks))
+    # gather: blocks side by side in coordinate order
+    ranks = [dict(a=np.full(n, float(rk))) for rk in range(P)]
+    G = gather_3d(ranks, "a", dims)
+    assert G.shape == tuple(dims[d] * (n[d] - 2) for d in range(3))
+    assert G[0, 0, 0] == 0 and G[-1, -1, -1] == P - 1 and G[0, 0, -1] == 1 and G[0, n[1] - 2, 0] == 2 and G[n[0] - 2, 0, 0] == 6
+
+
+def test_virtual_cartesian_ranks_time_step():
+    """run_navierstokes3D_ref on the topology ImplicitGlobalGrid picks by default for 4 ranks, (2,2,1): the overlapping
+    entries of x and y neighbours agree after the step's last halo update, and only the ranks on the inlet / outlet planes own
+    them (multi.jl:164,179)."""
+    from oracle.driver_ref import run_navierstokes3D_ref
+    out = run_navierstokes3D_ref(nx=12, nt=1, dims=(2, 2, 1), niter_cap=30)
+    r = out[-1].ranks
+    assert out[1].shape == (2 * 10, 2 * 6, 6)
+    assert [bool(f.owns_inlet) for f in r] == [True, True, False, False] and [bool(f.owns_outlet) for f in r] == [False, False, True, True]
+    for n in ("Pr", "Vy", "Vz"):
+        assert np.array_equal(r[0][n][-1, :, :], r[2][n][1, :, :]) and np.array_equal(r[0][n][-2, :, :], r[2][n][0, :, :]), n
+    for n in ("Pr", "Vx", "Vz"):
+        assert np.array_equal(r[0][n][:, -1, :], r[1][n][:, 1, :]) and np.array_equal(r[0][n][:, -2, :], r[1][n][:, 0, :]), n
