@@ -1,11 +1,14 @@
-// ns3d_mgpu.cpp — the z-slab multi-GPU half of the boundary (include/ns3d.h, "multi-GPU" section): what the reference
+// ns3d_mgpu.cpp — the multi-GPU half of the boundary (include/ns3d.h, "multi-GPU" section): what the reference
 // gets from ImplicitGlobalGrid.jl + MPI.jl — init_global_grid (multi.jl:325), update_halo! (:371,373,450,453,455,460,462,
 // 182,167,477), max_g (:21), gather! (:399-403,528-532), finalize_global_grid (:534) — plus the pseudo-transient loop of
 // a z-slab rank (multi.jl:458-471) with its halo traffic hidden behind the interior sweep.
 //
-// Decomposition: 1-D slabs along z, ImplicitGlobalGrid's indexing (overlap 2, halo width 1, nz_g = P·(nz−2)+2, an array
-// with nz+s planes has overlap 2+s, physical ends untouched).  Arrays are packed column-major, so every xy-plane — every
-// halo message — is ONE contiguous block: no pack/unpack kernels anywhere.
+// Decomposition: 1-D slabs along z by default, ImplicitGlobalGrid's indexing (overlap 2, halo width 1, nz_g = P·(nz−2)+2, an
+// array with nz+s planes has overlap 2+s, physical ends untouched).  Arrays are packed column-major, so every xy-plane — every
+// z halo message — is ONE contiguous block: no pack/unpack kernels on the z-slab path.  Any Cartesian topology
+// (ns3d_mgpu_create_cart; ns3d_dims_create = MPI_Dims_create, what init_global_grid picks when the script passes no dims) is
+// served by update_halo! / gather! / max_g with the reference's kernel-by-kernel loop on top: x and y faces are strided and
+// go through k_face_copy on both ends, dimensions in the order x, y, z.  The fused slab path below is z-slab only.
 //
 // Two forms, one schedule:
 //   * ns3d_mgpu_create      — ONE process drives P devices (a device may repeat: P virtual ranks on one GPU, which is how the
