@@ -7,6 +7,13 @@ ox_lx = -0.4 (committed) | 0 (domain centre, where the fixture's hot spot x=31,y
 `Vx[1,:,:]=vin` | uniform Vx | uniform Vy; g = 0 (committed) | 9.81.  Result (python oracle/fixture_probe.py, ≈2 min): none of
 the 32 comes within orders of magnitude (the fixture has O(0.2–0.6) at the hot spot with a far field of 1e-7…1e-4, i.e. a
 localized source a few dozen PT iterations old; every variant with a non-zero source gives O(1–400) and a far field ≥ 1e-2).
+A second family (`python oracle/fixture_probe.py radius`): sphere | cylinder of radius 0.05 … 0.12 lx at the domain centre
+with uniform or inlet-plane Vx: hot spot O(2 … 2500), far field of the same size — again nothing close.
+What the fixture itself says (read off its 64 numbers): the far field is uniform over x and y within a z plane
+(−1.5e-4 at z=23, +1.5e-7 / +1.4e-8 at z=12 / 13), i.e. a front that left the TOP wall ≈ 20 cells ago — the damped-wave
+iteration moves 1/√3.1 ≈ 0.57 cells per sweep, so the state is ≈ 37 sweeps old (= nchk, the first residual check) — plus a
+compact source at the domain centre (0.2 … 0.6, decaying 2–3× per cell).  The committed program has neither a source at
+the top wall nor anything at the domain centre (its obstacle sits at ox = −0.4 lx and its velocities start at zero).
 The fixture therefore stays unusable and parity with the Julia program stays UNPINNED.
 """
 import sys, math, itertools
@@ -72,7 +79,37 @@ def run(kind='cyl', ox_lx=-0.4, oz_lx=0.0, ic='vy_plane', g=0.0, nt=1, c_lx=0.05
     got = np.array([[[Pv[x - 1, y - 1, z - 1] for x in inds_x] for y in inds_y] for z in inds_z[:3]])
     return got, iters
 
+def run_radius(kind, a_lx, ic):
+    """second family: obstacle of radius a_lx·lx at the domain centre"""
+    p = multi_params(63)
+    p.a2 = p.b2 = (a_lx * p.lx) ** 2
+    f = _alloc_multi(p); nx, ny, nz = p.nx, p.ny, p.nz
+    f.xco_g = _x_g(1, p.dx, nx, nx, 0) - (p.lx - p.dx) / 2
+    f.yco_g = _x_g(1, p.dy, ny, ny, 0) - (p.ly - p.dy) / 2
+    f.zco_g = _x_g(1, p.dz, nz, nz, 0) - (p.lz - p.dz) / 2
+    if ic == 'vx_plane': f.Vx[0, :, :] = p.vin
+    else: f.Vx[:, :, :] = p.vin
+    c2 = (a_lx * p.lx) ** 2
+    obstacle(f, p, kind, 0.0, p.oy, 0.0, c2)
+    K.update_tau(f.txx, f.tyy, f.tzz, f.txy, f.txz, f.tyz, f.Vx, f.Vy, f.Vz, p.mu, p.dx, p.dy, p.dz)
+    K.predict_V(f.Vx, f.Vy, f.Vz, f.txx, f.tyy, f.tzz, f.txy, f.txz, f.tyz, p.rho, p.g, p.dt, p.dx, p.dy, p.dz)
+    obstacle(f, p, kind, 0.0, p.oy, 0.0, c2)
+    K.update_divV(f.divV, f.Vx, f.Vy, f.Vz, p.dx, p.dy, p.dz)
+    iters, errs = K.pt_solve(f.Pr, f.dPrdtau, f.divV, f.Rp, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, 0, True, 0.0, p.g,
+                             p.eps, p.niter, p.nchk, p.err_scale_num, p.psc)
+    Pv = np.asarray(f.Pr[1:-1, 1:-1, 1:-1])
+    return np.array([[[Pv[x - 1, y - 1, z - 1] for x in inds_x] for y in inds_y] for z in inds_z[:3]]), iters
+
+
 if __name__ == '__main__':
+    if sys.argv[1:] == ['radius']:
+        print('fixture: hot', ref[:, 2, 0], 'far', ref[:, 0, 3])
+        for kind in ('sphere', 'cyl'):
+            for a_lx in (0.05, 0.08, 0.1, 0.12):
+                for ic in ('vx_all', 'vx_plane'):
+                    got, iters = run_radius(kind, a_lx, ic)
+                    print(kind, a_lx, ic, 'iters', iters, 'hot', got[:, 2, 0], 'far', got[:, 0, 3], flush=True)
+        sys.exit(0)
     cases = []
     for kind in ('cyl', 'sphere'):
         for ox in (-0.4, 0.0):
