@@ -32,6 +32,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -121,6 +122,27 @@ def agree(ok):
 def bring_up_rccl(world, rank, device, nx, ny, nz, mode, tdt):
     """libns3d's own RCCL communicator (ns3d_mgpu_create_rank), probed with a verified plane exchange.  Every stage ends
     with a collective agreement, so either all ranks return a MultiGpu or all return (None, reason)."""
+    # a communicator that never comes up (or a send/recv that never completes) cannot be cancelled from inside the process:
+    # say so and end the rank, so that the launcher tears the job down instead of waiting for the driver's limit
+    limit = float(os.environ.get("NS3D_BENCH_RCCL_TIMEOUT", "300"))
+    stage = ["unique id"]
+
+    def give_up():
+        sys.stderr.write("bench.py rank %d: RCCL bring-up (%s) did not finish within %.0f s; rerun with --transport host\n"
+                         % (rank, stage[0], limit))
+        sys.stderr.flush()
+        os._exit(17)
+
+    dog = threading.Timer(limit, give_up)
+    dog.daemon = True
+    dog.start()
+    try:
+        return _bring_up_rccl(world, rank, device, nx, ny, nz, mode, tdt, stage)
+    finally:
+        dog.cancel()
+
+
+def _bring_up_rccl(world, rank, device, nx, ny, nz, mode, tdt, stage):
     from navierstokes3d_amd import kernels as K
     from navierstokes3d_amd import lib as L
     from navierstokes3d_amd.mgpu import MultiGpu
@@ -134,6 +156,7 @@ def bring_up_rccl(world, rank, device, nx, ny, nz, mode, tdt):
     box = [uid]
     dist.broadcast_object_list(box, src=0)
     mg = None
+    stage[0] = "ncclCommInitRank"
     try:                                            # stage 2: communicator
         mg = MultiGpu.create_rank(world, rank, device, box[0], nx, ny, nz, mode)
     except L.Ns3dError as e:
@@ -143,6 +166,7 @@ def bring_up_rccl(world, rank, device, nx, ny, nz, mode, tdt):
             mg.close()
         return None, "ncclCommInitRank failed on a rank" + (": " + why if why else "")
     ok = True
+    stage[0] = "probe send/recv"
     try:                                            # stage 3: one plane to each z neighbour and back, contents checked
         probe = K.zeros((8, 8, nz), tdt, torch.device("cuda", device))      # nz planes: overlap 2 like a cell-centred field
         probe.fill_(float(rank + 1))
