@@ -239,8 +239,9 @@ NS3D_DECL(float, f32)
  * 2+s (sends plane 2+s / size−(1+s), receives into 1 / size, 1-based); arrays with overlap < 2 have no halo; physical ends
  * are left untouched; the same rule per dimension for a Cartesian topology, dimensions in the order x, y, z so that edge and
  * corner values arrive in two / three hops.  Column-major xy-planes are contiguous, so a z message is one block as it lies;
- * x and y faces are packed / unpacked by a kernel on both ends.  The fused path (ns3d_slab_*, ns3d_pt_solve_slab) takes
- * z-slab topologies only: on a grid decomposed in x or y the loop multi.jl:458-471 runs kernel by kernel with ns3d_update_halo.
+ * x and y faces are packed / unpacked by a kernel on both ends.  ns3d_pt_solve_slab runs the loop multi.jl:458-471 on any
+ * topology: on z-slabs with the deep-ghost state below (several iterations per pass over memory), on a grid decomposed in x
+ * or y with one fused sweep and one halo update per iteration; ns3d_slab_load / _iterate / _store are z-slab only.
  *
  * An ns3d_mgpu holds `nlocal` of the P ranks: all P in the one-process form (ns3d_mgpu_create; planes move by
  * hipMemcpyPeerAsync over xGMI; a device may appear several times — virtual ranks), exactly one in the one-process-per-GPU
@@ -285,7 +286,9 @@ int ns3d_mgpu_pass_depth(const ns3d_mgpu *m);
 /* The pseudo-transient state of a z-slab rank lives in library-owned buffers extended by the ghost planes temporal
  * blocking needs: load → iterate / residual → store; ns3d_pt_solve_slab is the whole inner loop multi.jl:458-471
  * (load, plan, iterate with a global residual check every nchk iterations, store).  Iterates are bit-identical to the
- * single-device solve of the global grid.  (The seam planes of divV are exchanged at load: multi.jl:455's update_halo!(∇V)
+ * single-device solve of the global grid.  p describes the local grid of every rank; p->owns_outlet says whether the GLOBAL
+ * x-hi face carries the outlet rule (multi.jl:179) — the library applies it on the ranks that hold that face (all of them on
+ * z-slabs) — and the z halo flags of p are ignored (set per rank inside).  (The seam planes of divV are exchanged at load: multi.jl:455's update_halo!(∇V)
  * may but need not have run.) */
 int ns3d_slab_iterate(ns3d_mgpu *m, int n_iters);
 int ns3d_slab_plan(ns3d_mgpu *m);

@@ -113,6 +113,8 @@ struct MRank {
     hipStream_t comm = nullptr;                    // halo traffic (high priority)
     hipEvent_t ev_ready = nullptr, ev_landed = nullptr;
     SlabState st;
+    void *cbuf = nullptr;                          // solve_cart: the second pressure buffer
+    size_t cbuf_bytes = 0;
     void *gbuf = nullptr;                          // gather!: packed halo-stripped block
     size_t gbuf_bytes = 0;
 };
@@ -582,7 +584,7 @@ int solve_slab(ns3d_mgpu *m, T *const *Pr, T *const *D, const T *const *divV, co
 // hops), all fields of the call in one exchange per dimension.  z faces are contiguous planes and travel as they lie; x and
 // y faces are packed into / unpacked from the rank's message buffer by k_face_copy on the compute stream.
 template <class T>
-int update_halo_impl(ns3d_mgpu *m, T *const *fields, const int *extents, int nfields)
+int update_halo_core(ns3d_mgpu *m, T *const *fields, const int *extents, int nfields)
 {
     const int n = (int)m->loc.size();
     const int ncell[3] = {m->nx, m->ny, m->nz};
@@ -677,7 +679,87 @@ int update_halo_impl(ns3d_mgpu *m, T *const *fields, const int *extents, int nfi
             }
         }
     }
-    return finish_m(m);
+    return NS3D_OK;
+}
+template <class T>
+int update_halo_impl(ns3d_mgpu *m, T *const *fields, const int *extents, int nfields)
+{
+    const int rc = update_halo_core<T>(m, fields, extents, nfields);
+    return rc ? rc : finish_m(m);
+}
+
+// The inner loop multi.jl:458-471 on a topology that is decomposed in x or y: per iteration ONE fused sweep per rank
+// ({update_dPrdτ!; update_Pr!; set_bc_Pr!} with the boundary rule folded in on EVERY local face) and ONE update_halo!(Pr),
+// which overwrites the faces that have a neighbour with the neighbour's values — x, y, z in turn, so the edge and corner
+// entries between a halo face and a physical face arrive from the rank that owns them.  The interior of iterate n+1 reads
+// only iterate n, whose halos are complete: the iterates equal the reference's kernel-by-kernel sequence with its four halo
+// updates per iteration bit for bit (and the single-device solve of the global grid: Jacobi sweeps are decomposition
+// independent).  Temporal blocking would need deep ghosts in x and y as well: z-slabs (solve_slab) are the fast path.
+template <class T>
+int solve_cart(ns3d_mgpu *m, T *const *Pr, T *const *D, const T *const *divV, const ns3d_pt_params *p, double eps, int niter,
+               int nchk, double err_mul, double err_div, int *iters_done, double *err_hist, int max_checks, int *n_checks)
+{
+    int rc = ns3d_check_pt_params(p, "ns3d_pt_solve_slab");
+    if (rc) return rc;
+    if (p->nx != m->nx || p->ny != m->ny || p->nz != m->nz)
+        return fail(NS3D_ERR_ARG, "ns3d_pt_solve_slab: params grid %dx%dx%d differs from the grid of ns3d_mgpu_create %dx%dx%d", p->nx,
+                    p->ny, p->nz, m->nx, m->ny, m->nz);
+    if (p->bc_kind != NS3D_BC_MULTI) return fail(NS3D_ERR_ARG, "ns3d_pt_solve_slab: gpu.jl's boundary set is single-device");
+    const int n = (int)m->loc.size();
+    const size_t bytes = (size_t)m->nx * m->ny * m->nz * sizeof(T);
+    std::vector<T *> cur(n), other(n);
+    std::vector<ns3d_pt_params> pe(n, *p);
+    for (int l = 0; l < n; ++l) {
+        MRank &r = m->loc[l];
+        if (!Pr[l] || !D[l] || !divV[l]) return fail(NS3D_ERR_ARG, "ns3d_pt_solve_slab: null field pointer (local rank %d)", l);
+        ns3d_device_guard g(r.device);
+        if (r.cbuf_bytes < bytes) {
+            HIPCHK(0, hipStreamSynchronize(compute(r)));
+            if (r.cbuf) HIPCHK(0, hipFree(r.cbuf));
+            r.cbuf = nullptr; r.cbuf_bytes = 0;
+            HIPCHK(0, hipMalloc(&r.cbuf, bytes));
+            r.cbuf_bytes = bytes;
+        }
+        cur[l] = Pr[l]; other[l] = (T *)r.cbuf;
+        pe[l].owns_outlet = (p->owns_outlet && r.nbr[0][1] < 0) ? 1 : 0;      // multi.jl:179: the ranks on the outlet plane
+        pe[l].z_lo_is_halo = pe[l].z_hi_is_halo = 0;                          // every face folded; update_halo! overwrites
+    }
+    const int ext[3] = {m->nx, m->ny, m->nz};
+    int checks = 0, iter = 0, done = niter;
+    while (iter < niter) {
+        for (int l = 0; l < n; ++l) {
+            MRank &r = m->loc[l];
+            ns3d_device_guard g(r.device);
+            hipError_t e = ns3d_enqueue_pt1<T>(r.ctx, compute(r), cur[l], other[l], D[l], divV[l], &pe[l], 1, m->nz - 1);
+            if (e != hipSuccess) return fail(NS3D_ERR_HIP, "sweep launch: %s", hipGetErrorString(e));
+        }
+        if ((rc = update_halo_core<T>(m, other.data(), ext, 1))) return rc;
+        cur.swap(other);
+        ++iter;
+        if (nchk > 0 && iter % nchk == 0) {                                                     // multi.jl:464-469
+            for (int l = 0; l < n; ++l) {
+                MRank &r = m->loc[l];
+                ns3d_device_guard g(r.device);
+                hipError_t e = ns3d_enqueue_residual_key<T>(r.ctx, compute(r), cur[l], divV[l], &pe[l], r.ctx->key_dev);
+                if (e != hipSuccess) return fail(NS3D_ERR_HIP, "residual launch: %s", hipGetErrorString(e));
+            }
+            double mx;
+            if ((rc = reduce_keys(m, &mx))) return rc;
+            const double err = mx * err_mul / err_div;
+            if (err_hist && checks < max_checks) err_hist[checks] = err;
+            ++checks;
+            if (eps >= 0 && (err < eps || !std::isfinite(err))) { done = iter; break; }
+        }
+    }
+    for (int l = 0; l < n; ++l)
+        if (cur[l] != Pr[l]) {
+            MRank &r = m->loc[l];
+            ns3d_device_guard g(r.device);
+            HIPCHK(0, hipMemcpyAsync(Pr[l], cur[l], bytes, hipMemcpyDeviceToDevice, compute(r)));
+        }
+    if (iters_done) *iters_done = done;
+    if (n_checks) *n_checks = checks;
+    return NS3D_OK;
 }
 
 // rank block (bx×by×bz, packed) → its place in the global halo-stripped array (column-major, dims·block entries per side)
@@ -905,6 +987,7 @@ void ns3d_mgpu_destroy(ns3d_mgpu *m)
         free_slab(r);
         if (r.gbuf) (void)hipFree(r.gbuf);
         if (r.hbuf) (void)hipFree(r.hbuf);
+        if (r.cbuf) (void)hipFree(r.cbuf);
         if (r.ev_ready) (void)hipEventDestroy(r.ev_ready);
         if (r.ev_landed) (void)hipEventDestroy(r.ev_landed);
         if (r.comm) (void)hipStreamDestroy(r.comm);
@@ -1063,8 +1146,10 @@ int ns3d_slab_residual(ns3d_mgpu *m, double *out)
         if (!Pr || !dPrdtau || !divV) return fail(NS3D_ERR_ARG, "ns3d_pt_solve_slab: null field list");      \
         if (niter < 0 || nchk < 0) return fail(NS3D_ERR_ARG, "ns3d_pt_solve_slab: negative niter/nchk");     \
         m->loaded = false;                                                                                   \
-        int rc = solve_slab<T>(m, Pr, dPrdtau, divV, p, eps, niter, nchk, err_mul, err_div, iters_done,      \
-                               err_hist, max_checks, n_checks);                                              \
+        int rc = z_slabs(m) ? solve_slab<T>(m, Pr, dPrdtau, divV, p, eps, niter, nchk, err_mul, err_div,     \
+                                            iters_done, err_hist, max_checks, n_checks)                      \
+                            : solve_cart<T>(m, Pr, dPrdtau, divV, p, eps, niter, nchk, err_mul, err_div,     \
+                                            iters_done, err_hist, max_checks, n_checks);                     \
         return rc ? rc : finish_m(m);                                                                        \
     }
 

@@ -160,9 +160,11 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
     coords = list(getattr(grid, "local_coords", [(0, 0, me) for me in local_ranks]))
     ps = [multi_params(nx, dims=dims, coords=c3, **shape) for c3 in coords]
     p = ps[0]
-    if fused and (dims[0] > 1 or dims[1] > 1):
-        raise L.Ns3dError("the fused pseudo-transient loop takes z-slab topologies only (dims = (1,1,P)); dims = %r needs "
-                          "fused=False (the loop multi.jl:458-471 kernel by kernel)" % (dims,))
+    if fused and (dims[0] > 1 or dims[1] > 1) and getattr(grid, "mg", None) is None:
+        raise L.Ns3dError("a topology decomposed in x or y (dims = %r) needs the C-ABI grid (mgpu.MgpuGrid) or fused=False" % (dims,))
+    # multi.jl:179 `xve_g == lx/2`: the outlet rule as the ranks on the last x coordinate evaluate it (the library applies it
+    # on those ranks only; every z-slab rank is one of them)
+    outlet_rule = multi_params(nx, dims=dims, coords=(dims[0] - 1, 0, 0), **shape).owns_outlet
     nx, ny, nz = p.nx, p.ny, p.nz
     niter = p.niter if niter_cap is None else min(p.niter, niter_cap)
     fs = [_alloc(nx, ny, nz, dtype, torch.device("cuda", c.device)) for c in ctxs]             # :343-360
@@ -188,6 +190,8 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
     iframe += 1
     pts = [K.pt_params(f.Pr, q.rho, q.dt, q.dtau, q.damp, q.dx, q.dy, q.dz, L.NS3D_BC_MULTI, q.owns_outlet, 0.0, q.g,
                        q.coords[2] > 0, q.coords[2] < dims[2] - 1) for f, q in zip(fs, ps)]
+    pt_all = K.pt_params(fs[0].Pr, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, L.NS3D_BC_MULTI, outlet_rule, 0.0, p.g,
+                         False, False)      # ns3d_pt_solve_slab: one set for every local rank, halo flags set inside
     if not temporal:
         for c in ctxs:
             c.set_pt2_variant(-1)
@@ -223,7 +227,7 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
             done, errs = K.pt_solve(fs[0].Pr, fs[0].dPrdtau, fs[0].divV, pts[0], p.eps, niter, p.nchk, p.ly * p.ly, p.psc,
                                     ctx=ctxs[0])
         elif mg is not None:                                    # the whole loop inside libns3d (ns3d_pt_solve_slab)
-            done, errs = mg.pt_solve_slab(col("Pr"), col("dPrdtau"), col("divV"), pts[0], p.eps, niter, p.nchk,
+            done, errs = mg.pt_solve_slab(col("Pr"), col("dPrdtau"), col("divV"), pt_all, p.eps, niter, p.nchk,
                                           p.ly * p.ly, p.psc)
         elif slab is not None:                                  # z-slab rank over torch.distributed, deep ghosts
             slab.load(fs[0].Pr, fs[0].dPrdtau, fs[0].divV)

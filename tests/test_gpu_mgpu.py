@@ -159,6 +159,49 @@ def test_pt_solve_slab_equals_global_pt_solve(hip, oracle, P):
     mg.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("dims", [(2, 1, 1), (1, 2, 1), (2, 2, 1), (2, 2, 2), (3, 1, 2)])
+def test_pt_solve_on_a_cartesian_topology_equals_global_pt_solve(hip, dims, dtype):
+    """ns3d_pt_solve_slab on a grid decomposed in x and y (one fused sweep + one update_halo! per iteration inside the
+    library): same iteration count, same error history and same fields — halo entries included — as ns3d_pt_solve on the
+    global grid; the outlet rule only on the ranks of the last x coordinate."""
+    import torch
+    n = (20, 14, 10)
+    N = tuple(dims[d] * (n[d] - 2) + 2 for d in range(3))
+    g = geometry(*N)
+    Pg, Dg, Rg = fields(*N, ["c", "i", "c"], 91, dtype)
+    Pg *= 1e-3; Dg *= 1e-3; Rg *= 1e-6
+    eps, niter, nchk, mul, div = (1.0e-4 if dtype == np.float64 else 1.0e-3), 300, 17, 0.36, 1000.0
+    ctx = hip.Context(0, "strict")
+    dP, dD = hip.from_numpy(Pg), hip.from_numpy(Dg)
+    pg = hip.pt_params(dP, g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, True, 0.25, 0.0)
+    it_ref, errs_ref = hip.pt_solve(dP, dD, hip.from_numpy(Rg), pg, eps, niter, nchk, mul, div, ctx=ctx)
+    torch.cuda.synchronize()
+    Pref, Dref = hip.to_numpy(dP), hip.to_numpy(dD)
+    ctx.close()
+    assert nchk < it_ref and len(errs_ref) == it_ref // nchk
+    from navierstokes3d_amd.mgpu import MultiGpu
+    from oracle.driver_ref import cart_coords
+    P = dims[0] * dims[1] * dims[2]
+    mg = MultiGpu.create([0] * P, *n, "strict", dims=dims)
+
+    def cut(A, r, shrink):
+        c = cart_coords(r, dims)
+        return np.asfortranarray(A[tuple(slice(c[d] * (n[d] - 2), c[d] * (n[d] - 2) + n[d] - shrink) for d in range(3))])
+
+    Pr = [hip.from_numpy(cut(Pg, r, 0)) for r in range(P)]
+    D = [hip.from_numpy(cut(Dg, r, 2)) for r in range(P)]
+    R = [hip.from_numpy(cut(Rg, r, 0)) for r in range(P)]
+    p = hip.pt_params(Pr[0], g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, True, 0.25, 0.0)
+    it, errs = mg.pt_solve_slab(Pr, D, R, p, eps, niter, nchk, mul, div)
+    mg.sync()
+    assert it == it_ref and errs == errs_ref
+    for r in range(P):
+        assert np.array_equal(hip.to_numpy(Pr[r]), cut(Pref, r, 0)), r
+        assert np.array_equal(hip.to_numpy(D[r]), cut(Dref, r, 2)), r
+    mg.close()
+
+
 @pytest.mark.parametrize("P,fused,temporal", [(2, True, True), (3, True, True), (2, True, False), (2, False, False)])
 def test_driver_on_mgpu_grid_vs_oracle_virtual_ranks(hip, P, fused, temporal):
     """The product driver (multi.jl:287-536) on the C-ABI grid — update_halo!, max_g, gather!, and the inner loop as
@@ -232,9 +275,11 @@ def test_update_halo_and_gather_on_a_cartesian_topology(hip, dims):
 
 @pytest.mark.parametrize("dims,nx,shape", [((2, 1, 1), 14, dict(ny=16, nz=16)), ((2, 2, 1), 14, dict(ny=9, nz=16)),
                                            ((2, 2, 2), 14, dict(ny=9, nz=9)), ((3, 2, 1), 10, dict(ny=9, nz=16))])
-def test_driver_on_a_cartesian_topology_vs_oracle_virtual_ranks(hip, dims, nx, shape):
+@pytest.mark.parametrize("fused", [False, True])
+def test_driver_on_a_cartesian_topology_vs_oracle_virtual_ranks(hip, dims, nx, shape, fused):
     """The driver on the topologies ImplicitGlobalGrid picks by default for 2, 4 and 8 ranks (multi.jl:325 →
-    MPI_Dims_create), inner loop kernel by kernel as written (multi.jl:458-471): iteration counts, residual histories, every
+    MPI_Dims_create), inner loop kernel by kernel as written (multi.jl:458-471) or inside the library (ns3d_pt_solve_slab on a
+    Cartesian grid: one fused sweep and one halo update per iteration): iteration counts, residual histories, every
     rank's fields and the gathered arrays against the oracle's virtual ranks, bit for bit.  Only the ranks on the inlet /
     outlet planes apply those conditions (multi.jl:164,179).  The local sizes are chosen so that the GLOBAL grid is the same
     near-isotropic 26×16×16 for every topology: dτ follows max(dx,dy,dz) (multi.jl:341), so the grids ceil(0.6 nx) gives
@@ -251,9 +296,7 @@ def test_driver_on_a_cartesian_topology_vs_oracle_virtual_ranks(hip, dims, nx, s
     assert (p0.nx_g, p0.ny_g, p0.nz_g) == (26, 16, 16)
     mg = MultiGpu.create([0] * P, p0.nx, p0.ny, p0.nz, "strict", dims=dims)
     grid = MgpuGrid(mg, p0.nx, p0.ny, p0.nz)
-    with pytest.raises(L.Ns3dError):                          # the fused loop is z-slab only and says so
-        run_navierstokes3D(nx=nx, nt=1, grid=grid, niter_cap=cap, shape=shape)
-    out = run_navierstokes3D(nx=nx, nt=nt, mode="strict", fused=False, grid=grid, niter_cap=cap, return_info=True, shape=shape)
+    out = run_navierstokes3D(nx=nx, nt=nt, mode="strict", fused=fused, grid=grid, niter_cap=cap, return_info=True, shape=shape)
     info = out[-1]
     ref = run_navierstokes3D_ref(nx=nx, nt=nt, dims=dims, niter_cap=cap, shape=shape)
     assert info.iters == ref[-1].iters and info.errs == ref[-1].errs and info.iters[-1] < cap
@@ -321,5 +364,5 @@ def test_mgpu_argument_errors(hip):
     d = [hip.zeros((10, 6, 4)), hip.zeros((10, 6, 4))]
     p = hip.pt_params(z[0], 1000.0, 0.01, 0.01, 0.1, 0.1, 0.1, 0.1, 0, True, 0.0, 0.0)
     with pytest.raises(L.Ns3dError, match="z-slab"):
-        mg.slab_load(z, d, z, p)                              # fused path: z-slabs only
+        mg.slab_load(z, d, z, p)                              # the deep-ghost state: z-slabs only
     mg.close()
