@@ -596,14 +596,15 @@ def test_pt_iterate_and_solve_with_deep_temporal_blocking(hip, oracle, grid, dep
     ctx.close()
 
 
-def _full_size_properties(hip, oracle, n, dtype):
-    """A full-size BASELINE grid (n³ cells), where the oracle cannot sweep the whole grid in test time: (a) the planned
+def _full_size_properties(hip, oracle, n, dtype, slab_at=None):
+    """A full-size BASELINE grid (n³ cells, or n = (nx, ny, nz)), where the oracle cannot sweep the whole grid in test time: (a) the planned
     two-iteration kernel (ns3d_plan_pt times the tile shapes on these very arguments), two launches of the
     one-thread-per-cell sweep and two of the z-marching sweep give the same bits on the whole grid (three independent kernels;
-    compared on the device); (b) locality — two iterations on planes [a+2, b-2) depend only on planes [a, b) — lets the oracle
+    compared on the device), and the three-iteration pass equals three single sweeps; (b) locality — two iterations on planes [a+2, b-2) depend only on planes [a, b) — lets the oracle
     check a 30-plane sub-slab cut out of the middle, x/y faces and outlet plane included, bit for bit."""
     import torch
-    g = geometry(n, n, n)
+    nx, ny, nz = (n, n, n) if isinstance(n, int) else n
+    g = geometry(nx, ny, nz)
     gen = torch.Generator(device="cuda"); gen.manual_seed(20240512)
     tdt, bits = (torch.float64, torch.int64) if dtype == "f64" else (torch.float32, torch.int32)
     zeros = lambda shape: hip.zeros(shape, tdt)
@@ -613,26 +614,35 @@ def _full_size_properties(hip, oracle, n, dtype):
         t.permute(2, 1, 0).uniform_(-1.0, 1.0, generator=gen)
         return t
 
-    P0, D0, R = rnd_dev(n, n, n), rnd_dev(n - 2, n - 2, n - 2), rnd_dev(n, n, n)
+    P0, D0, R = rnd_dev(nx, ny, nz), rnd_dev(nx - 2, ny - 2, nz - 2), rnd_dev(nx, ny, nz)
     ctx = hip.Context(0, "strict")
     p = _params(hip, P0, g, 0, True, 0.75)
     # (a1) the two-iteration kernel: plan (times the tile shapes, keeps the winner), then the launch proper
-    Pa, Da = zeros((n, n, n)), zeros((n - 2, n - 2, n - 2))
+    Pa, Da = zeros((nx, ny, nz)), zeros((nx - 2, ny - 2, nz - 2))
     hip.plan_pt(P0, Pa, D0, Da, R, p, ctx=ctx)
     Pa.zero_(); Da.zero_()
     hip.pt_sweep2(P0, Pa, D0, Da, R, p, ctx=ctx)
     # (a2/a3) two single sweeps, two different kernel families
     for variant in (100, 2200):
         ctx.set_pt_variant(variant)
-        Pb, Pc, Db = zeros((n, n, n)), zeros((n, n, n)), hip.clone(D0)
-        hip.pt_sweep(P0, Pb, Db, R, p, 1, n - 1, ctx=ctx)
-        hip.pt_sweep(Pb, Pc, Db, R, p, 1, n - 1, ctx=ctx)
+        Pb, Pc, Db = zeros((nx, ny, nz)), zeros((nx, ny, nz)), hip.clone(D0)
+        hip.pt_sweep(P0, Pb, Db, R, p, 1, nz - 1, ctx=ctx)
+        hip.pt_sweep(Pb, Pc, Db, R, p, 1, nz - 1, ctx=ctx)
         torch.cuda.synchronize()
-        assert torch.equal(Pa.view(bits), Pc.view(bits)), "Pr differs between kernels at %d^3" % n
-        assert torch.equal(Da.view(bits), Db.view(bits)), "dPrdτ differs between kernels at %d^3" % n
+        assert torch.equal(Pa.view(bits), Pc.view(bits)), "Pr differs between kernels at %r" % (n,)
+        assert torch.equal(Da.view(bits), Db.view(bits)), "dPrdτ differs between kernels at %r" % (n,)
+        if variant == 100:          # (a4) the three-iteration pass (k_pt_sweepN) against a third single sweep
+            hip.pt_sweep(Pc, Pb, Db, R, p, 1, nz - 1, ctx=ctx)
+            Pn, Dn = zeros((nx, ny, nz)), zeros((nx - 2, ny - 2, nz - 2))
+            hip.pt_sweepn(3, P0, Pn, D0, Dn, R, p, ctx=ctx)
+            torch.cuda.synchronize()
+            assert torch.equal(Pn.view(bits), Pb.view(bits)), "Pr differs after three iterations at %r" % (n,)
+            assert torch.equal(Dn.view(bits), Db.view(bits)), "dPrdτ differs after three iterations at %r" % (n,)
+            del Pn, Dn
         del Pb, Pc, Db
     # (b) oracle on the sub-slab of planes [a, b) (sliced on the device: only the sub-slab crosses PCIe)
-    a, b = n // 2 - 16, n // 2 + 14
+    mid = nz // 2 if slab_at is None else slab_at
+    a, b = mid - 16, mid + 14
     Ps = hip.to_numpy(P0[:, :, a:b])
     Ds = hip.to_numpy(D0[:, :, a:b - 2])
     Rs = hip.to_numpy(R[:, :, a:b])
@@ -640,6 +650,8 @@ def _full_size_properties(hip, oracle, n, dtype):
     assert np.array_equal(hip.to_numpy(Pa[:, :, a + 2:b - 2]), Ps[:, :, 2:-2])
     assert np.array_equal(hip.to_numpy(Da[:, :, a + 1:b - 3]), Ds[:, :, 1:-1])          # dPrdτ index = plane − 1
     ctx.close()
+    del P0, D0, R, Pa, Da
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
@@ -652,3 +664,18 @@ def test_full_size_512_cubed_properties(hip, oracle, dtype):
 def test_full_size_1024_cubed_properties(hip, oracle, dtype):
     """BASELINE.json configs[4]'s one-GPU point (1024³, 1.07 G cells, fp64 and fp32): 8.6 / 4.3 GB per array."""
     _full_size_properties(hip, oracle, 1024, dtype)
+
+
+@pytest.mark.parametrize("dtype,shape", [("f64", (1536, 1536, 1000)), ("f32", (2048, 2048, 1100))])
+def test_grids_beyond_32_bit_indexing(hip, oracle, dtype, shape):
+    """Maximum sizes: one MI355X holds 288 GB, so a single rank can own grids whose element count (2.36 G cells, fp64) or whose
+    element AND byte offsets (4.61 G cells, fp32: past 2³² elements from plane 1024 on) do not fit 32 bits.  Same three-kernel
+    agreement on the whole grid as the BASELINE sizes; the oracle's sub-slab is cut out of the LAST planes, where every offset
+    is beyond the 32-bit range (19 / 18.5 GB per array, ≈ 190 GB in the test)."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    cells = shape[0] * shape[1] * shape[2]
+    need = 10.5 * cells * (8 if dtype == "f64" else 4)
+    if free < need:
+        pytest.skip("needs %.0f GB of free device memory, %.0f GB available" % (need / 1e9, free / 1e9))
+    _full_size_properties(hip, oracle, shape, dtype, slab_at=shape[2] - 24)
