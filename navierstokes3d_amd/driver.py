@@ -5,7 +5,8 @@
 
 Same keyword names, same return contract (C_v,Pr_v,Vx_v,Vy_v,Vz_v: halo-stripped global host arrays on rank 0,
 multi.jl:528-535).  Extra keyword-only options select the arithmetic mode, the fused PT path and the z-slab
-process grid.  Plotting (do_vis) is out of scope and raises if requested.
+process grid.  do_vis writes the reference's mid-plane heat maps as bare PNG files (vis.py: same names, slices and colour
+limits; no axes — Plots.jl itself is out of scope).
 
 The time loops below follow the reference line by line (cited); with `fused=True` the inner pseudo-transient
 loop {update_dPrdτ!; update_Pr!; set_bc_Pr!}×n is replaced by ns3d_pt_solve / overlapped ns3d_pt_sweep calls
@@ -23,6 +24,7 @@ from . import lib as L
 from .halo import ZSlabGrid
 from .slab import SlabPTSolver
 from .params import gpu_params, multi_params
+from .vis import save_frame_gpu, save_frame_multi
 
 
 def _alloc(nx, ny, nz, dtype, device):
@@ -142,8 +144,6 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
     fused=False (ImplicitGlobalGrid's own default is MultiGpu.dims_create(P), e.g. (2,2,2) for 8 ranks).
     `shape` (dict: ny, nz, ly_lx, lz_lx) overrides the literals multi.jl:302-303,323-324 for grids the reference cannot
     produce without editing them (BASELINE configs[3]: 512×512×1024 global)."""
-    if do_vis:
-        raise NotImplementedError("plotting (multi.jl:416-443, 486-513) is out of scope of this build")
     if device is None:
         device = torch.cuda.current_device()
     shape = dict(shape or {})
@@ -184,9 +184,15 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
     grid.update_halo(col("C"), col("Vx"), col("Vy"), col("Vz"))                               # :373
     sync = lambda: [c.sync() for c in ctxs]
     iframe = 0
-    if do_save:                                                                               # :404-413
+    nz_g_all = dims[2] * (nz - 2) + 2
+    ny_g_all = dims[1] * (ny - 2) + 2
+    if do_save or do_vis:                                                                     # :399-403
         sync()
-        _save_frame(grid, _gather_all(grid, fs), iframe)
+        gathered = _gather_all(grid, fs)
+        if do_save:                                                                           # :404-413
+            _save_frame(grid, gathered, iframe)
+        if do_vis and _is_root(grid):                                                         # :416-443
+            save_frame_multi(gathered, ny_g_all, nz_g_all, iframe)
     iframe += 1
     pts = [K.pt_params(f.Pr, q.rho, q.dt, q.dtau, q.damp, q.dx, q.dy, q.dz, L.NS3D_BC_MULTI, q.owns_outlet, 0.0, q.g,
                        q.coords[2] > 0, q.coords[2] < dims[2] - 1) for f, q in zip(fs, ps)]
@@ -204,7 +210,7 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
                             p.owns_outlet, 0.0, p.g)
     scratch = K.clone(fs[0].Pr) if (fused and P > 1 and mg is None and slab is None) else None
     info = SimpleNamespace(iters=[], errs=[], params=p)
-    nsave = 10                                                                                # :332
+    nsave = nvis = 10                                                                         # :330,332
     root = _is_root(grid)
     for it in range(1, nt + 1):                                                               # :446
         for f, c in zip(fs, ctxs):
@@ -251,9 +257,13 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
             K.copy(f.Vz_o, f.Vz, ctx=c); K.copy(f.C_o, f.C, ctx=c)
             K.advect(f.Vx, f.Vx_o, f.Vy, f.Vy_o, f.Vz, f.Vz_o, f.C, f.C_o, p.dt, p.dx, p.dy, p.dz, faithful, ctx=c)  # :476
         grid.update_halo(col("Vx"), col("Vy"), col("Vz"))                                     # :477 (not C)
-        if do_save and it % nsave == 0:                                                       # :479-525
+        if (do_vis and it % nvis == 0) or (do_save and it % nsave == 0):                      # :479-525 (one frame counter)
             sync()
-            _save_frame(grid, _gather_all(grid, fs), iframe)
+            gathered = _gather_all(grid, fs)
+            if do_vis and it % nvis == 0 and root:                                            # :486-513
+                save_frame_multi(gathered, ny_g_all, nz_g_all, iframe)
+            if do_save and it % nsave == 0:                                                   # :515-522
+                _save_frame(grid, gathered, iframe)
             iframe += 1
     sync()
     out = _gather_all(grid, fs)                                                               # :528-532
@@ -293,9 +303,8 @@ def runme(do_vis=False, do_save=False, *, nx=255, nt=10000, mode="strict", fused
           faithful=True, device=None, niter_cap=None, do_print=False, initial=None):
     """runme (gpu.jl:12-173): single device, gravity, hydrostatic x-planes.  Returns (fields, info).
     nx/nt are literals in the reference (gpu.jl:44,51: 255, 10000) and keyword options here.  do_save writes the MAT files
-    of gpu.jl:89,168-170 (step 0 and every nsave = 10 steps)."""
-    if do_vis:
-        raise NotImplementedError("plotting (gpu.jl:90-117, 143-167) is out of scope of this build")
+    of gpu.jl:89,168-170 (step 0 and every nsave = 10 steps); do_vis the heat maps of gpu.jl:90-117,143-167 (frame 0 and
+    every nvis = 10 steps)."""
     if device is None:
         device = torch.cuda.current_device()
     dev = torch.device("cuda", device)
@@ -310,11 +319,17 @@ def runme(do_vis=False, do_save=False, *, nx=255, nt=10000, mode="strict", fused
     cyl = (p.a2, p.b2, p.ox, p.oy, p.sinb, p.cosb, p.lx, p.ly, p.lz, p.dx, p.dy, p.dz)
     pt = K.pt_params(f.Pr, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, L.NS3D_BC_GPU, False, 0.0, p.g)
     info = SimpleNamespace(iters=[], errs=[], params=p)
-    nsave = 10                                                                                # :52
+    nsave = nvis = 10                                                                         # :50,52
     if do_save:                                                                               # :89
         os.makedirs("./out_save", exist_ok=True)
         ctx.sync()
         _save_mat("out_save/step_0.mat", f, p, True)
+    iframe = 0
+    host = lambda: {n: K.to_numpy(getattr(f, n)) for n in ("Pr", "C", "Vx", "Vy", "Vz")}
+    if do_vis:                                                                                # :90-117
+        ctx.sync()
+        save_frame_gpu(host(), ny, nz, iframe)
+        iframe += 1
     for it in range(1, nt + 1):                                                               # :119
         K.update_tau(f.txx, f.tyy, f.tzz, f.txy, f.txz, f.tyz, f.Vx, f.Vy, f.Vz, p.mu, p.dx, p.dy, p.dz, ctx=ctx)  # :121
         K.predict_V(f.Vx, f.Vy, f.Vz, f.txx, f.tyy, f.tzz, f.txy, f.txz, f.tyz, p.rho, p.g, p.dt, p.dx, p.dy, p.dz,
@@ -348,6 +363,10 @@ def runme(do_vis=False, do_save=False, *, nx=255, nt=10000, mode="strict", fused
         K.copy(f.Vx_o, f.Vx, ctx=ctx); K.copy(f.Vy_o, f.Vy, ctx=ctx)                          # :141
         K.copy(f.Vz_o, f.Vz, ctx=ctx); K.copy(f.C_o, f.C, ctx=ctx)
         K.advect(f.Vx, f.Vx_o, f.Vy, f.Vy_o, f.Vz, f.Vz_o, f.C, f.C_o, p.dt, p.dx, p.dy, p.dz, faithful, ctx=ctx)  # :142
+        if do_vis and it % nvis == 0:                                                         # :143-167
+            ctx.sync()
+            save_frame_gpu(host(), ny, nz, iframe)
+            iframe += 1
         if do_save and it % nsave == 0:                                                       # :168-170
             ctx.sync()
             _save_mat("out_save/step_%d.mat" % it, f, p, False)

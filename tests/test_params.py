@@ -53,3 +53,52 @@ def test_algorithmic_bytes():
     # 5 318.6 MB per PT iteration at 512³ fp64, 232.4 MB at 255×153×153
     assert round(bench.algorithmic_bytes(512, 512, 512, 8) / 1e6, 1) == 5318.6
     assert round(bench.algorithmic_bytes(255, 153, 153, 8) / 1e6, 1) == 232.4
+
+
+def _read_png(path):
+    """minimal PNG reader for the files vis.write_png makes (8-bit RGB, filter 0): returns (h, w, 3) uint8"""
+    import struct
+    import zlib
+    import numpy as np
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(raw):
+        n, tag = struct.unpack(">I4s", raw[pos:pos + 8])
+        data = raw[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + data) & 0xFFFFFFFF
+        chunks.append((tag, data))
+        pos += 12 + n
+    assert [t for t, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    w, h, depth, ctype = struct.unpack(">IIBB", chunks[0][1][:10])
+    assert (depth, ctype) == (8, 2)
+    rows = np.frombuffer(zlib.decompress(chunks[1][1]), dtype=np.uint8).reshape(h, 1 + 3 * w)
+    assert not rows[:, 0].any()
+    return rows[:, 1:].reshape(h, w, 3)
+
+
+def test_heatmap_png_files(tmp_path):
+    """vis.py: valid PNG (signature, chunk CRCs, inflatable rows); orientation of heatmap(x, y, A'): x to the right, y upwards;
+    colour limits clamp; NaN is grey; the frame writers use the reference's file names (multi.jl:435-443, gpu.jl:101-115)."""
+    import numpy as np
+    from navierstokes3d_amd import vis
+    A = np.zeros((6, 4))
+    A[5, 0] = 1.0                     # largest x, smallest y → bottom right
+    A[0, 3] = np.nan                  # smallest x, largest y → top left
+    shp = vis.heatmap_png(str(tmp_path / "a.png"), A, (0.0, 1.0), min_side=8)
+    img = _read_png(tmp_path / "a.png")
+    assert img.shape[:2] == shp == (8, 12)                     # 4×6 cells drawn as 2×2 blocks
+    assert tuple(img[-1, -1]) == (252, 255, 164) and tuple(img[0, 0]) == (128, 128, 128) and tuple(img[0, -1]) == (0, 0, 4)
+    vis.heatmap_png(str(tmp_path / "b.png"), A * 10 - 5, (0.0, 1.0), min_side=1)          # clamped at both ends
+    img = _read_png(tmp_path / "b.png")
+    assert img.shape == (4, 6, 3) and tuple(img[-1, -1]) == (252, 255, 164) and tuple(img[-1, 0]) == (0, 0, 4)
+    rng = np.random.default_rng(1)
+    fv = [rng.random(s) for s in ((10, 6, 6), (10, 6, 6), (11, 6, 6), (10, 7, 6), (10, 6, 7))]
+    names = vis.save_frame_multi(fv, 8, 8, 3, str(tmp_path / "viz3D_out"))
+    assert sorted(n.split("/")[-1] for n in names) == sorted("3D_NavierStokes_%s_%s_0003.png" % (t, f) for t in ("xy", "xz")
+                                                             for f in ("C", "Pr", "Vx", "Vy", "Vz"))
+    assert _read_png(names[0]).shape[2] == 3
+    g = dict(Pr=fv[0], C=fv[1], Vx=fv[2], Vy=fv[3], Vz=fv[4])
+    names = vis.save_frame_gpu(g, 6, 6, 0, str(tmp_path / "viz3D_out"))
+    assert sorted(n.split("/")[-1] for n in names) == sorted("3D_NavierStokes_%s%s_0000.png" % (t, f) for t in ("", "long_")
+                                                             for f in ("C", "Pr", "Vx", "Vy", "Vz"))

@@ -30,3 +30,4 @@ python3 tools/kernel_rates.py > $O/${TAG}_kernel_rates_512.jsonl 2>/dev/null; gr
 python3 tools/run_config.py --script multi --nx 63 --nt 20 > $O/${TAG}_config_a_63x38x38.json 2>/dev/null; tail -c 300 $O/${TAG}_config_a_63x38x38.json; echo
 python3 tools/run_config.py --script multi --nx 255 --nt 3 --compare-fast > $O/${TAG}_config_b_multi_255x153x153.json 2>/dev/null; tail -c 300 $O/${TAG}_config_b_multi_255x153x153.json; echo
 python3 tools/run_config.py --script gpu --nx 255 --nt 3 > $O/${TAG}_config_b_gpujl_255x153x153.json 2>/dev/null; tail -c 300 $O/${TAG}_config_b_gpujl_255x153x153.json; echo
+python3 tools/cart_rates.py > $O/${TAG}_cart_rates.jsonl 2> $O/${TAG}_cart_rates.err; cat $O/${TAG}_cart_rates.jsonl
