@@ -240,3 +240,61 @@ def test_virtual_cartesian_ranks_time_step():
         assert np.array_equal(r[0][n][-1, :, :], r[2][n][1, :, :]) and np.array_equal(r[0][n][-2, :, :], r[2][n][0, :, :]), n
     for n in ("Pr", "Vx", "Vz"):
         assert np.array_equal(r[0][n][:, -1, :], r[1][n][:, 1, :]) and np.array_equal(r[0][n][:, -2, :], r[1][n][:, 0, :]), n
+
+
+def test_projection_identity_div_grad_is_the_laplacian(oracle):
+    """Chorin's projection as an algebraic identity of the three restated operators, for ANY pressure field:
+    update_∇V!(correct_V!(V*, Pr)) = update_∇V!(V*) − dt/ρ·∇²Pr = −dt/ρ·compute_res!(Pr, ∇V*) on every cell whose six faces
+    correct_V! updates.  A misread index offset in @d_xi (correct_V!), @d_xa (update_∇V!) or @d2_xi (compute_res!) breaks it at
+    O(1); dyadic data make every operation exact, so the identity holds to the bit."""
+    nx, ny, nz = 11, 9, 8
+    h, dt, rho = 0.5, 0.25, 2.0
+    rng = np.random.default_rng(5)
+    dy = lambda *s: np.asfortranarray(rng.integers(-8, 9, size=s).astype(np.float64) / 4)      # multiples of 1/4
+    Pr, Vx, Vy, Vz = dy(nx, ny, nz), dy(nx + 1, ny, nz), dy(nx, ny + 1, nz), dy(nx, ny, nz + 1)
+    div0 = np.zeros((nx, ny, nz), order="F")
+    oracle.update_divV(div0, Vx, Vy, Vz, h, h, h)
+    Rp = np.zeros((nx - 2, ny - 2, nz - 2), order="F")
+    oracle.compute_res(Rp, Pr, div0, rho, dt, h, h, h)
+    oracle.correct_V(Vx, Vy, Vz, Pr, dt, rho, h, h, h)
+    div1 = np.zeros((nx, ny, nz), order="F")
+    oracle.update_divV(div1, Vx, Vy, Vz, h, h, h)
+    inner = div1[1:-1, 1:-1, 1:-1]
+    assert np.abs(Rp).max() > 1 and np.array_equal(inner, -(dt / rho) * Rp)
+    # … and the faces correct_V! leaves alone keep the divergence of the outermost cells as it was, up to their one inner face
+    assert np.array_equal(div1[0, 0, 0], div0[0, 0, 0])
+
+
+def test_viscous_predictor_is_exact_for_cubic_shear_flows(oracle):
+    """update_τ! → predict_V! on the six pure shear flows u_a = s_b³ (velocity component a depending on coordinate b ≠ a, cell-
+    centred coordinate s_b = (index+½)·h in b): the analytic answer is Δu_a = dt/ρ·μ·6·s_b, and the second difference of a
+    cubic is exact, so the staggered stencils must return exactly that at every face predict_V! updates — with s_b the
+    coordinate of the row the face itself sits in.  Pairing the wrong rows (an offset misread in @d_yi/@d_xa of the shear
+    terms) gives 6·(s_b ± h) instead.  All data dyadic: exact to the bit."""
+    n = (9, 8, 7)
+    h, dt, rho, mu = 0.5, 0.25, 2.0, 0.5
+    z = lambda *s: np.zeros(s, order="F")
+    for a in range(3):
+        for b in range(3):
+            if a == b:
+                continue
+            V = [z(n[0] + 1, n[1], n[2]), z(n[0], n[1] + 1, n[2]), z(n[0], n[1], n[2] + 1)]
+            s_b = (np.arange(n[b]) + 0.5) * h
+            shape = [1, 1, 1]; shape[b] = n[b]
+            V[a][...] = (s_b ** 3).reshape(shape)
+            V0 = [v.copy(order="F") for v in V]
+            tau = [z(*n), z(*n), z(*n), z(n[0] - 1, n[1] - 1, n[2] - 1), z(n[0] - 1, n[1] - 1, n[2] - 1), z(n[0] - 1, n[1] - 1, n[2] - 1)]
+            oracle.update_tau(*tau, V[0], V[1], V[2], mu, h, h, h)
+            assert all(np.all(t == 0) for t in tau[:3])                      # no normal deviatoric stress in a shear flow
+            oracle.predict_V(V[0], V[1], V[2], *tau, rho, 0.0, dt, h, h, h)
+            for c in range(3):
+                dV = V[c] - V0[c]
+                if c != a:
+                    assert np.all(dV == 0), (a, b, c)
+                    continue
+                want = np.zeros_like(dV)
+                want[...] = ((dt / rho) * mu * 6.0 * s_b).reshape(shape)
+                upd = [slice(1, -1)] * 3                                      # predict_V! updates the inner entries only
+                assert np.array_equal(dV[tuple(upd)], want[tuple(upd)]), (a, b)
+                outer = np.ones(dV.shape, bool); outer[tuple(upd)] = False
+                assert np.all(dV[outer] == 0), (a, b)
