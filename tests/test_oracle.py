@@ -298,3 +298,24 @@ def test_viscous_predictor_is_exact_for_cubic_shear_flows(oracle):
                 assert np.array_equal(dV[tuple(upd)], want[tuple(upd)]), (a, b)
                 outer = np.ones(dV.shape, bool); outer[tuple(upd)] = False
                 assert np.all(dV[outer] == 0), (a, b)
+
+
+def test_advect_reproduces_linear_fields_exactly(oracle):
+    """backtrack!/lerp (multi.jl:190-215) is a trilinear interpolation at the departure point x − v·dt: a field that is linear
+    in x, y, z, carried by a uniform velocity with fractional CFL numbers of both signs in the three directions, comes out as
+    the same linear function shifted by v·dt — exactly, on dyadic data — wherever the departure cell lies inside the array.
+    (Which of the 8 neighbours pair with which weight is what the index/weight logic of backtrack! has to get right.)"""
+    nx, ny, nz = 10, 9, 8
+    h, dt = 0.5, 0.25
+    v = (0.5, -1.0, 1.5)                                            # CFL = v·dt/h = 0.25, −0.5, 0.75
+    lin = lambda X, Y, Z: 3.0 * X - 2.0 * Y + 0.5 * Z + 1.0
+    xc, yc, zc = [(np.arange(m) + 0.5) * h for m in (nx, ny, nz)]
+    C_o = np.asfortranarray(lin(xc[:, None, None], yc[None, :, None], zc[None, None, :]))
+    Vx_o = np.asfortranarray(np.full((nx + 1, ny, nz), v[0])); Vy_o = np.asfortranarray(np.full((nx, ny + 1, nz), v[1]))
+    Vz_o = np.asfortranarray(np.full((nx, ny, nz + 1), v[2]))
+    outs = [np.zeros_like(a, order="F") for a in (Vx_o, Vy_o, Vz_o, C_o)]
+    oracle.advect(outs[0], Vx_o, outs[1], Vy_o, outs[2], Vz_o, outs[3], C_o, dt, h, h, h, True)
+    want = lin(xc[:, None, None] - v[0] * dt, yc[None, :, None] - v[1] * dt, zc[None, None, :] - v[2] * dt)
+    assert np.array_equal(outs[3][1:-1, 1:-1, 1:-1], want[1:-1, 1:-1, 1:-1])
+    assert not np.array_equal(outs[3][1:-1, 1:-1, 1:-1], C_o[1:-1, 1:-1, 1:-1])
+    assert np.all(outs[0][1:-1, 1:-1, 1:-1] == v[0]) and np.all(outs[1][1:-1, 1:-1, 1:-1] == v[1])      # uniform fields are fixed points
