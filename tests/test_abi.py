@@ -108,3 +108,28 @@ def test_multi_gpu_layer_fails_loudly_without_gpu(L):
     for fn in ("ns3d_mgpu_world", "ns3d_mgpu_nlocal", "ns3d_mgpu_nz_g", "ns3d_mgpu_pass_depth"):
         assert getattr(lib, fn)(None) == -1
     assert lib.ns3d_slab_iterate(None, 1) == L.NS3D_ERR_ARG and lib.ns3d_mgpu_sync(None) == L.NS3D_ERR_ARG
+
+
+def build_c_host(tmp_path):
+    """tests/c_host/ns3d_c_host.c with gcc as C11, warnings as errors, against include/ns3d.h and the in-tree libns3d.so"""
+    import subprocess
+    exe = str(tmp_path / "ns3d_c_host")
+    libdir = os.path.join(ROOT, "navierstokes3d_amd")
+    cmd = ["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I",
+           "/opt/rocm/include", os.path.join(ROOT, "tests", "c_host", "ns3d_c_host.c"), "-L", libdir, "-lns3d", "-L", "/opt/rocm/lib",
+           "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_host_links(L, tmp_path):
+    """include/ns3d.h is a C header (the boundary the reference's `ccall` binds): a C11 translation unit that uses the context,
+    the reference-signature kernels, the fused path and the error channel compiles without a warning and links against
+    libns3d.so alone (+ the HIP runtime for its own allocations).  Without a GPU it reports the library's message and exits 3."""
+    import subprocess
+    exe = build_c_host(tmp_path)
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 3 and "ns3d_create failed" in r.stderr and "no CPU path" in r.stderr
