@@ -1,0 +1,146 @@
+"""julia/NS3DShim.jl cannot be executed (no Julia toolchain here or on the GPU box).  What CAN be checked mechanically is
+checked here: every `ccall((:ns3d_…, libns3d), Ret, (ArgTypes…), args…)` in the shim against the prototype the C preprocessor
+expands out of include/ns3d.h — symbol exists, return class, number and class (pointer / double / int / 64-bit int) of every
+argument, as many actual arguments as declared types — and the field-for-field layout of `struct PtParams` against
+`ns3d_pt_params` (and against the ctypes mirror the GPU tests drive the same entry points through)."""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "julia", "NS3DShim.jl")
+HEADER = os.path.join(ROOT, "include", "ns3d.h")
+
+
+def split_top(s):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        depth += ch in "([{"
+        depth -= ch in ")]}"
+        if ch == "," and depth == 0:
+            out.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def closing(s, i):
+    depth = 0
+    for j in range(i, len(s)):
+        depth += s[j] == "("
+        if s[j] == ")":
+            depth -= 1
+            if depth == 0:
+                return j
+    raise ValueError("unbalanced")
+
+
+def shim_source():
+    return re.sub(r"#[^\n]*", "", open(SHIM, encoding="utf-8").read())
+
+
+def julia_ccalls():
+    src, calls = shim_source(), []
+    for m in re.finditer(r"ccall\(\(:(\w+),\s*libns3d\)\s*,", src):
+        start = src.index("(", m.start())
+        parts = split_top(src[start + 1:closing(src, start)])
+        ret, types, args = parts[1], parts[2], parts[3:]
+        assert types.startswith("(") and types.endswith(")"), (m.group(1), types)
+        calls.append((m.group(1), ret, split_top(types[1:-1]), args))
+    return calls
+
+
+def jclass(t):
+    t = t.strip()
+    if t == "Cint":
+        return "int"
+    if t == "Cdouble":
+        return "double"
+    if t in ("Clong", "Clonglong", "Culonglong"):
+        return "int64"
+    if t == "Cvoid":
+        return "void"
+    if t in ("PF", "Cstring") or t.startswith("Ptr{") or t.startswith("Ref{"):
+        return "ptr"
+    raise ValueError("unmapped Julia C type " + t)
+
+
+def cclass(p):
+    p = p.strip()
+    if "*" in p:
+        return "ptr"
+    if p.startswith("double"):
+        return "double"
+    if p.startswith("int"):
+        return "int"
+    if p.startswith("long") or p.startswith("unsigned"):
+        return "int64"
+    raise ValueError("unmapped C parameter " + p)
+
+
+def header_prototypes():
+    txt = subprocess.run(["gcc", "-E", "-P", HEADER], capture_output=True, text=True, check=True).stdout
+    txt = re.sub(r"\s+", " ", txt)
+    protos = {}
+    for m in re.finditer(r"([\w ]+?[\s\*]+)(ns3d_\w+)\s*\(([^()]*)\)\s*;", txt):
+        ret, name, params = m.group(1).strip(), m.group(2), m.group(3).strip()
+        pl = [] if params in ("", "void") else [cclass(p) for p in split_top(params)]
+        protos[name] = ("ptr" if "*" in ret else "void" if ret.endswith("void") else "int", pl)
+    return protos, txt
+
+
+def test_every_ccall_matches_its_prototype():
+    protos, _ = header_prototypes()
+    calls = julia_ccalls()
+    assert len(calls) >= 30 and len(protos) >= 100
+    for name, ret, types, args in calls:
+        assert name in protos, "the shim binds %s, which include/ns3d.h does not declare" % name
+        cret, cparams = protos[name]
+        assert jclass(ret) == cret, (name, ret, cret)
+        assert [jclass(t) for t in types] == cparams, (name, types, cparams)
+        assert len(args) == len(types), (name, len(args), len(types))
+    bound = {c[0] for c in calls}
+    # the reference-signature kernels and the grid layer are all bound
+    for need in ("update_tau", "predict_V", "set_cylinder", "update_divV", "update_dPrdtau", "update_Pr", "compute_res", "correct_V",
+                 "advect", "bc_x", "bc_y", "bc_z", "pt_solve", "pt_solve_slab", "update_halo", "max_abs"):
+        assert "ns3d_%s_f64" % need in bound, need
+    for need in ("ns3d_create", "ns3d_last_error", "ns3d_dims_create", "ns3d_mgpu_unique_id", "ns3d_mgpu_create_rank_cart",
+                 "ns3d_mgpu_ctx", "ns3d_mgpu_coords", "ns3d_mgpu_destroy"):
+        assert need in bound, need
+
+
+def test_ptparams_struct_layout():
+    _, txt = header_prototypes()
+    body = re.search(r"typedef struct ns3d_pt_params \{(.*?)\} ns3d_pt_params;", txt).group(1)
+    cfields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ctype, names = decl.split(" ", 1)
+        cfields += [(n.strip(), ctype) for n in names.split(",")]
+    jbody = re.search(r"struct PtParams(.*?)\nend", shim_source(), re.S).group(1)
+    jfields = [(n, {"Cdouble": "double", "Cint": "int"}[t]) for n, t in re.findall(r"(\w+)::(\w+)", jbody)]
+    assert jfields == cfields
+    from navierstokes3d_amd import lib as L
+    import ctypes as C
+    pyfields = [(n, {C.c_double: "double", C.c_int: "int"}[t]) for n, t in L.PtParams._fields_]
+    assert pyfields == cfields
+
+
+def test_definitions_are_swallowed_and_calls_forwarded():
+    """The two macros the scripts' kernels go through: `@parallel function …` / `@parallel_indices (…) function …` must expand
+    to nothing (their bodies use ParallelStencil macros that do not exist here), calls must be forwarded."""
+    src = shim_source()
+    assert re.search(r"_is_definition\(ex\)\s*=", src)
+    i = src.index("macro parallel(")
+    body = src[i:src.index("\nend", i)]
+    assert "_is_definition" in body and "nothing" in body
+    i = src.index("macro parallel_indices(")                      # only ever applied to definitions (multi.jl:108-281)
+    assert "nothing" in src[i:src.index("\nend", i)]
+    for name in ("init_parallel_stencil", "zeros"):
+        assert "macro %s(" % name in src
+    for fn in ("init_global_grid", "finalize_global_grid", "nx_g", "ny_g", "nz_g", "x_g", "y_g", "z_g", "update_halo!", "gather!"):
+        assert re.search(r"(function\s+%s\(|\n%s\()" % (re.escape(fn), re.escape(fn)), src), fn
