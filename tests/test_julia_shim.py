@@ -144,3 +144,42 @@ def test_definitions_are_swallowed_and_calls_forwarded():
         assert "macro %s(" % name in src
     for fn in ("init_global_grid", "finalize_global_grid", "nx_g", "ny_g", "nz_g", "x_g", "y_g", "z_g", "update_halo!", "gather!"):
         assert re.search(r"(function\s+%s\(|\n%s\()" % (re.escape(fn), re.escape(fn)), src), fn
+
+
+def shim_methods():
+    """name → list of (n_positional_min, varargs) of the shim's function definitions (long and short form)"""
+    src = shim_source()
+    out = {}
+    for m in re.finditer(r"(?:^|\n)\s*(?:function\s+)?([\w!∇τ]+)\(", src):
+        name = m.group(1)
+        start = m.end() - 1
+        end = closing(src, start)
+        after = src[end + 1:end + 40].lstrip()
+        is_long = src[m.start():m.end()].lstrip().startswith("function")
+        if not is_long and not after.startswith("="):
+            continue                                               # a call, not a definition
+        params = src[start + 1:end].split(";")[0]
+        pl = [p for p in split_top(params) if p.strip()]
+        varargs = any(p.strip().endswith("...") for p in pl)
+        out.setdefault(name, []).append((len(pl) - (1 if varargs else 0), varargs))
+    return out
+
+
+def test_the_shim_serves_every_call_site_of_the_reference_scripts():
+    """tests/golden/reference_call_sites.json (oracle/extract_call_sites.py: every `@parallel kernel!(…)` call and every
+    ImplicitGlobalGrid call of multi.jl and gpu.jl, as data) against the shim's method table: the callee exists and takes that
+    many positional arguments.  (`@parallel (ranges) f!(…)` forwards f!(…): the ranges are dropped by the macro.)"""
+    import json
+    sites = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_call_sites.json"), encoding="utf-8"))
+    meths = shim_methods()
+    assert len(sites["parallel_calls"]) >= 40 and len(sites["grid_calls"]) >= 50
+    for c in sites["parallel_calls"] + sites["grid_calls"]:
+        name, n = c["callee"], c["nargs"]
+        assert name in meths, "%s (%s:%d) has no method in the shim" % (name, c["script"], c["line"])
+        assert any((n == k and not va) or (va and n >= k) for k, va in meths[name]), (name, n, meths[name], c["script"], c["line"])
+    src = shim_source()
+    for mac in sites["macros"]:
+        if mac.startswith("@"):
+            assert "macro %s(" % mac[1:] in src, mac
+        else:
+            assert "module Data" in src and mac.split(".")[1] in src, mac
