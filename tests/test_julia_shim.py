@@ -183,3 +183,17 @@ def test_the_shim_serves_every_call_site_of_the_reference_scripts():
             assert "macro %s(" % mac[1:] in src, mac
         else:
             assert "module Data" in src and mac.split(".")[1] in src, mac
+
+
+def test_the_python_mirror_serves_the_same_call_sites():
+    """navierstokes3d_amd/kernels.py mirrors the reference's kernel names (ASCII: τ→tau, ∇V→divV, no `!`) with the same
+    positional arguments: every `@parallel kernel!(…)` call site of the two scripts binds to its mirror's signature."""
+    import inspect
+    import json
+    from navierstokes3d_amd import kernels as K
+    sites = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_call_sites.json"), encoding="utf-8"))
+    for c in sites["parallel_calls"]:
+        name = c["callee"].rstrip("!").replace("τ", "tau").replace("∇V", "divV")
+        fn = getattr(K, name, None)
+        assert fn is not None, (c["callee"], name)
+        inspect.signature(fn).bind(*([None] * c["nargs"]))           # raises TypeError when the arity does not fit
