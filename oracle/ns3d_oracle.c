@@ -10,8 +10,13 @@
  * PARITY UNPINNED: the reference is Julia + ParallelStencil/ImplicitGlobalGrid (un-vendored,
  * unpinned); no Julia exists in the build container, and the reference's single known-answer test
  * (test/test3D.jl:8-32) is stale and structurally unrunnable.  The oracle is
- * therefore pinned only by (i) an independent NumPy transcription (oracle/numpy_ref.py) that must
- * agree bit-for-bit and (ii) analytic properties (tests/test_oracle_*.py).
+ * therefore pinned by (i) an independent NumPy transcription (oracle/numpy_ref.py) that must agree
+ * bit-for-bit, (ii) analytic properties (tests/test_oracle.py) and (iii) the reference's own SOURCE
+ * TEXT evaluated mechanically (oracle/jl_eval.py: every kernel and both drivers of the two scripts,
+ * executed token by token under ParallelStencil's published macro table and ImplicitGlobalGrid's
+ * one-rank formulas; outputs in tests/golden/jl_eval_*.npz), which this file reproduces bit for bit.
+ * "Unpinned" remains true by the letter: no vector held by the reference and no run of the reference
+ * itself stands behind it — the semantics of the two un-vendored packages are stated, not executed.
  *
  * Arithmetic contract: IEEE-754, one rounding per operation, NO fused multiply-add
  * (compile with -ffp-contract=off), operation order exactly that of the Julia expressions
