@@ -661,6 +661,32 @@ def generate_driver_goldens():
     print(len(res), "arrays →", path)
 
 
+def field_digest(a):
+    """sha256 of the array's bytes in memory order of a column-major copy (what a bit-for-bit comparison needs, in 64 characters)"""
+    import hashlib
+    return hashlib.sha256(np.asfortranarray(a).tobytes(order="F")).hexdigest()
+
+
+CONFIG_A = ("multi", 63, 3)      # BASELINE configs[0]'s grid (63×38×38), the first three time steps: 37, 259, 296 PT iterations
+
+
+def generate_config_a_digest():
+    """the reference's own CPU-runnable configuration from its text (≈1–2 min of Python): digests instead of 13 MB of arrays"""
+    import json
+    script, nx, nt = CONFIG_A
+    fields, iters, errs, st = Driver(script).run(nx, nt)
+    out = {"script": script, "nx": nx, "nt": nt, "iters": iters, "errs_hex": [[float(e).hex() for e in es] for es in errs],
+           "scalars_hex": {k: float(st[k]).hex() for k in SCALARS}, "shape": {f: list(fields[_py_names(f)].shape) for f in FIELDS},
+           "sha256": {f: field_digest(fields[_py_names(f)]) for f in FIELDS},
+           "max_abs": {f: float(np.abs(fields[_py_names(f)]).max()) for f in FIELDS}}
+    path = os.path.join(ROOT, "tests", "golden", "jl_eval_config_a.json")
+    json.dump(out, open(path, "w"), indent=1, ensure_ascii=False)
+    print("config A digest →", path, iters)
+
+
 if __name__ == "__main__":
+    import sys
     generate_goldens()
     generate_driver_goldens()
+    if "--config-a" in sys.argv:
+        generate_config_a_digest()

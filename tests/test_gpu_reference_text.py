@@ -84,3 +84,21 @@ def test_drivers_equal_the_reference_drivers_evaluated_from_their_text(hip, fuse
         assert [e for es in info.errs for e in es] == gold[pre + "errs"].tolist(), pre
         for jl, name in _F2P.items():
             assert np.array_equal(hip.to_numpy(getattr(f, name)), gold[pre + "field/" + jl], equal_nan=True), pre + jl
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_config_a_equals_the_reference_text(hip, fused):
+    """run_navierstokes3D(nx=63, nt=3) — BASELINE configs[0]'s grid 63×38×38 — on the GPU against the digests of the same run
+    evaluated from multi.jl's text (tests/golden/jl_eval_config_a.json): 37, 259, 296 PT iterations, residual histories to the
+    bit, sha256 of every array the product keeps."""
+    import json
+    from oracle import jl_eval
+    from navierstokes3d_amd.driver import run_navierstokes3D
+    g = json.load(open(os.path.join(GOLD, "jl_eval_config_a.json"), encoding="utf-8"))
+    out = run_navierstokes3D(nx=g["nx"], nt=g["nt"], mode="strict", fused=fused, return_info=True)
+    info, f = out[-1], out[-1].fields
+    assert info.iters == g["iters"]
+    assert [[float(e).hex() for e in es] for es in info.errs] == g["errs_hex"]
+    for jl, name in _F2P.items():
+        a = hip.to_numpy(getattr(f, name))
+        assert list(a.shape) == g["shape"][jl] and jl_eval.field_digest(a) == g["sha256"][jl], jl

@@ -463,3 +463,23 @@ def test_driver_text_evaluation_is_reproducible_where_the_reference_is_present()
     assert set(res) == set(gold.files)
     for k, v in res.items():
         assert np.array_equal(v, gold[k], equal_nan=True), k
+
+
+def test_config_a_from_the_reference_text(oracle):
+    """BASELINE configs[0]'s grid — `run_navierstokes3D(nx=63)`, 63×38×38 — for the first three time steps (37, 259, 296 PT
+    iterations), evaluated from multi.jl's text (oracle/jl_eval.py --config-a, ≈75 s of Python; stored as sha256 digests of the
+    18 arrays plus iteration counts, residual histories and scalars in hex): the oracle driver gives the same bits."""
+    import json
+    from oracle import jl_eval
+    from oracle.driver_ref import run_navierstokes3D_ref
+    g = json.load(open(os.path.join(GOLD, "jl_eval_config_a.json"), encoding="utf-8"))
+    out = run_navierstokes3D_ref(nx=g["nx"], nt=g["nt"])
+    info, f, p = out[-1], out[-1].ranks[0], out[-1].params
+    assert info.iters == g["iters"] == [37, 259, 296]
+    assert [[float(e).hex() for e in es] for es in info.errs] == g["errs_hex"]
+    for k, v in g["scalars_hex"].items():
+        assert float(getattr(p, _S2O.get(k, k))).hex() == v, k
+    for jl, digest in g["sha256"].items():
+        a = np.asarray(f[_F2O[jl]])
+        assert list(a.shape) == g["shape"][jl] and jl_eval.field_digest(a) == digest, jl
+    assert g["max_abs"]["Pr"] > 0 and g["max_abs"]["Vx"] > 0
