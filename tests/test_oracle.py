@@ -483,3 +483,36 @@ def test_config_a_from_the_reference_text(oracle):
         a = np.asarray(f[_F2O[jl]])
         assert list(a.shape) == g["shape"][jl] and jl_eval.field_digest(a) == digest, jl
     assert g["max_abs"]["Pr"] > 0 and g["max_abs"]["Vx"] > 0
+
+
+def test_viscous_predictor_pairs_the_right_neighbours_in_all_three_directions(oracle):
+    """The cubic shear flows again, now modulated in the other two directions: u_a = s_a·s_c·s_b³ with s_a the FACE coordinate
+    along the component's own direction (index·h) and s_b, s_c cell-centre coordinates.  Analytically Δu_a = dt/ρ·μ·6·s_a·s_c·s_b
+    at the updated face's own (s_a, s_b, s_c); every term that is not ∂τ_ab/∂b cancels exactly in the stencils (τ_aa is constant
+    along a, τ_ac constant along c), so `update_τ! → predict_V!` must return exactly that — which they only do if the shear
+    stress an update reads was built from the velocities of ITS OWN face row/column/plane in all three directions (the +1
+    offsets of @d_yi/@d_zi/@d_xi against @inn and @d_ya/@d_za/@d_xa).  Dyadic data, exact to the bit."""
+    n = (7, 6, 5)
+    h, dt, rho, mu = 0.5, 0.25, 2.0, 0.5
+    z = lambda *s: np.zeros(s, order="F")
+    for a in range(3):
+        for b in range(3):
+            if a == b:
+                continue
+            c = 3 - a - b
+            ext = list(n); ext[a] += 1
+            coord = [None] * 3
+            coord[a] = np.arange(ext[a]) * h                          # faces along a
+            coord[b] = (np.arange(ext[b]) + 0.5) * h                  # centres along b and c
+            coord[c] = (np.arange(ext[c]) + 0.5) * h
+            grid = np.meshgrid(*coord, indexing="ij")
+            V = [z(n[0] + 1, n[1], n[2]), z(n[0], n[1] + 1, n[2]), z(n[0], n[1], n[2] + 1)]
+            V[a][...] = grid[a] * grid[c] * grid[b] ** 3
+            V0 = V[a].copy(order="F")
+            tau = [z(*n), z(*n), z(*n), z(n[0] - 1, n[1] - 1, n[2] - 1), z(n[0] - 1, n[1] - 1, n[2] - 1), z(n[0] - 1, n[1] - 1, n[2] - 1)]
+            oracle.update_tau(*tau, V[0], V[1], V[2], mu, h, h, h)
+            oracle.predict_V(V[0], V[1], V[2], *tau, rho, 0.0, dt, h, h, h)
+            want = (dt / rho) * mu * 6.0 * grid[a] * grid[c] * grid[b]
+            inner = (slice(1, -1),) * 3
+            assert np.array_equal((V[a] - V0)[inner], want[inner]), (a, b)
+            assert np.abs(want[inner]).min() > 0
