@@ -679,6 +679,13 @@ def generate_config_a_digest():
            "scalars_hex": {k: float(st[k]).hex() for k in SCALARS}, "shape": {f: list(fields[_py_names(f)].shape) for f in FIELDS},
            "sha256": {f: field_digest(fields[_py_names(f)]) for f in FIELDS},
            "max_abs": {f: float(np.abs(fields[_py_names(f)]).max()) for f in FIELDS}}
+    # what test/test3D.jl:12-17 samples — Pr of run_navierstokes3D(nx=63, nt=1), halo-stripped, at inds_x × inds_y × inds_z —
+    # from the committed script's own text (the fixture in that test holds 0.2 … 0.6 at its hot spot: it is stale)
+    f1, it1, _, _ = Driver(script).run(63, 1)
+    Pv = f1["Pr"][1:-1, 1:-1, 1:-1]
+    ix, iy, iz = [31, 38, 50, 51], [2, 5, 19, 31], [12, 13, 23, 23]
+    out["test3D_nt1"] = {"iters": it1, "Pr_samples": [[[float(Pv[x - 1, y - 1, z - 1]) for x in ix] for y in iy] for z in iz],
+                         "max_abs_Pr": float(np.abs(f1["Pr"]).max())}
     path = os.path.join(ROOT, "tests", "golden", "jl_eval_config_a.json")
     json.dump(out, open(path, "w"), indent=1, ensure_ascii=False)
     print("config A digest →", path, iters)

@@ -516,3 +516,21 @@ def test_viscous_predictor_pairs_the_right_neighbours_in_all_three_directions(or
             inner = (slice(1, -1),) * 3
             assert np.array_equal((V[a] - V0)[inner], want[inner]), (a, b)
             assert np.abs(want[inner]).min() > 0
+
+
+def test_the_reference_fixture_is_stale_by_the_reference_s_own_text():
+    """test/test3D.jl:12-32 samples Pr of run_navierstokes3D(nx=63, nt=1) at 4×4×4 indices and expects 0.2 … 0.6 at a hot spot.
+    The committed multi.jl, evaluated from its text (jl_eval_config_a.json → test3D_nt1), gives Pr ≡ 0 after that step (the
+    predictor is exactly divergence-free) — and so does the oracle: the fixture belongs to an earlier program."""
+    import json
+    from oracle.driver_ref import run_navierstokes3D_ref
+    sys_path_ok = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    g = json.load(open(os.path.join(GOLD, "jl_eval_config_a.json"), encoding="utf-8"))["test3D_nt1"]
+    assert g["iters"] == [37] and g["max_abs_Pr"] == 0.0 and not np.any(np.array(g["Pr_samples"]))
+    out = run_navierstokes3D_ref(nx=63, nt=1)
+    assert out[-1].iters == [37] and not np.any(out[1])
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fixture_probe", os.path.join(sys_path_ok, "fixture_probe.py"))
+    fp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fp)
+    assert fp.ref.shape == (3, 4, 4) and np.abs(fp.ref).min() > 1e-9 and fp.ref[1, 2, 0] == 0.6208831467566082
