@@ -91,7 +91,7 @@ int ns3d_set_pt2_variant(ns3d_ctx *ctx, int variant);
 /* N-iteration sweep (ns3d_pt_sweepn): variant = shape*100 + kz.  Shapes (columns per workgroup): 1: 64×32 (512 threads),
  * 2: 128×16, 3: 256×8, 4: 64×48 and 5: 128×24 (six rows per thread), 6/7/8: 64×16 / 64×20 / 64×24 with 256-thread
  * workgroups, 9: 64×32 with 256 threads (one wave per SIMD); +10: the next step's loads issued before level 1 (11 = the
- * built-in choice); +20 (21, 26): loads two steps ahead; 22: fp32 only, 64×48 with 768 threads (three waves per SIMD).
+ * built-in choice); 22: fp32 only, 64×48 with 768 threads (three waves per SIMD).
  * kz as above.  0 = built-in.  A shape that cannot hold `nlev` levels (tile too small, LDS) makes the call fail. */
 int ns3d_set_ptn_variant(ns3d_ctx *ctx, int variant);
 /* PT iterations per pass over memory in ns3d_pt_iterate / ns3d_pt_solve: 0 = automatic, 1…4 forced (same results). */

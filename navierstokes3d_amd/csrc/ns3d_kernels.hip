@@ -1779,14 +1779,14 @@ static hipError_t launch_sweep2(hipStream_t s, SweepArgs<T> &a, int kz)
 // value is computed with exactly the arithmetic of the single sweep: bit-identical to NL k_pt_sweep launches.
 // Boundary cells of P^NL: the x-face cell beside an interior cell is stored here, y/z faces by k_pt_faces_* (SEPF form).
 // =========================================================================================================
-// PF: where the loads of later steps are issued — 0: the next step's, between and after the levels; 1 (EARLY): the next
-// step's, before level 1; 2: TWO steps ahead, before level 1, through a second set of staging registers (more bytes in flight)
+// PF: where the loads of the next step are issued — 0: between and after the levels; 1 (EARLY): before level 1.  (Loads two
+// steps ahead through a second set of staging registers were measured and dropped: no gain, 16 more registers.)
 template <class T, int NL, int WX, int WY, int CPT, int PF, int MINW = 1>
 __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a, int ntx, int nty)
 {
     static_assert(NL >= 2 && NL <= 4, "levels");
-    constexpr bool EARLY = PF >= 1;
-    constexpr int AHEAD = PF == 2 ? 1 : 0;   // extra planes of look-ahead
+    static_assert(PF == 0 || PF == 1, "PF");
+    constexpr bool EARLY = PF == 1;
     constexpr int TX = 64 * WX, TY = CPT * WY, PX = TX + 2, OV = 2 * (NL - 1);
     static_assert(TX > OV + 2 && TY > OV + 2, "tile too small for this many levels");
     __shared__ T L0[2][(TY + 2) * PX];       // P⁰ plane with halo ring: element (lx+1, lr+1)
@@ -1893,22 +1893,6 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
         if (hasB) hB = Pp[offB];
         if (hasC) hC = Pp[offC];
     }
-    // PF == 2: the staging registers of the step after next (plane kfirst+2 of P⁰ and its halo ring, d⁰/∇V of plane kfirst+1)
-    T p0q[PF == 2 ? CPT : 1], d0q[PF == 2 ? CPT : 1], r0q[PF == 2 ? CPT : 1], hAq = (T)0, hBq = (T)0, hCq = (T)0;
-    if constexpr (PF == 2) {
-        const int kp = min(max(kfirst + 2, 0), nz - 1);
-        const int ka = min(max(kfirst + 1, 1), nz - 2);
-        const T *__restrict__ Pn = P + (idx_t)kp * sz;
-#pragma unroll
-        for (int r = 0; r < CPT; ++r) {
-            p0q[r] = Pn[poff[r]];
-            d0q[r] = ld_stream<T, true>(Din + (idx_t)(ka - 1) * dsz + doff[r]);
-            r0q[r] = ld_stream<T, true>(RHS + (idx_t)ka * sz + roff[r]);
-        }
-        if (hasA) hAq = Pn[offA];
-        if (hasB) hBq = Pn[offB];
-        if (hasC) hCq = Pn[offC];
-    }
     __syncthreads();
 
     const int nsteps = (ke - kb) + OV;
@@ -1918,8 +1902,8 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
         // ---------------- the loads of the next step: plane k1+2 of P⁰ (+ halo ring), d⁰/∇V of plane k1+1 ----------------
         T p0n[CPT], d0n[CPT], r0n[CPT], hAn = (T)0, hBn = (T)0, hCn = (T)0;
         auto issue_next = [&]() {
-            const int kp = min(max(k1 + 2 + AHEAD, 0), nz - 1);
-            const int ka = min(max(k1 + 1 + AHEAD, 1), nz - 2);
+            const int kp = min(max(k1 + 2, 0), nz - 1);
+            const int ka = min(max(k1 + 1, 1), nz - 2);
             const T *__restrict__ Pn = P + (idx_t)kp * sz;
 #pragma unroll
             for (int r = 0; r < CPT; ++r) {
@@ -2041,10 +2025,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
             for (int r = 0; r < CPT; ++r) {
 #pragma unroll
                 for (int l = NL - 1; l >= 1; --l) rr[l][r] = rr[l - 1][r];
-                if constexpr (PF == 2) {
-                    d0[r] = d0q[r]; d0q[r] = d0n[r];
-                    rr[0][r] = r0q[r]; r0q[r] = r0n[r];
-                } else if constexpr (EARLY) {
+                if constexpr (EARLY) {
                     d0[r] = d0n[r];
                     rr[0][r] = r0n[r];
                 } else {
@@ -2067,17 +2048,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
         if (hasC) bad |= !val_ok<T>(hC);
         if (bad) Lbad = 1;
 #endif
-        if constexpr (PF == 2) {
 #pragma unroll
-            for (int r = 0; r < CPT; ++r) { p0m[r] = p0c[r]; p0c[r] = p0p[r]; p0p[r] = p0q[r]; p0q[r] = p0n[r]; }
-            hA = hAq; hB = hBq; hC = hCq;
-            hAq = hAn; hBq = hBn; hCq = hCn;
-        } else {
-            (void)p0q; (void)d0q; (void)r0q; (void)hAq; (void)hBq; (void)hCq;
-#pragma unroll
-            for (int r = 0; r < CPT; ++r) { p0m[r] = p0c[r]; p0c[r] = p0p[r]; p0p[r] = p0n[r]; }
-            hA = hAn; hB = hBn; hC = hCn;
-        }
+        for (int r = 0; r < CPT; ++r) { p0m[r] = p0c[r]; p0c[r] = p0p[r]; p0p[r] = p0n[r]; }
+        hA = hAn; hB = hBn; hC = hCn;
         __syncthreads();
         cur ^= 1;
     }
@@ -2158,8 +2131,6 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
     case 22: if constexpr (sizeof(T) == 4) { NS3D_SWN(NLV, 1, 12, 4, true); } else return hipErrorInvalidValue; /* fp32: 64×48, 768 threads = three waves per SIMD */ \
     case 17: NS3D_SWN(NLV, 1, 4, 5, true);                                                                  \
     case 11: NS3D_SWN(NLV, 1, 8, 4, true);                                                                  \
-    case 21: NS3D_SWN(NLV, 1, 8, 4, 2);      /* +20: loads two steps ahead */                               \
-    case 26: NS3D_SWN(NLV, 1, 4, 4, 2);                                                                     \
     case 12: NS3D_SWN(NLV, 2, 4, 4, true);                                                                  \
     case 13: NS3D_SWN(NLV, 4, 2, 4, true);                                                                  \
     default: return hipErrorInvalidValue;                                                                   \
