@@ -410,7 +410,7 @@ static Plan tune_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
     // a clear per-ITERATION gain (≥ 2 %), head to head.
     const long long cells = (long long)p->nx * p->ny * nk;
     if (c->pt_depth <= 0 && cells >= NS3D_DEEP_MIN_CELLS && nk >= 12) {
-        static const int cand[] = {1100, 100, 1600, 600, 2200, 1132};   // the first one is the built-in shape: it wins near-ties
+        static const int cand[] = {1100, 2300, 100, 1600, 600, 2200, 1132};   // the first one is the built-in shape: it wins near-ties
         int bestn = c->ptn_variant;
         float best3 = 0.f, ms = 0.f;
         if (c->ptn_variant > 0) { if (!time_launch(3, bestn, best3)) best3 = 0.f; }
@@ -426,13 +426,17 @@ static Plan tune_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
                 pl.vn = bestn;
             }
         }
-        // four iterations per pass: only fp32 has the registers for it (64×48 columns with 768 threads = three waves per SIMD)
-        if (sizeof(T) == 4 && nk >= 16) {
-            static const int cand4[] = {2200, 1100};
+        // four iterations per pass: needs three waves per SIMD to pay — 768-thread workgroups of 64×48 columns (four rows per
+        // thread) in fp32, of 64×24 columns (two rows per thread: 154 registers) in fp64; 2391 = ONE round of workgroups, each
+        // marching the whole z range (no chunk overlap)
+        if (nk >= 16) {
+            static const int cand4_f32[] = {2200, 2700, 1100}, cand4_f64[] = {2300, 2391, 2800};
+            const int *cand4 = sizeof(T) == 4 ? cand4_f32 : cand4_f64;
             const float cur_per_it = pl.depth == 3 ? best3 / 3.f : ms2 / 2.f;
             int best4v = 0;
             float best4 = 0.f;
-            for (int v : cand4) {
+            for (int q4 = 0; q4 < 3; ++q4) {
+                const int v = cand4[q4];
                 if (c->ptn_variant > 0 && v != c->ptn_variant) continue;
                 if (!time_launch(4, v, ms)) continue;
                 if (best4 == 0.f || ms < 0.98f * best4) { best4 = ms; best4v = v; }
@@ -447,7 +451,7 @@ static Plan tune_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
             }
         }
     } else if (c->pt_depth >= 3 && c->ptn_variant <= 0 && cells >= NS3D_TWO_MIN_CELLS) {
-        static const int cand[] = {1100, 100, 1600, 600, 2200, 1132};
+        static const int cand[] = {1100, 2300, 2391, 100, 1600, 600, 2200, 1132};
         float bestd = 0.f, ms = 0.f;
         for (int v : cand) {
             if (!time_launch(c->pt_depth, v, ms)) continue;

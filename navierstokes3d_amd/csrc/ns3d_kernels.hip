@@ -2113,7 +2113,9 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
     a.k0 = k0; a.k1 = k1; a.kz = 1;
     if (k1 <= k0) return hipSuccess;
     int shape = variant / 100, kz = variant % 100;
-    if (variant == 0) { shape = 11; kz = 0; }     // 64×32 columns, next step's loads issued before level 1 (measured best at 512³)
+    // built-in: 64×32 columns, next step's loads issued before level 1 (measured best at 512³ for three levels); four levels
+    // want three waves per SIMD: 64×24 columns with 768 threads in fp64, 64×48 in fp32
+    if (variant == 0) { shape = nlev == 4 ? (sizeof(T) == 8 ? 23 : 22) : 11; kz = 0; }
 #define NS3D_SWN(NLV, WXV, WYV, CPTV, PFV) return launch_sweepN<T, NLV, WXV, WYV, CPTV, PFV>(s, a, kz)
 #define NS3D_SWN_SHAPES(NLV)                                                                                \
     switch (shape) {                                                                                        \
@@ -2130,6 +2132,10 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
     case 16: NS3D_SWN(NLV, 1, 4, 4, true);                                                                  \
     case 22: if constexpr (sizeof(T) == 4) { NS3D_SWN(NLV, 1, 12, 4, true); } else return hipErrorInvalidValue; /* fp32: 64×48, 768 threads = three waves per SIMD */ \
     case 17: NS3D_SWN(NLV, 1, 4, 5, true);                                                                  \
+    case 23: NS3D_SWN(NLV, 1, 12, 2, true);  /* 64×24, 768 threads, two rows per thread: three waves per SIMD */ \
+    case 24: NS3D_SWN(NLV, 1, 16, 2, true);  /* 64×32, 1024 threads: four waves per SIMD (fp64 spills 7 registers) */ \
+    case 27: NS3D_SWN(NLV, 1, 16, 3, true);  /* 64×48, 1024 threads, three rows per thread */                    \
+    case 28: NS3D_SWN(NLV, 1, 12, 2, false);                                                                     \
     case 11: NS3D_SWN(NLV, 1, 8, 4, true);                                                                  \
     case 12: NS3D_SWN(NLV, 2, 4, 4, true);                                                                  \
     case 13: NS3D_SWN(NLV, 4, 2, 4, true);                                                                  \
