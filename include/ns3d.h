@@ -78,8 +78,9 @@ void *ns3d_get_stream(ns3d_ctx *ctx);
 int ns3d_sync(ns3d_ctx *ctx);
 /* Tuning knob for the fused PT sweep (0 = default); see DESIGN.md. */
 int ns3d_set_pt_variant(ns3d_ctx *ctx, int variant);
-/* Temporal blocking: ns3d_pt_iterate / ns3d_pt_solve advance TWO PT iterations per pass over memory where the
- * schedule allows it (same results).  variant < 0 disables, 0 = automatic; otherwise shape*100 + kz with the tile
+/* Temporal blocking: ns3d_pt_iterate / ns3d_pt_solve advance SEVERAL PT iterations per pass over memory where the
+ * schedule allows it (same results): two (this knob), or three / four on large grids where the plan phase measures a gain
+ * (ns3d_set_pt_depth, ns3d_set_ptn_variant below).  variant < 0 disables, 0 = automatic; otherwise shape*100 + kz with the tile
  * shapes of DESIGN.md §4.2 and kz = planes per z-chunk (1..89 literal; 0 or 91..99: as many chunks as fill two /
  * kz-90 whole rounds of workgroups on the chip).  The environment variable NS3D_PT2_VARIANT presets it at ns3d_create. */
 int ns3d_set_pt2_variant(ns3d_ctx *ctx, int variant);
@@ -280,7 +281,7 @@ int ns3d_mgpu_sync(ns3d_mgpu *m);
 int ns3d_max_g(ns3d_mgpu *m, const double *local_max, double *out);    /* NaN-propagating */
 /* Most PT iterations a pass over memory may advance in ns3d_slab_* / ns3d_pt_solve_slab = ghost planes per seam + 1: 4 (default),
  * 3, 2 or 1 (plain one-plane halo, single sweeps).  Passes run two iterations until ns3d_slab_plan has measured whether three
- * (fp32: four) pay on this grid; every rank uses the same depth. */
+ * or four pay on this grid; every rank uses the same depth. */
 int ns3d_mgpu_set_temporal(ns3d_mgpu *m, int depth);
 int ns3d_mgpu_pass_depth(const ns3d_mgpu *m);
 /* The pseudo-transient state of a z-slab rank lives in library-owned buffers extended by the ghost planes temporal

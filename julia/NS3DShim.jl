@@ -247,7 +247,7 @@ end
 """
     pt_solve!(Pr, dPrdτ, ∇V, ρ, dt, dτ, damp, dx, dy, dz; bc_kind, owns_outlet, g, εit, niter, nchk, ly, psc) -> (iters, errs)
 
-One rank: `ns3d_pt_solve_f64` — fused sweeps (two PT iterations per pass over memory), residual check every `nchk`
+One rank: `ns3d_pt_solve_f64` — fused sweeps (two to four PT iterations per pass over memory), residual check every `nchk`
 iterations with `err = max|Rp|·ly²/psc`, exit on `err < εit || !isfinite(err)`.  `bc_kind = 0`: multi.jl's set_bc_Pr!
 (:175-181), `1`: gpu.jl's (:281-286).
 """
