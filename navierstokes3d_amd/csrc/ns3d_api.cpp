@@ -312,7 +312,7 @@ static int ensure_pingpong_d(ns3d_ctx *c, const ns3d_pt_params *p, T **buf)
 // How a pass over memory is made: PT iterations per pass (depth 2: k_pt_sweep2 with tile variant v2; 3, 4: k_pt_sweepN with
 // tile variant vn).  Explicit settings (ns3d_set_pt2_variant / _ptn_variant / _pt_depth) always win.
 struct Plan { int depth, v2, vn; bool known; };
-static const long long NS3D_DEEP_MIN_CELLS = 16ll * 1000 * 1000;    // below this three iterations per pass never paid
+static const long long NS3D_DEEP_MIN_CELLS = 8ll * 1000 * 1000;     // below this a deeper pass never paid (192³: two per pass; 256×256×128: four, +10 %)
 template <class T>
 static Plan lookup_plan(const ns3d_ctx *c, int mode, const ns3d_pt_params *p, int k0, int k1)
 {
