@@ -36,6 +36,9 @@
 namespace NS3D_NS {
 
 typedef long long idx_t;
+#ifndef NS3D_STEP_UNROLL
+#define NS3D_STEP_UNROLL 0      // 0: chosen per tile shape (k_pt_sweepN); 1, 2, 4: forced, for A/B builds
+#endif
 #define IX3(i, j, k, sx, sy) ((idx_t)(i) + (idx_t)(sx) * ((idx_t)(j) + (idx_t)(sy) * (idx_t)(k)))
 
 // Grid spacings.  STRICT divides (x/dx, x/dx/dx) exactly like the Julia expressions; FAST multiplies by
@@ -1897,7 +1900,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
 
     const int nsteps = (ke - kb) + OV;
     int cur = 0;
-    for (int s = 0; s < nsteps; ++s) {
+    auto step = [&](const int s) __attribute__((always_inline)) {
         const int k1 = kfirst + s;
         // ---------------- the loads of the next step: plane k1+2 of P⁰ (+ halo ring), d⁰/∇V of plane k1+1 ----------------
         T p0n[CPT], d0n[CPT], r0n[CPT], hAn = (T)0, hBn = (T)0, hCn = (T)0;
@@ -2053,7 +2056,22 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
         hA = hAn; hB = hBn; hC = hCn;
         __syncthreads();
         cur ^= 1;
+    };
+    // The z rings rotate every step (≈ 16 register-pair moves per row, a quarter of a step's vector instructions); with the
+    // body repeated UNR times per trip the copies inside a trip are renamed away and only the back edge shuffles: +4…7 % at
+    // 512³ (profiles/r2_step_unroll_ab.log).  The compiler does not unroll a loop with a barrier and a run-time trip count by
+    // itself, so the repetition is written out; four copies for the two-rows-per-thread shapes (two spilled registers), two for
+    // the four-row 512-thread ones, none where three or more rows per thread already fill the register budget of a 768- or
+    // 1024-thread workgroup (fp32 64×48: 34 registers would spill).
+    constexpr int UNR = NS3D_STEP_UNROLL > 0 ? NS3D_STEP_UNROLL : ((WX * WY >= 12 && CPT >= 3) ? 1 : (CPT <= 2 ? 4 : 2));
+    int s = 0;
+    if constexpr (UNR > 1) {
+        for (; s + UNR <= nsteps; s += UNR) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) step(s + u);
+        }
     }
+    for (; s < nsteps; ++s) step(s);
 }
 
 template <class T, int NL, int WX, int WY, int CPT, int PF, int MINW = 1>

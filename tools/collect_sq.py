@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--runs", default="2:1392", help="depth:variant[,depth:variant…]")
     ap.add_argument("--modes", default="strict,fast")
     ap.add_argument("--dtype", default="f64")
+    ap.add_argument("--grid", default="512")
     a = ap.parse_args()
     res = {}
     for mode, run in [(m, r) for m in a.modes.split(",") for r in a.runs.split(",")]:
@@ -33,7 +34,7 @@ def main():
         shutil.rmtree(wd, ignore_errors=True)
         cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + COUNTERS + ["-f", "csv", "-d", wd, "-o", "p", "--", sys.executable,
                os.path.join(ROOT, "bench.py"), "--steps", str(8 * int(depth)), "--warmup", depth, "--no-cpu-baseline", "--mode", mode,
-               "--dtype", a.dtype, "--depth", depth, "--variant2" if depth == "2" else "--variantn", variant]
+               "--dtype", a.dtype, "--grid", a.grid, "--depth", depth, "--variant2" if depth == "2" else "--variantn", variant]
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
         acc = {}
         for f in glob.glob(os.path.join(wd, "**", "*counter_collection.csv"), recursive=True):
