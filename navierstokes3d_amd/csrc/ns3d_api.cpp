@@ -430,13 +430,14 @@ static Plan tune_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
         // thread) in fp32, of 64×24 columns (two rows per thread: 154 registers) in fp64; 2391 = ONE round of workgroups, each
         // marching the whole z range (no chunk overlap)
         if (nk >= 16) {
-            static const int cand4_f32[] = {2200, 2700, 1100}, cand4_f64[] = {2300, 2391, 2800};
+            static const int cand4_f32[] = {2200, 2700, 1100, 0}, cand4_f64[] = {2300, 2391, 2800, 2891};
             const int *cand4 = sizeof(T) == 4 ? cand4_f32 : cand4_f64;
             const float cur_per_it = pl.depth == 3 ? best3 / 3.f : ms2 / 2.f;
             int best4v = 0;
             float best4 = 0.f;
-            for (int q4 = 0; q4 < 3; ++q4) {
+            for (int q4 = 0; q4 < 4; ++q4) {
                 const int v = cand4[q4];
+                if (v == 0) continue;
                 if (c->ptn_variant > 0 && v != c->ptn_variant) continue;
                 if (!time_launch(4, v, ms)) continue;
                 if (best4 == 0.f || ms < 0.98f * best4) { best4 = ms; best4v = v; }
@@ -451,7 +452,7 @@ static Plan tune_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
             }
         }
     } else if (c->pt_depth >= 3 && c->ptn_variant <= 0 && cells >= NS3D_TWO_MIN_CELLS) {
-        static const int cand[] = {1100, 2300, 2391, 100, 1600, 600, 2200, 1132};
+        static const int cand[] = {1100, 2300, 2391, 2800, 2891, 100, 1600, 600, 2200, 1132};
         float bestd = 0.f, ms = 0.f;
         for (int v : cand) {
             if (!time_launch(c->pt_depth, v, ms)) continue;

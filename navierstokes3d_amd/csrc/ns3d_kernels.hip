@@ -1492,7 +1492,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
 
     const int nsteps = (ke - kb) + 2;
     int cur = 0;
-    for (int s = 0; s < nsteps; ++s) {
+    auto step = [&](const int s) __attribute__((always_inline)) {
         const int k1 = kb - 1 + s, k2 = k1 - 1;
         const T *__restrict__ l0 = L0[cur];
         const T *__restrict__ l1 = L1[cur];
@@ -1650,7 +1650,18 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
         hA = hAn; hB = hBn; hC = hCn;
         __syncthreads();
         cur ^= 1;
+    };
+    // the step body written out four times per trip for the two-rows-per-thread shapes (see k_pt_sweepN: the ring rotations
+    // inside a trip are renamed away); the four- and six-row shapes have no registers to spare for it
+    constexpr int UNR = NS3D_STEP_UNROLL > 0 ? NS3D_STEP_UNROLL : (CPT <= 2 ? 4 : 1);
+    int s = 0;
+    if constexpr (UNR > 1) {
+        for (; s + UNR <= nsteps; s += UNR) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) step(s + u);
+        }
     }
+    for (; s < nsteps; ++s) step(s);
 }
 
 // ---- y- and z-face cells of P² as separate launches (used with the SEPF form of k_pt_sweep2) ----------------------
@@ -2063,6 +2074,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
     // itself, so the repetition is written out; four copies for the two-rows-per-thread shapes (two spilled registers), two for
     // the four-row 512-thread ones, none where three or more rows per thread already fill the register budget of a 768- or
     // 1024-thread workgroup (fp32 64×48: 34 registers would spill).
+    // (4 is as good as 6 or 12; an ODD count is 15–35 % slower: the LDS double-buffer parity stops being a compile-time fact)
     constexpr int UNR = NS3D_STEP_UNROLL > 0 ? NS3D_STEP_UNROLL : ((WX * WY >= 12 && CPT >= 3) ? 1 : (CPT <= 2 ? 4 : 2));
     int s = 0;
     if constexpr (UNR > 1) {
