@@ -1911,7 +1911,10 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
 
     const int nsteps = (ke - kb) + OV;
     int cur = 0;
-    auto step = [&](const int s) __attribute__((always_inline)) {
+    // EDGE steps: the pipeline is still filling (s < 2(ℓ−1) for some level) or some level's plane touches a z face of the domain
+    // (the boundary rule replaces the neighbour beyond it); everywhere else — the bulk of a chunk — neither test is compiled in
+    auto step = [&](const int s, auto edge_tag) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
         const int k1 = kfirst + s;
         // ---------------- the loads of the next step: plane k1+2 of P⁰ (+ halo ring), d⁰/∇V of plane k1+1 ----------------
         T p0n[CPT], d0n[CPT], r0n[CPT], hAn = (T)0, hBn = (T)0, hCn = (T)0;
@@ -1974,9 +1977,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
             slow = slow || (__builtin_amdgcn_ballot_w64(bad) != 0);
 #endif
             T out_p[CPT], out_d[CPT];
-            if (s >= 2 * (l - 1)) {
+            if (!EDGE || s >= 2 * (l - 1)) {
                 const T *__restrict__ ll = LN[l - 2][cur];
-                const bool zlo = (kl == 1), zhi = (kl == nz - 2);
+                const bool zlo = EDGE && (kl == 1), zhi = EDGE && (kl == nz - 2);
                 auto level = [&](auto slow_tag) {
 #pragma unroll
                     for (int r = 0; r < CPT; ++r) {
@@ -1993,8 +1996,10 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
                             if (gjf == 1) sv = c;
                             if (gjf == ny - 2) nv = c;
                         }
-                        if (zlo) bv = c;
-                        if (zhi) tv = c;
+                        if constexpr (EDGE) {
+                            if (zlo) bv = c;
+                            if (zhi) tv = c;
+                        }
                         const T res = decltype(slow_tag)::value
                                           ? poisson_rhs_slow<T>(c, w, e, sv, nv, bv, tv, rr[l - 1][r], a.rho_dt, g)
                                           : poisson_rhs_nochk<T>(c, w, e, sv, nv, bv, tv, rr[l - 1][r], a.rho_dt, g);
@@ -2078,12 +2083,24 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
     constexpr int UNR = NS3D_STEP_UNROLL > 0 ? NS3D_STEP_UNROLL : ((WX * WY >= 12 && CPT >= 3) ? 1 : (CPT <= 2 ? 4 : 2));
     int s = 0;
     if constexpr (UNR > 1) {
-        for (; s + UNR <= nsteps; s += UNR) {
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) step(s + u);
+        // bulk steps [hot_lo, hot_hi): every level active, planes 2 … nz−3 for the levels that substitute z faces (ℓ ≥ 2)
+        const int hot_lo = max(OV, NL + 1 - kfirst), hot_hi = min(nsteps, nz - 1 - kfirst);
+        const int h0 = min(nsteps, (hot_lo + 1) & ~1);          // an EVEN number of edge steps first: the double-buffer parity
+        for (; s + 2 <= h0; s += 2) {                           // is back at 0 after every trip of every loop here
+            step(s, std::true_type{});
+            step(s + 1, std::true_type{});
         }
+        if (s == h0)
+            for (; s + UNR <= hot_hi; s += UNR) {
+#pragma unroll
+#ifdef NS3D_NO_EDGE_SPLIT      // A/B: the general step form in the bulk loop as well
+                for (int u = 0; u < UNR; ++u) step(s + u, std::true_type{});
+#else
+                for (int u = 0; u < UNR; ++u) step(s + u, std::false_type{});
+#endif
+            }
     }
-    for (; s < nsteps; ++s) step(s);
+    for (; s < nsteps; ++s) step(s, std::true_type{});
 }
 
 template <class T, int NL, int WX, int WY, int CPT, int PF, int MINW = 1>
