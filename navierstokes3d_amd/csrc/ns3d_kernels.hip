@@ -1492,7 +1492,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
 
     const int nsteps = (ke - kb) + 2;
     int cur = 0;
-    auto step = [&](const int s) __attribute__((always_inline)) {
+    // EDGE steps: level 2 not yet active (s < 2) or its plane next to a z face; the bulk steps compile neither test in
+    auto step = [&](const int s, auto edge_tag) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
         const int k1 = kb - 1 + s, k2 = k1 - 1;
         const T *__restrict__ l0 = L0[cur];
         const T *__restrict__ l1 = L1[cur];
@@ -1554,8 +1556,8 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
 #endif
         if constexpr (!EARLY) issue_next();
         // ---------------- level 2 at plane k2 ----------------
-        if (s >= 2) {
-            const bool zlo = (k2 == 1), zhi = (k2 == nz - 2);
+        if (!EDGE || s >= 2) {
+            const bool zlo = EDGE && (k2 == 1), zhi = EDGE && (k2 == nz - 2);
             const bool plain_k = !(zlo || zhi);
             T *__restrict__ Dk = D + (idx_t)(k2 - 1) * dsz;
             auto level2 = [&](auto slow_tag) {
@@ -1576,8 +1578,10 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
                     if (gjf == 1) sv = c;
                     if (gjf == ny - 2) nv = c;
                 }
-                if (zlo) bv = c;
-                if (zhi) tv = c;
+                if constexpr (EDGE) {
+                    if (zlo) bv = c;
+                    if (zhi) tv = c;
+                }
                 const T res = decltype(slow_tag)::value
                                   ? poisson_rhs_slow<T>(c, w, e, sv, nv, bv, tv, r1c[r], a.rho_dt, g)
                                   : poisson_rhs_nochk<T>(c, w, e, sv, nv, bv, tv, r1c[r], a.rho_dt, g);
@@ -1656,12 +1660,19 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
     constexpr int UNR = NS3D_STEP_UNROLL > 0 ? NS3D_STEP_UNROLL : (CPT <= 2 ? 4 : 1);
     int s = 0;
     if constexpr (UNR > 1) {
-        for (; s + UNR <= nsteps; s += UNR) {
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) step(s + u);
+        const int hot_lo = max(2, 4 - kb), hot_hi = min(nsteps, nz - kb);       // bulk: s ≥ 2 and plane k2 = kb−2+s in [2, nz−3]
+        const int h0 = min(nsteps, (hot_lo + 1) & ~1);                          // an even number of edge steps first (parity)
+        for (; s + 2 <= h0; s += 2) {
+            step(s, std::true_type{});
+            step(s + 1, std::true_type{});
         }
+        if (s == h0)
+            for (; s + UNR <= hot_hi; s += UNR) {
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) step(s + u, std::false_type{});
+            }
     }
-    for (; s < nsteps; ++s) step(s);
+    for (; s < nsteps; ++s) step(s, std::true_type{});
 }
 
 // ---- y- and z-face cells of P² as separate launches (used with the SEPF form of k_pt_sweep2) ----------------------

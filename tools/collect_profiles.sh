@@ -24,8 +24,8 @@ rm -rf /tmp/ns3d_kt; rocprofv3 --kernel-trace --stats -f csv -d /tmp/ns3d_kt -o 
 f=$(find /tmp/ns3d_kt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/${TAG}_kernel_stats_fast_512.csv
 rm -rf /tmp/ns3d_kt; rocprofv3 --kernel-trace --stats -f csv -d /tmp/ns3d_kt -o kt -- python3 bench.py --no-cpu-baseline --dtype f32 > $O/${TAG}_bench_under_rocprof_f32.json 2>> $O/${TAG}_rocprof.err
 f=$(find /tmp/ns3d_kt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/${TAG}_kernel_stats_f32_512.csv
-python3 tools/collect_sq.py --out $O/${TAG}_pmc_sq_512.json --runs 4:2300,3:1100,2:1392 --modes strict,fast 2>&1 | tail -4
-python3 tools/collect_traffic.py --out $O/${TAG}_traffic_512.json --runs 4:2300,4:2391,4:2800,3:1100,2:1392 --modes strict,fast 2>&1 | tail -4
+python3 tools/collect_sq.py --out $O/${TAG}_pmc_sq_512.json --runs 4:2891,4:2300,3:1100,2:1392 --modes strict,fast 2>&1 | tail -4
+python3 tools/collect_traffic.py --out $O/${TAG}_traffic_512.json --runs 4:2300,4:2391,4:2800,4:2891,3:1100,2:1392 --modes strict,fast 2>&1 | tail -4
 python3 tools/collect_traffic.py --out $O/${TAG}_traffic_512_f32.json --runs 4:2200,3:100,2:1100 --modes strict --dtype f32 2>&1 | tail -3
 python3 tools/kernel_rates.py > $O/${TAG}_kernel_rates_512.jsonl 2>/dev/null; grep -c kernel $O/${TAG}_kernel_rates_512.jsonl
 python3 tools/run_config.py --script multi --nx 63 --nt 20 > $O/${TAG}_config_a_63x38x38.json 2>/dev/null; tail -c 300 $O/${TAG}_config_a_63x38x38.json; echo
