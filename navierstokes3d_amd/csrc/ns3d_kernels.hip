@@ -2121,10 +2121,25 @@ static hipError_t launch_sweepN(hipStream_t s, SweepArgs<T> &a, int kz)
     } else {
     const int nk = a.k1 - a.k0;
     const int ntx = max(1, (a.nx - 2 - OV + (TX - OV) - 1) / (TX - OV)), nty = max(1, (a.ny - 2 - OV + (TY - OV) - 1) / (TY - OV));
-    if (kz <= 0 || kz > 90) {
+    if (kz <= 0) {
+        // chunks per tile column that minimise the z-steps the slowest CU marches: rounds of workgroups × (planes per chunk + the
+        // 2(NL−1) steps a chunk spends filling its pipeline) — the tail round of an unlucky tile count (1024²: 1026 tiles on 256
+        // CUs) costs a whole chunk, so such grids want shorter chunks
         static const int per_cu = workgroups_per_cu((const void *)k_pt_sweepN<T, NL, WX, WY, CPT, PF, MINW>, 64 * WX * WY);
         const long slots = (long)device_cus() * per_cu, tiles = (long)ntx * nty;
-        const int want = kz > 90 ? kz - 90 : 2;
+        const int cmax = max(1, nk / (6 * NL));
+        long best_c = 1, best_cost = -1;
+        for (long c = 1; c <= cmax && c <= 64; ++c) {
+            const int kzc = (int)((nk + c - 1) / c);
+            const long wgs = tiles * ((nk + kzc - 1) / kzc);
+            const long cost = ((wgs + slots - 1) / slots) * (kzc + OV);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_c = c; }
+        }
+        kz = (int)((nk + best_c - 1) / best_c);
+    } else if (kz > 90) {
+        static const int per_cu = workgroups_per_cu((const void *)k_pt_sweepN<T, NL, WX, WY, CPT, PF, MINW>, 64 * WX * WY);
+        const long slots = (long)device_cus() * per_cu, tiles = (long)ntx * nty;
+        const int want = kz - 90;
         const int cmax = max(1, nk / (6 * NL));              // short chunks are mostly pipeline fill (2(NL−1) steps each)
         long best_c = 1;
         double best_fill = 0.0;
