@@ -430,7 +430,7 @@ static Plan tune_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
         // (two rows per thread: 154 registers), in fp32 1024-thread workgroups of 64×32 columns (two rows per thread, ≤ 128
         // registers) or 768 threads on 64×48; 2391 / 2891 = ONE round of workgroups, each marching the whole z range
         if (nk >= 16) {
-            static const int cand4_f32[] = {2400, 2200, 2700, 1100}, cand4_f64[] = {2300, 2391, 2800, 2891};
+            static const int cand4_f32[] = {2400, 2200, 2700, 1100}, cand4_f64[] = {2800, 2891, 2300, 2391};
             const int *cand4 = sizeof(T) == 4 ? cand4_f32 : cand4_f64;
             const float cur_per_it = pl.depth == 3 ? best3 / 3.f : ms2 / 2.f;
             int best4v = 0;

@@ -2184,8 +2184,9 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
     if (k1 <= k0) return hipSuccess;
     int shape = variant / 100, kz = variant % 100;
     // built-in: 64×32 columns, next step's loads issued before level 1 (measured best at 512³ for three levels); four levels
-    // want three or four waves per SIMD: 64×24 columns with 768 threads in fp64, 64×32 with 1024 threads in fp32
-    if (variant == 0) { shape = nlev == 4 ? (sizeof(T) == 8 ? 23 : 24) : 11; kz = 0; }
+    // want three or four waves per SIMD: 64×24 columns with 768 threads in fp64 (loads between the levels: measured best once the
+    // steps were written out), 64×32 with 1024 threads in fp32
+    if (variant == 0) { shape = nlev == 4 ? (sizeof(T) == 8 ? 28 : 24) : 11; kz = 0; }
 #define NS3D_SWN(NLV, WXV, WYV, CPTV, PFV) return launch_sweepN<T, NLV, WXV, WYV, CPTV, PFV>(s, a, kz)
 #define NS3D_SWN_SHAPES(NLV)                                                                                \
     switch (shape) {                                                                                        \
