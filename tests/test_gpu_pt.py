@@ -680,3 +680,38 @@ def test_grids_beyond_32_bit_indexing(hip, oracle, dtype, shape):
     if free < need:
         pytest.skip("needs %.0f GB of free device memory, %.0f GB available" % (need / 1e9, free / 1e9))
     _full_size_properties(hip, oracle, shape, dtype, slab_at=shape[2] - 24)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("grid", [(300, 200, 150), (257, 255, 131), (513, 511, 66), (190, 770, 75)])
+def test_planned_passes_on_odd_large_grids(hip, grid, dtype):
+    """Grids of 8–20 M cells with extents that divide no tile stride: ns3d_pt_iterate plans by itself (two-, three- and
+    four-iteration candidates, one-round and chunked variants), and its 13 iterations — three passes of four and a single sweep, or
+    whatever it chose — equal 13 launches of the one-thread-per-cell sweep bit for bit on the whole grid (compared on the device)."""
+    import torch
+    nx, ny, nz = grid
+    g = geometry(nx, ny, nz)
+    g["dx"], g["dy"], g["dz"] = 2.0 ** -8, 2.0 ** -7, 2.0 ** -8            # power-of-two spacings: the deep plans are candidates
+    tdt, bits = (torch.float64, torch.int64) if dtype == "f64" else (torch.float32, torch.int32)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(77)
+
+    def rnd_dev(*shape):
+        t = hip.zeros(shape, tdt)
+        t.permute(2, 1, 0).uniform_(-1.0, 1.0, generator=gen)
+        return t
+
+    P0, D0, R = rnd_dev(nx, ny, nz), rnd_dev(nx - 2, ny - 2, nz - 2), rnd_dev(nx, ny, nz)
+    ctx = hip.Context(0, "strict")
+    p = _params(hip, P0, g, 0, True, 0.5)
+    Pa, Da = hip.clone(P0), hip.clone(D0)
+    hip.pt_iterate(Pa, Da, R, p, 13, ctx=ctx)
+    depth = ctx.last_pt_depth()
+    ctx.set_pt_variant(100)
+    Pb, Pc, Db = hip.clone(P0), hip.zeros((nx, ny, nz), tdt), hip.clone(D0)
+    for _ in range(13):
+        hip.pt_sweep(Pb, Pc, Db, R, p, 1, nz - 1, ctx=ctx)
+        Pb, Pc = Pc, Pb
+    torch.cuda.synchronize()
+    assert depth in (2, 3, 4)
+    assert torch.equal(Pa.view(bits), Pb.view(bits)) and torch.equal(Da.view(bits), Db.view(bits)), (grid, dtype, depth)
+    ctx.close()
