@@ -89,11 +89,11 @@ int ns3d_set_pt2_variant(ns3d_ctx *ctx, int variant);
  * every shape gives the same bits) and the process remembers the winner per device and grid; that first call therefore
  * synchronises the stream.  Off: a built-in choice by grid size.  ns3d_last_pt2_variant: the variant of the latest two-iteration launch
  * (0 = built-in choice). */
-/* N-iteration sweep (ns3d_pt_sweepn): variant = shape*100 + kz.  Shapes (columns per workgroup): 1: 64×32 (512 threads),
- * 2: 128×16, 3: 256×8, 4: 64×48 and 5: 128×24 (six rows per thread), 6/7/8: 64×16 / 64×20 / 64×24 with 256-thread
- * workgroups, 9: 64×32 with 256 threads (one wave per SIMD); +10: the next step's loads issued before level 1 (11 = the
- * built-in choice); 22: fp32 only, 64×48 with 768 threads (three waves per SIMD).
- * kz as above.  0 = built-in.  A shape that cannot hold `nlev` levels (tile too small, LDS) makes the call fail. */
+/* N-iteration sweep (ns3d_pt_sweepn): variant = shape*100 + kz.  Shapes (columns per workgroup): 1: 64×32 (512 threads, four
+ * rows per thread), 2: 128×16, 6: 64×16 with 256-thread workgroups; +10 (11, 12, 16): the next step's loads issued before level 1;
+ * 22: fp32 only, 64×48 with 768 threads; 23 / 28: 64×24 with 768 threads and two rows per thread (three waves per SIMD; loads
+ * before level 1 / between the levels); 24: fp32 only, 64×32 with 1024 threads.  kz as above (0: chosen per launch).  0 = built-in.
+ * A shape that cannot hold `nlev` levels (tile too small, LDS) or does not exist for the element type makes the call fail. */
 int ns3d_set_ptn_variant(ns3d_ctx *ctx, int variant);
 /* PT iterations per pass over memory in ns3d_pt_iterate / ns3d_pt_solve: 0 = automatic, 1…4 forced (same results). */
 int ns3d_set_pt_depth(ns3d_ctx *ctx, int depth);

@@ -410,7 +410,7 @@ static Plan tune_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
     // a clear per-ITERATION gain (≥ 2 %), head to head.
     const long long cells = (long long)p->nx * p->ny * nk;
     if (c->pt_depth <= 0 && cells >= NS3D_DEEP_MIN_CELLS && nk >= 12) {
-        static const int cand[] = {1100, 2300, 100, 1600, 600, 2200, 1132};   // the first one is the built-in shape: it wins near-ties
+        static const int cand[] = {1100, 2800, 2300, 100, 1600, 600, 2200, 1132};   // the first one is the built-in shape: it wins near-ties
         int bestn = c->ptn_variant;
         float best3 = 0.f, ms = 0.f;
         if (c->ptn_variant > 0) { if (!time_launch(3, bestn, best3)) best3 = 0.f; }
@@ -430,7 +430,7 @@ static Plan tune_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
         // (two rows per thread: 154 registers), in fp32 1024-thread workgroups of 64×32 columns (two rows per thread, ≤ 128
         // registers) or 768 threads on 64×48; 2391 / 2891 = ONE round of workgroups, each marching the whole z range
         if (nk >= 16) {
-            static const int cand4_f32[] = {2400, 2200, 2700, 1100}, cand4_f64[] = {2800, 2891, 2300, 2391};
+            static const int cand4_f32[] = {2400, 2200, 1100, 0}, cand4_f64[] = {2800, 2891, 2300, 2391};
             const int *cand4 = sizeof(T) == 4 ? cand4_f32 : cand4_f64;
             const float cur_per_it = pl.depth == 3 ? best3 / 3.f : ms2 / 2.f;
             int best4v = 0;

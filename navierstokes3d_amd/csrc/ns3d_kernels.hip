@@ -2165,10 +2165,11 @@ static hipError_t launch_sweepN(hipStream_t s, SweepArgs<T> &a, int kz)
 }
 
 // `nlev` fused PT iterations (Pin,Din) → (Pout,Dout) for the output planes [k0,k1).  variant = shape*100 + kz:
-// shape 1: 64×32 columns (one wave wide, 8 high, 4 rows per thread), 2: 128×16, 3: 256×8, 4: 64×48 (6 rows per thread),
-// 5: 128×24, 6/7/8: 64×16 / 64×20 / 64×24 with 256-thread workgroups (several per CU), 9: 64×32 with 256 threads (one wave
-// per SIMD, 8 rows per thread; measured slower: 0.58 against 0.45 ms per iteration at 512³); +10: loads of the next step issued
-// before level 1 (EARLY); kz as in pt_sweep2.  0 = built-in choice.
+// shape 1: 64×32 columns (one wave wide, 8 high, 4 rows per thread), 2: 128×16, 6: 64×16 with 256-thread workgroups (two per
+// CU); +10: loads of the next step issued before level 1 (EARLY); 22: fp32 64×48 with 768 threads; 23 / 28 (EARLY / not): 64×24
+// with 768 threads and two rows per thread; 24: fp32 64×32 with 1024 threads; kz: planes per z-chunk, 0 = chosen by
+// launch_sweepN, 91…99 = as many chunks as fill kz−90 rounds.  0 = built-in choice.  (Shapes that lost every A/B — 256×8, six
+// rows per thread, one wave per SIMD, 64×20/64×24 with 256 threads, 64×48 with 1024 — are no longer instantiated.)
 template <class T>
 hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout, const T *Din, T *Dout, const T *RHS,
                      const ns3d_pt_params &p, int k0, int k1)
@@ -2192,24 +2193,14 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
     switch (shape) {                                                                                        \
     case 1: NS3D_SWN(NLV, 1, 8, 4, false);                                                                  \
     case 2: NS3D_SWN(NLV, 2, 4, 4, false);                                                                  \
-    case 3: NS3D_SWN(NLV, 4, 2, 4, false);                                                                  \
-    case 4: NS3D_SWN(NLV, 1, 8, 6, false);                                                                  \
-    case 5: NS3D_SWN(NLV, 2, 4, 6, false);                                                                  \
     case 6: NS3D_SWN(NLV, 1, 4, 4, false);   /* 256-thread workgroups: two (or three) per CU */             \
-    case 7: NS3D_SWN(NLV, 1, 4, 5, false);                                                                  \
-    case 8: NS3D_SWN(NLV, 1, 4, 6, false);                                                                  \
-    case 9: NS3D_SWN(NLV, 1, 4, 8, false);   /* one wave per SIMD, up to 512 registers: 64×32 */            \
-    case 19: NS3D_SWN(NLV, 1, 4, 8, true);                                                                  \
     case 16: NS3D_SWN(NLV, 1, 4, 4, true);                                                                  \
     case 22: if constexpr (sizeof(T) == 4) { NS3D_SWN(NLV, 1, 12, 4, true); } else return hipErrorInvalidValue; /* fp32: 64×48, 768 threads = three waves per SIMD */ \
-    case 17: NS3D_SWN(NLV, 1, 4, 5, true);                                                                  \
     case 23: NS3D_SWN(NLV, 1, 12, 2, true);  /* 64×24, 768 threads, two rows per thread: three waves per SIMD */ \
-    case 24: NS3D_SWN(NLV, 1, 16, 2, true);  /* 64×32, 1024 threads: four waves per SIMD (fp64 spills 7 registers) */ \
-    case 27: NS3D_SWN(NLV, 1, 16, 3, true);  /* 64×48, 1024 threads, three rows per thread */                    \
+    case 24: if constexpr (sizeof(T) == 4) { NS3D_SWN(NLV, 1, 16, 2, true); } else return hipErrorInvalidValue; /* fp32: 64×32, 1024 threads = four waves per SIMD (fp64 would spill) */ \
     case 28: NS3D_SWN(NLV, 1, 12, 2, false);                                                                     \
     case 11: NS3D_SWN(NLV, 1, 8, 4, true);                                                                  \
     case 12: NS3D_SWN(NLV, 2, 4, 4, true);                                                                  \
-    case 13: NS3D_SWN(NLV, 4, 2, 4, true);                                                                  \
     default: return hipErrorInvalidValue;                                                                   \
     }
     switch (nlev) {

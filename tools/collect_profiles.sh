@@ -26,7 +26,7 @@ rm -rf /tmp/ns3d_kt; rocprofv3 --kernel-trace --stats -f csv -d /tmp/ns3d_kt -o 
 f=$(find /tmp/ns3d_kt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/${TAG}_kernel_stats_f32_512.csv
 python3 tools/collect_sq.py --out $O/${TAG}_pmc_sq_512.json --runs 4:2891,4:2300,3:1100,2:1392 --modes strict,fast 2>&1 | tail -4
 python3 tools/collect_traffic.py --out $O/${TAG}_traffic_512.json --runs 4:2300,4:2391,4:2800,4:2891,3:1100,2:1392 --modes strict,fast 2>&1 | tail -4
-python3 tools/collect_traffic.py --out $O/${TAG}_traffic_512_f32.json --runs 4:2200,3:100,2:1100 --modes strict --dtype f32 2>&1 | tail -3
+python3 tools/collect_traffic.py --out $O/${TAG}_traffic_512_f32.json --runs 4:2400,4:2200,3:100,2:1100 --modes strict --dtype f32 2>&1 | tail -3
 python3 tools/kernel_rates.py > $O/${TAG}_kernel_rates_512.jsonl 2>/dev/null; grep -c kernel $O/${TAG}_kernel_rates_512.jsonl
 python3 tools/run_config.py --script multi --nx 63 --nt 20 > $O/${TAG}_config_a_63x38x38.json 2>/dev/null; tail -c 300 $O/${TAG}_config_a_63x38x38.json; echo
 python3 tools/run_config.py --script multi --nx 255 --nt 3 --compare-fast > $O/${TAG}_config_b_multi_255x153x153.json 2>/dev/null; tail -c 300 $O/${TAG}_config_b_multi_255x153x153.json; echo
