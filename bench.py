@@ -7,13 +7,19 @@
 
 Metric (BASELINE.json): Mcells·PT-iter/s (+ achieved HBM GB/s) on the 512³ lid-driven-cavity Poisson-only
 configuration (BASELINE.json configs[2]; synthetic, SURVEY.md §8d Config 3).  One "step" = one PT iteration
-{update_dPrdτ!; update_Pr!; set_bc_Pr!} (multi.jl:459-463) over the whole grid; the K timed steps are issued as K/2
-launches of the two-iteration kernel k_pt_sweep2 (one single-iteration launch more when K is odd).  Fields are resident
-in HBM before the timed region; an untimed plan phase before the warm-up lets the library time its tile shapes once.
+{update_dPrdτ!; update_Pr!; set_bc_Pr!} (multi.jl:459-463) over the whole grid; the K timed steps are issued as passes
+of the planned depth (two, three or four iterations per launch of k_pt_sweep2 / k_pt_sweepN; single sweeps for a
+remainder).  Fields are resident in HBM before the timed region; an untimed plan phase before the warm-up lets the
+library time its tile shapes once.  After the timed region every line CERTIFIES ITSELF (config.verified, untimed): one
+more pass of exactly the timed kernel instance — same depth, same tile variant, same arithmetic build — from the state
+the run left behind is compared on the device, bit for bit in STRICT mode (FAST: relative L2 ≤ 1e-6), with as many one-thread-per-cell single sweeps
+(N>1: one pass of the slab schedule against {single sweep; update_halo!(Pr)} per iteration, multi.jl:459-463); a mismatch
+prints verified: false and exits with status 3.
 For N>1 every rank owns one 512×512×512 z-slab of an implicit global grid 512×512×(N·510+2) (weak scaling, the
-reference's own model: local size fixed, multi.jl:325,338); per two iterations two planes of Pr and one of dPrdτ travel
-to each z neighbour behind the interior sweep — by RCCL send/recv over xGMI inside libns3d.so (ns3d_mgpu_create_rank,
-ns3d_slab_iterate).  `python bench.py --gpus N` without a launcher starts its N ranks itself (torch.distributed.run as a
+reference's own model: local size fixed, multi.jl:325,338); per pass the `depth` outermost own planes of Pr and depth−1
+of dPrdτ travel to each z neighbour behind the interior sweep — by RCCL send/recv over xGMI inside libns3d.so
+(ns3d_mgpu_create_rank, ns3d_slab_iterate).  The same line carries a `strong` object: the same GLOBAL grid (BASELINE:
+"512³ grid, 1/2/4/8 MI355X") split into N z-slabs, measured right after the weak run with the same K and W.  `python bench.py --gpus N` without a launcher starts its N ranks itself (torch.distributed.run as a
 child process, before this process touches the GPU).  The ranks agree COLLECTIVELY on the transport: a gloo group comes up
 first (control plane: unique id, barriers, timing), RCCL is brought up and probed with a verified plane exchange, and only
 if every rank succeeded is it used; otherwise all ranks together take the host-staged transport over gloo and the line says so.
@@ -204,6 +210,9 @@ def main():
                     help="weak: n x n x nz per GPU (the reference's model); strong: n x n x nz is the GLOBAL grid, split in z")
     ap.add_argument("--no-autotune", action="store_true", help="built-in tile choice instead of timing the shapes once")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the untimed self-check of the timed kernel / schedule")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="N>1: skip the second measurement (the same GLOBAL grid split in z) reported as `strong`")
     ap.add_argument("--cpu-iters", type=int, default=12)
     ap.add_argument("--transport", default=os.environ.get("NS3D_BENCH_TRANSPORT", "auto"), choices=["auto", "rccl", "host"],
                     help="N>1: rccl = libns3d's RCCL communicator (fails loudly if it cannot come up), host = host-staged "
@@ -230,17 +239,65 @@ def main():
         build.build()
     if world > 1:
         dist.barrier()
-    from navierstokes3d_amd import kernels as K
-    from navierstokes3d_amd import lib as L
-    from navierstokes3d_amd.halo import ZSlabGrid
     from navierstokes3d_amd.params import cavity_params
 
     p = cavity_params(a.n, a.nz)
     if a.scaling == "strong" and world > 1:
-        # global nz_g = P*(nz_loc-2)+2 (ImplicitGlobalGrid): the largest local slab that does not exceed the requested grid
-        nz_loc = (p.nz - 2) // world + 2
-        p = cavity_params(a.n, nz_loc)
-        p.dz = p.dx
+        p = strong_params(a.n, p.nz, world)
+    head = run_case(a, world, rank, device, ndev, shared_gpu, p, a.scaling)
+    strong = None
+    if not a.no_strong and a.scaling == "weak":
+        # BASELINE.json's metric reads "512³ grid, 1/2/4/8 MI355X": the same GLOBAL grid split in z, next to the weak headline
+        if world == 1:
+            strong = strong_object(head, world)
+        else:
+            strong = strong_object(run_case(a, world, rank, device, ndev, shared_gpu, strong_params(a.n, p.nz, world), "strong"), world)
+    ok = True
+    if rank == 0:
+        out = json_line(a, world, head)
+        if strong is not None:
+            out["strong"] = strong
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(a.n, 128, a.cpu_iters, a.dtype)
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "Mcells*iter/s", "cores": 0, "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+        ok = out["config"]["verified"] is not False and (strong is None or strong.get("verified") is not False)
+    if world > 1:
+        ok = agree(ok)
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        sys.stderr.write("bench.py: the timed kernel / schedule did NOT reproduce the single-sweep reference (config.verified)\n")
+        sys.exit(3)
+
+
+def strong_params(n, nz_g, world):
+    """Global grid n x n x nz_g split into `world` z-slabs of ImplicitGlobalGrid's shape nz_g = P*(nz_loc-2)+2: the smallest
+    local slab whose global grid is not smaller than the one asked for (512³ on 4: 130 planes each → 514; on 8: 66 → 514)."""
+    from navierstokes3d_amd.params import cavity_params
+    nz_loc = -(-(nz_g - 2) // world) + 2
+    p = cavity_params(n, nz_loc)
+    p.dz = p.dx
+    return p
+
+
+def strong_object(r, world):
+    return {"value": r["value"], "unit": "Mcells*iter/s", "ms_per_step": r["ms_per_step"], "scaling": "strong",
+            "global_grid": r["global_grid"], "planes_per_rank": r["local_grid"][2], "pt_depth": r["depth"],
+            "ptn_variant": r["ptn_variant"], "pt2_variant": r["pt2_variant"], "transport": r["transport"],
+            "hbm_gbps_algorithmic": r["effective"] * world, "verified": r["verified"], "verify": r["verify"],
+            "finite": r["finite"]}
+
+
+def run_case(a, world, rank, device, ndev, shared_gpu, p, scaling):
+    """One timed measurement: plan (untimed), W warm-up iterations, EXACTLY K timed iterations between barriers + device
+    synchronisation, then the untimed self-check.  Returns a dict on every rank (timings are the maximum over ranks)."""
+    from navierstokes3d_amd import kernels as K
+    from navierstokes3d_amd import lib as L
+    from navierstokes3d_amd.halo import ZSlabGrid
     nx, ny, nz = p.nx, p.ny, p.nz
     tdt = torch.float64 if a.dtype == "f64" else torch.float32
     dev = torch.device("cuda", device)
@@ -258,6 +315,8 @@ def main():
                 reason = why
         if mg is not None:
             transport, rccl_ranks = "RCCL send/recv over xGMI inside libns3d (ns3d_mgpu_create_rank)", mg.rccl_ranks()
+            if os.environ.get("NS3D_RCCL_LIB"):
+                transport += " [NS3D_RCCL_LIB=%s]" % os.path.basename(os.environ["NS3D_RCCL_LIB"])
         else:
             transport = "host-staged over gloo (%s)" % reason[:200]
     if mg is not None:
@@ -301,6 +360,7 @@ def main():
         slab.set_temporal_blocking(depth == 2)
         slab.load(Pr, D, rhs)
     D2 = K.zeros((nx - 2, ny - 2, nz - 2), tdt, dev) if use2 else None
+    st = {"Pr": Pr, "Pb": Pb, "D": D, "D2": D2}
 
     def schedule(n):
         """the passes ns3d_pt_iterate makes for n iterations at `depth` iterations per pass (4 = 2+2, not 3+1)"""
@@ -320,7 +380,6 @@ def main():
         """n PT iterations {update_dPrdτ!; update_Pr!; set_bc_Pr!}.  One GPU: what ns3d_pt_iterate does, with the buffer
         swaps visible (`depth` iterations per pass over memory where n allows).  z-slab ranks: seam planes first, their
         exchange behind the interior sweep."""
-        nonlocal Pr, Pb, D, D2
         if mg is not None:
             mg.slab_iterate(n)
             return
@@ -329,21 +388,21 @@ def main():
             return
         for its in schedule(n):
             if its == 1:
-                K.pt_sweep(Pr, Pb, D, rhs, pt, 1, nz - 1, ctx=ctx)
-                Pr, Pb = Pb, Pr
+                K.pt_sweep(st["Pr"], st["Pb"], st["D"], rhs, pt, 1, nz - 1, ctx=ctx)
+                st["Pr"], st["Pb"] = st["Pb"], st["Pr"]
                 continue
             if its == 2:
-                K.pt_sweep2(Pr, Pb, D, D2, rhs, pt, ctx=ctx)
+                K.pt_sweep2(st["Pr"], st["Pb"], st["D"], st["D2"], rhs, pt, ctx=ctx)
             else:
-                K.pt_sweepn(its, Pr, Pb, D, D2, rhs, pt, ctx=ctx)
-            Pr, Pb, D, D2 = Pb, Pr, D2, D
+                K.pt_sweepn(its, st["Pr"], st["Pb"], st["D"], st["D2"], rhs, pt, ctx=ctx)
+            st["Pr"], st["Pb"], st["D"], st["D2"] = st["Pb"], st["Pr"], st["D2"], st["D"]
 
     # plan phase, untimed and outside the warmup count: ns3d_plan_pt times the tile shapes of k_pt_sweep2 / k_pt_sweepN on
     # these arguments, decides how many iterations a pass advances, and the process keeps the winner (same bits either way)
     if use2 and not a.no_autotune:
-        K.plan_pt(Pr, Pb, D, D2, rhs, pt, ctx=ctx)
+        K.plan_pt(st["Pr"], st["Pb"], st["D"], st["D2"], rhs, pt, ctx=ctx)
         depth = ctx.last_pt_depth() if a.depth <= 0 else a.depth
-        Pb.zero_(); D2.zero_()
+        st["Pb"].zero_(); st["D2"].zero_()
         torch.cuda.synchronize()
     run(a.warmup)
     torch.cuda.synchronize()
@@ -369,76 +428,136 @@ def main():
     elif slab is not None:
         err = slab.residual()
     else:
-        err = K.residual_max(Pr, rhs, pt, ctx=ctx)
+        err = K.residual_max(st["Pr"], rhs, pt, ctx=ctx)
     err = err * (p.ly * p.ly) / p.psc
-    finite = bool(np.isfinite(err))
+    passes = schedule(a.steps)
 
-    if rank == 0:
-        cells_g = nx * ny * grid.nz_g()
-        itemsize = 8 if a.dtype == "f64" else 4
-        # the dominant kernel: k_pt_sweep2 / k_pt_sweepN advance `depth` iterations per launch (k_pt_sweep: one)
-        passes = schedule(a.steps)
-        its_per_launch = max(passes)
-        launches = len(passes)
-        kern_ms = dev_ms / launches                  # HIP events around the timed launches on the launch stream
-        must_move = algorithmic_bytes(nx, ny, nz, itemsize)          # bytes ONE pass has to move, per launch
-        physical = must_move / (kern_ms * 1e-3) / 1e9
-        effective = a.steps * algorithmic_bytes(nx, ny, nz, itemsize) / (dev_ms * 1e-3) / 1e9   # 40 B per cell and iteration
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "pt_sweep_traffic.json")
-        if world == 1 and os.path.exists(tfile):
-            try:
-                tj = json.load(open(tfile))
-                key = "%dx%dx%d_%s_%s_x%d" % (nx, ny, nz, a.dtype, a.mode, its_per_launch)
-                if its_per_launch >= 2:                         # measured per tile shape (tools/collect_traffic.py)
-                    key += "_v%d" % (ctx.last_pt2_variant() if its_per_launch == 2 else ctx.last_ptn_variant())
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "Mcells*PT-iter/s, fused pseudo-transient Poisson iteration, %dx%dx%d per GPU" % (nx, ny, nz),
-            "value": cells_g * a.steps / wall / 1e6,
-            "unit": "Mcells*iter/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": wall / a.steps * 1e3,
-            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
-            "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": "lid-driven-cavity Poisson-only PT iteration (BASELINE configs[2])",
-                       "local_grid": [nx, ny, nz], "global_grid": [nx, ny, grid.nz_g()],
-                       "decomposition": "z-slabs x%d" % world,
-                       "transport": transport, "rccl_ranks": rccl_ranks,
-                       "arith_mode": a.mode, "variant": a.variant,
-                       "pt_depth": its_per_launch, "pt2_variant": ctx.last_pt2_variant(),
-                       "ptn_variant": ctx.last_ptn_variant(), "residual_after_run": err, "finite": finite},
-            "hbm_gbps_algorithmic": effective * world,
-            "roofline": {"bound": "hbm", "achieved": physical, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": physical / HBM_PEAK_GBPS,
-                         "definition": "bytes one launch must move (one pass: itemsize*(N+4*N_inner)) / launch time / peak",
-                         "traffic": traffic, "traffic_source": "profiles lookup" if traffic is not None else "none",
-                         # what the memory system actually delivered: PMC bytes of a launch / launch time (the overlap rows of
-                         # neighbouring tiles are read more than once, so this exceeds `achieved`)
-                         "hbm_gbps_measured": (traffic / (kern_ms * 1e-3) / 1e9) if traffic is not None else None,
-                         "hbm_frac_measured": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic is not None else None,
-                         "kernel": {1: "k_pt_sweep", 2: "k_pt_sweep2"}.get(its_per_launch, "k_pt_sweepN<%d levels>" % its_per_launch),
-                         "kernel_ms": kern_ms,
-                         "pt_iterations_per_launch": its_per_launch, "bytes_per_launch": must_move,
-                         "effective_gbps": effective, "effective_frac": effective / HBM_PEAK_GBPS,
-                         "effective_definition": "SURVEY 8d: 40 B per cell and PT ITERATION (itemsize*(N+4*N_inner) per "
-                                                 "iteration) / time / peak; exceeds frac by the temporal-blocking factor"},
-        }
-        if world == 1 and not a.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(a.n, 128, a.cpu_iters, a.dtype)
-            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
-                out["cpu_baseline"] = {"value": None, "unit": "Mcells*iter/s", "cores": 0, "kind": "port",
-                                       "sample": "failed: %r" % (e,)}
-        print(json.dumps(out))
+    # ---- self-check, untimed: the timed kernel instance / schedule against one-thread-per-cell single sweeps ---------------
+    # One GPU: ONE pass of exactly the kernel that was timed (same depth, same tile variant) from the state the run left
+    # behind, against `depth` launches of k_pt_sweep_naive (multi.jl:459-463, one launch per iteration).  z-slab ranks: one
+    # pass of the library's schedule (deep ghosts, seam-first, exchange behind the interior) against `depth` × {single sweep;
+    # update_halo!(Pr)} — the reference's own per-iteration sequence, multi.jl:459-463.  STRICT: bit for bit on the device.
+    verify = {"against": None, "iterations": 0, "bitwise": None, "rel_l2": None}
+    verified = None
+    if not a.no_verify:
+        vd = max(passes) if passes else 0
+        if vd >= 1:
+            vctx = ctx
+            if world == 1:
+                P0, D0 = st["Pr"], st["D"]
+                Pa, Da = st["Pb"], (st["D2"] if st["D2"] is not None else K.clone(D0))
+                if vd == 1:
+                    Da = K.clone(D0)
+                    K.pt_sweep(P0, Pa, Da, rhs, pt, 1, nz - 1, ctx=ctx)
+                elif vd == 2:
+                    K.pt_sweep2(P0, Pa, D0, Da, rhs, pt, ctx=ctx)
+                else:
+                    K.pt_sweepn(vd, P0, Pa, D0, Da, rhs, pt, ctx=ctx)
+                halo = lambda X: None
+                verify["against"] = "%d launches of the one-thread-per-cell sweep (k_pt_sweep_naive)" % vd
+            else:
+                P0, D0 = K.zeros((nx, ny, nz), tdt, dev), K.zeros((nx - 2, ny - 2, nz - 2), tdt, dev)
+                Pa, Da = K.zeros((nx, ny, nz), tdt, dev), K.zeros((nx - 2, ny - 2, nz - 2), tdt, dev)
+                (mg.slab_store if mg is not None else slab.store)(P0, D0)
+                run(vd)
+                (mg.slab_store if mg is not None else slab.store)(Pa, Da)
+                halo = mg.update_halo if mg is not None else grid.update_halo
+                verify["against"] = "%d x {one-thread-per-cell sweep; update_halo!(Pr)} per rank" % vd
+            vctx.set_pt_variant(100)
+            Pq, Pw, Dq = K.clone(P0), K.clone(P0), K.clone(D0)
+            for _ in range(vd):
+                K.pt_sweep(Pq, Pw, Dq, rhs, pt, 1, nz - 1, ctx=vctx)
+                halo(Pw)
+                Pq, Pw = Pw, Pq
+            vctx.set_pt_variant(a.variant)
+            if os.environ.get("NS3D_BENCH_SABOTAGE") == "1":      # test hook: the check must be able to fail
+                Pq[nx // 2, ny // 2, nz // 2] += 1.0
+            torch.cuda.synchronize()
+            bits = torch.int64 if a.dtype == "f64" else torch.int32
+            bitwise = bool(torch.equal(Pa.view(bits), Pq.view(bits)) and torch.equal(Da.view(bits), Dq.view(bits)))
+            den = torch.linalg.vector_norm(Pq.double()).item()
+            num = torch.linalg.vector_norm((Pa - Pq).double()).item()
+            rel = num / den if den > 0 else num
+            okv = bitwise if a.mode == "strict" else (rel <= 1e-6 and bool(np.isfinite(rel)))
+            if world > 1:
+                t = torch.tensor([1.0 if okv else 0.0, 1.0 if bitwise else 0.0, -rel], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                okv, bitwise, rel = bool(t[0].item()), bool(t[1].item()), -t[2].item()
+            verify.update(iterations=vd, bitwise=bitwise, rel_l2=rel,
+                          criterion="bitwise" if a.mode == "strict" else "rel_l2 <= 1e-6 (BASELINE north_star tolerance)")
+            verified = okv
+            del Pq, Pw, Dq
+    res = {
+        "value": nx * ny * grid.nz_g() * a.steps / wall / 1e6, "wall": wall, "dev_ms": dev_ms,
+        "ms_per_step": wall / a.steps * 1e3, "local_grid": [nx, ny, nz], "global_grid": [nx, ny, grid.nz_g()],
+        "depth": max(passes) if passes else depth, "launches": len(passes), "err": err, "finite": bool(np.isfinite(err)),
+        "pt2_variant": ctx.last_pt2_variant(), "ptn_variant": ctx.last_ptn_variant(), "transport": transport,
+        "rccl_ranks": rccl_ranks, "scaling": scaling, "verified": verified, "verify": verify,
+        "arith_build": ctx.arith_build(p.dx, p.dy, p.dz),
+        "effective": a.steps * algorithmic_bytes(nx, ny, nz, 8 if a.dtype == "f64" else 4) / (dev_ms * 1e-3) / 1e9,
+    }
     ctx.sync()
     if mg is not None:
         mg.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    elif world == 1:
+        ctx.close()
+    del st, Pr, Pb, D, D2, rhs
+    torch.cuda.empty_cache()
+    return res
+
+
+def json_line(a, world, r):
+    nx, ny, nz = r["local_grid"]
+    itemsize = 8 if a.dtype == "f64" else 4
+    # the dominant kernel: k_pt_sweep2 / k_pt_sweepN advance `depth` iterations per launch (k_pt_sweep: one)
+    its_per_launch, launches = r["depth"], r["launches"]
+    kern_ms = r["dev_ms"] / launches                 # HIP events around the timed launches on the launch stream
+    must_move = algorithmic_bytes(nx, ny, nz, itemsize)          # bytes ONE pass has to move, per launch
+    physical = must_move / (kern_ms * 1e-3) / 1e9
+    effective = r["effective"]                       # 40 B per cell and iteration
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "pt_sweep_traffic.json")
+    if world == 1 and os.path.exists(tfile):
+        try:
+            tj = json.load(open(tfile))
+            key = "%dx%dx%d_%s_%s_x%d" % (nx, ny, nz, a.dtype, a.mode, its_per_launch)
+            if its_per_launch >= 2:                         # measured per tile shape (tools/collect_traffic.py)
+                key += "_v%d" % (r["pt2_variant"] if its_per_launch == 2 else r["ptn_variant"])
+            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return {
+        "metric": "Mcells*PT-iter/s, fused pseudo-transient Poisson iteration, %dx%dx%d per GPU" % (nx, ny, nz),
+        "value": r["value"],
+        "unit": "Mcells*iter/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": r["ms_per_step"],
+        "higher_is_better": True, "scaling": r["scaling"], "vs_baseline": None,
+        "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": "lid-driven-cavity Poisson-only PT iteration (BASELINE configs[2])",
+                   "local_grid": r["local_grid"], "global_grid": r["global_grid"],
+                   "decomposition": "z-slabs x%d" % world,
+                   "transport": r["transport"], "rccl_ranks": r["rccl_ranks"],
+                   "arith_mode": a.mode, "arith_build": r["arith_build"], "variant": a.variant,
+                   "pt_depth": its_per_launch, "pt2_variant": r["pt2_variant"],
+                   "ptn_variant": r["ptn_variant"], "residual_after_run": r["err"], "finite": r["finite"],
+                   "verified": r["verified"], "verify": r["verify"]},
+        "hbm_gbps_algorithmic": effective * world,
+        "roofline": {"bound": "hbm", "achieved": physical, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": physical / HBM_PEAK_GBPS,
+                     "definition": "bytes one launch must move (one pass: itemsize*(N+4*N_inner)) / launch time / peak",
+                     "traffic": traffic, "traffic_source": "profiles lookup" if traffic is not None else "none",
+                     # what the memory system actually delivered: PMC bytes of a launch / launch time (the overlap rows of
+                     # neighbouring tiles are read more than once, so this exceeds `achieved`)
+                     "hbm_gbps_measured": (traffic / (kern_ms * 1e-3) / 1e9) if traffic is not None else None,
+                     "hbm_frac_measured": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic is not None else None,
+                     "kernel": {1: "k_pt_sweep", 2: "k_pt_sweep2"}.get(its_per_launch, "k_pt_sweepN<%d levels>" % its_per_launch),
+                     "kernel_ms": kern_ms,
+                     "pt_iterations_per_launch": its_per_launch, "bytes_per_launch": must_move,
+                     "effective_gbps": effective, "effective_frac": effective / HBM_PEAK_GBPS,
+                     "effective_definition": "SURVEY 8d: 40 B per cell and PT ITERATION (itemsize*(N+4*N_inner) per "
+                                             "iteration) / time / peak; exceeds frac by the temporal-blocking factor"},
+    }
 
 
 if __name__ == "__main__":

@@ -101,9 +101,15 @@ int ns3d_set_autotune(ns3d_ctx *ctx, int on);
 int ns3d_last_pt2_variant(const ns3d_ctx *ctx);
 int ns3d_last_ptn_variant(const ns3d_ctx *ctx);   /* tile variant of the latest N-iteration launch */
 int ns3d_last_pt_depth(const ns3d_ctx *ctx);      /* PT iterations of the latest multi-iteration pass; after ns3d_plan_pt: the planned depth */
+/* Which of the four compilations of the kernels a call with these grid spacings runs on this context: 0 = `strict` (plain IEEE
+ * divisions), 1 = `strictx` (same bits, divisions by the spacings through the correctly rounded divisor-known-in-advance sequence),
+ * 3 = `strictp` (same bits; every spacing a power of two, x/d = x*(1/d) exactly), 2 = `fast` (reciprocals + FMA, NS3D_FAST).
+ * The reference has no counterpart (its arithmetic is whatever Julia emits for `x/dx/dx`, multi.jl:71); reported by bench.py. */
+int ns3d_arith_build(const ns3d_ctx *ctx, double dx, double dy, double dz);
 /* ns3d_pt_solve replays each residual-check block (nchk iterations) as one HIP graph: -1 = automatically on
  * launch-bound grids (< 3 M cells), 0 = never, 1 = always.  Same results either way. */
 int ns3d_set_graph_mode(ns3d_ctx *ctx, int mode);
+int ns3d_cached_graphs(const ns3d_ctx *ctx);      /* residual-check blocks this context holds as instantiated HIP graphs */
 
 /* Parameters of the fused pseudo-transient path (ns3d_pt_iterate / ns3d_pt_solve). */
 typedef struct ns3d_pt_params {

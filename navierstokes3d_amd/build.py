@@ -50,8 +50,24 @@ def needs_build():
     return any(os.path.getmtime(s) > t for s in _sources())
 
 
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "ns3d.h")]
+
+
+def _deps_of(obj, fallback):
+    """the repo's own files a unit was compiled from (its -MD dependency file); every header when there is none yet"""
+    try:
+        words = open(obj + ".d").read().replace("\\\n", " ").split()
+    except OSError:
+        return fallback
+    root = os.path.realpath(os.path.join(HERE, ".."))
+    deps = [w for w in words[1:] if os.path.realpath(w).startswith(root)]
+    return deps if deps and all(os.path.exists(d) for d in deps) else fallback
+
+
 def build(force=False, verbose=False, extra_flags=()):
-    """Compile every HIP translation unit for gfx950 and link libns3d.so. Returns the library path."""
+    """Compile every HIP translation unit for gfx950 and link libns3d.so. Returns the library path.  Units whose object is
+    newer than their source and every header are not recompiled (the kernel unit is compiled four times: ≈2 min)."""
     if not force and not needs_build():
         return LIB
     hipcc = _hipcc()
@@ -59,19 +75,27 @@ def build(force=False, verbose=False, extra_flags=()):
     os.makedirs(bdir, exist_ok=True)
     objs = []
     procs = []
+    stamp = os.path.join(bdir, "flags.txt")
+    flags_now = " ".join(COMMON + list(extra_flags))
+    same_flags = os.path.exists(stamp) and open(stamp).read() == flags_now
     for src, obj, flags in UNITS:
         o = os.path.join(bdir, obj)
-        cmd = [hipcc] + COMMON + list(flags) + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", o]
+        objs.append(o)
+        deps = _deps_of(o, [os.path.join(CSRC, src)] + _headers())
+        if not force and same_flags and os.path.exists(o) and all(os.path.getmtime(d) <= os.path.getmtime(o) for d in deps):
+            continue
+        cmd = [hipcc] + COMMON + list(flags) + list(extra_flags) + ["-MD", "-MF", o + ".d", "-c", os.path.join(CSRC, src), "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(o)
     for cmd, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), out.decode(errors="replace")))
         if verbose and out:
             print(out.decode(errors="replace"))
+    with open(stamp, "w") as f:
+        f.write(flags_now)
     cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))

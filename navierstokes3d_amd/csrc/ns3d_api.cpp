@@ -201,6 +201,8 @@ int ns3d_set_autotune(ns3d_ctx *c, int on)
 int ns3d_last_pt2_variant(const ns3d_ctx *c) { return c ? c->last_pt2 : -1; }
 int ns3d_last_ptn_variant(const ns3d_ctx *c) { return c ? c->last_ptn : -1; }
 int ns3d_last_pt_depth(const ns3d_ctx *c) { return c ? c->last_depth : -1; }
+int ns3d_cached_graphs(const ns3d_ctx *c) { return c ? (int)c->graphs.size() : -1; }
+int ns3d_arith_build(const ns3d_ctx *c, double dx, double dy, double dz) { return c ? mode_of(c, dx, dy, dz) : -1; }
 
 int ns3d_set_ptn_variant(ns3d_ctx *c, int v)
 {
@@ -618,6 +620,15 @@ static hipError_t enqueue_iters(ns3d_ctx *c, hipStream_t s, int n, bool two, T *
     return e;
 }
 
+// Field by field: the struct has four bytes of padding after owns_outlet that a C caller's stack struct or Julia's
+// Ref(PtParams(…)) leaves indeterminate — a memcmp would miss the cache on every call and re-capture a graph each time.
+static bool same_pt_params(const ns3d_pt_params &a, const ns3d_pt_params &b)
+{
+    return a.rho == b.rho && a.dt == b.dt && a.dtau == b.dtau && a.damp == b.damp && a.dx == b.dx && a.dy == b.dy && a.dz == b.dz &&
+           a.nx == b.nx && a.ny == b.ny && a.nz == b.nz && a.bc_kind == b.bc_kind && a.owns_outlet == b.owns_outlet &&
+           a.outlet_val == b.outlet_val && a.g == b.g && a.z_lo_is_halo == b.z_lo_is_halo && a.z_hi_is_halo == b.z_hi_is_halo;
+}
+
 // One residual-check block (nchk iterations) as a HIP graph: launch-bound grids (63×38×38: ≈2 µs of kernel per ≈5 µs
 // launch) replay the whole block with one host call.  Graphs are cached per buffer state in the context.
 template <class T>
@@ -629,7 +640,7 @@ static int run_block_graph(ns3d_ctx *c, hipStream_t s, int n, bool two, T *&src,
         if (g.src == src && g.dst == dst && g.dsrc == dsrc && g.ddst == ddst && g.rhs == divV && g.n == n && g.two == two &&
             g.mode == mode && g.v1 == c->pt_variant && g.v2 == c->pt2_variant && g.vn == c->ptn_variant && g.depth == c->pt_depth &&
             g.esize == (int)sizeof(T) &&
-            std::memcmp(&g.p, p, sizeof *p) == 0) {
+            same_pt_params(g.p, *p)) {
             HIPCHK(c, hipGraphLaunch(g.exec, s));
             src = (T *)g.src_out; dst = (T *)g.dst_out; dsrc = (T *)g.dsrc_out; ddst = (T *)g.ddst_out;
             return NS3D_OK;

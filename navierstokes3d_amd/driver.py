@@ -176,6 +176,8 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
         # :370 Pr = -(z_g-dz/2)*ρ*g (+0+0): identically 0 because g = 1/Fr² = 0 (:316); evaluated for fidelity
         zg = np.array([(me * (nz - 2) + iz) * q.dz for iz in range(nz)])
         f.Pr[:, :, :] = torch.from_numpy(-(zg - q.dz / 2) * q.rho * q.g + 0.0).to(f.Pr.device, dtype)[None, None, :]
+    if any(getattr(c, "_pinned", False) for c in ctxs):    # ranks on streams of their own: the torch writes above come first
+        torch.cuda.synchronize()
     grid.update_halo(col("Pr"))                                                               # :371
     cyls = [(q.a2, q.b2, q.ox, q.oy, q.sinb, q.cosb, q.xco_g, q.yco_g, q.zco_g, q.lx, q.ly, q.lz, q.dx, q.dy, q.dz)
             for q in ps]

@@ -87,9 +87,11 @@ class Context:
             raise L.Ns3dError("ns3d_create failed: " + L.last_error())
         self.use_torch_stream()
 
-    def use_torch_stream(self, stream=None):
-        """Launch on PyTorch's current stream so that tensor ops (uploads, copies) are ordered with kernels."""
+    def use_torch_stream(self, stream=None, pin=False):
+        """Launch on PyTorch's current stream so that tensor ops (uploads, copies) are ordered with kernels.  pin: stay on
+        `stream` whatever PyTorch's current stream becomes (a rank of a MultiGpu created with own_streams)."""
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self._pinned = bool(pin and stream is not None)
         self._stream = s.cuda_stream
         L.check(self.lib.ns3d_set_stream(self.handle, C.c_void_p(s.cuda_stream)))
 
@@ -117,6 +119,10 @@ class Context:
     def last_pt_depth(self):
         """PT iterations of the latest multi-iteration pass (after plan_pt: the planned depth)."""
         return int(self.lib.ns3d_last_pt_depth(self.handle))
+
+    def arith_build(self, dx, dy, dz):
+        """Which compilation of the kernels these grid spacings select: 'strict' | 'strictx' | 'strictp' | 'fast'."""
+        return {0: "strict", 1: "strictx", 2: "fast", 3: "strictp"}[int(self.lib.ns3d_arith_build(self.handle, dx, dy, dz))]
 
     def set_pt2_variant(self, v):
         """Temporal blocking (two PT iterations per pass) in pt_iterate / pt_solve: v < 0 off, 0 default tile."""
@@ -150,7 +156,7 @@ class Context:
             pass
 
     def call(self, name, ref, *args):
-        if torch.cuda.current_stream(self.device).cuda_stream != self._stream:
+        if not getattr(self, "_pinned", False) and torch.cuda.current_stream(self.device).cuda_stream != self._stream:
             self.use_torch_stream()     # follow `with torch.cuda.stream(...)` blocks
         fn = getattr(self.lib, "ns3d_%s_%s" % (name, _DT[ref.dtype]))
         L.check(fn(self.handle, *args))

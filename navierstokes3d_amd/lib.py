@@ -65,7 +65,8 @@ SIGNATURES = {
 }
 CONTEXT_SYMBOLS = ["ns3d_version", "ns3d_last_error", "ns3d_create", "ns3d_destroy", "ns3d_flags",
                    "ns3d_set_stream", "ns3d_use_own_stream", "ns3d_get_stream", "ns3d_sync", "ns3d_set_pt_variant",
-                   "ns3d_set_pt2_variant", "ns3d_set_ptn_variant", "ns3d_set_pt_depth", "ns3d_set_graph_mode", "ns3d_set_autotune", "ns3d_last_pt2_variant", "ns3d_last_ptn_variant", "ns3d_last_pt_depth"]
+                   "ns3d_set_pt2_variant", "ns3d_set_ptn_variant", "ns3d_set_pt_depth", "ns3d_set_graph_mode", "ns3d_set_autotune", "ns3d_last_pt2_variant", "ns3d_last_ptn_variant", "ns3d_last_pt_depth",
+                   "ns3d_arith_build", "ns3d_cached_graphs"]
 
 
 _PP = C.POINTER(C.c_void_p)      # T *const *  — one device pointer per local rank (field-major for field lists)
@@ -151,6 +152,10 @@ def load():
     lib.ns3d_last_ptn_variant.restype = _I
     lib.ns3d_last_pt_depth.argtypes = [_P]
     lib.ns3d_last_pt_depth.restype = _I
+    lib.ns3d_cached_graphs.argtypes = [_P]
+    lib.ns3d_cached_graphs.restype = _I
+    lib.ns3d_arith_build.argtypes = [_P, _D, _D, _D]
+    lib.ns3d_arith_build.restype = _I
     for name, args in SIGNATURES.items():
         for suf in ("f64", "f32"):
             fn = getattr(lib, "ns3d_%s_%s" % (name, suf))

@@ -55,9 +55,12 @@ class MultiGpu:
         return tuple(d3)
 
     @classmethod
-    def create(cls, devices, nx, ny, nz, mode="strict", async_=True, dims=None):
+    def create(cls, devices, nx, ny, nz, mode="strict", async_=True, dims=None, own_streams=False):
         """dims=None: z-slabs over len(devices) ranks; dims=(Px,Py,Pz): a Cartesian topology, devices[rank] in MPI_Cart
-        rank order (last dimension fastest)."""
+        rank order (last dimension fastest).  own_streams: every rank computes on a non-blocking stream of its own (as the
+        ranks of different devices always do) instead of following PyTorch's current stream of its device — with several
+        virtual ranks on ONE device this is what makes the ready/landed events between the ranks carry the ordering; the
+        caller then orders its own tensor work with torch.cuda.synchronize() before and MultiGpu.sync() after."""
         lib = L.load()
         devs = (C.c_int * len(devices))(*[int(d) for d in devices])
         flags = _FLAGS[mode] | (L.NS3D_ASYNC if async_ else 0)
@@ -72,6 +75,10 @@ class MultiGpu:
         self = cls(h, mode)
         self._devices = [int(d) for d in devices]
         self._wrap_contexts()
+        if own_streams:
+            self._own = [torch.cuda.Stream(device=d) for d in self._devices]
+            for c, st in zip(self.contexts, self._own):
+                c.use_torch_stream(st, pin=True)
         return self
 
     @staticmethod
@@ -133,6 +140,10 @@ class MultiGpu:
         L.check(self.lib.ns3d_mgpu_sync(self.handle))
 
     def _follow_torch_streams(self):
+        if getattr(self, "_own", None):       # pinned rank streams: what PyTorch's streams hold so far is complete first
+            for d in set(self._devices):
+                torch.cuda.current_stream(d).synchronize()
+            return
         for c in self.contexts:
             if torch.cuda.current_stream(c.device).cuda_stream != c._stream:
                 c.use_torch_stream()

@@ -23,6 +23,12 @@ def test_bench_prints_one_json_line(extra):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert d["value"] > 0 and d["ms_per_step"] > 0 and d["config"]["finite"] is True and "workload" in d["config"]
+    # every line certifies itself: one pass of the timed kernel instance against single sweeps, on the device
+    v = d["config"]["verify"]
+    assert d["config"]["verified"] is True and v["iterations"] == d["config"]["pt_depth"] and v["rel_l2"] <= 1e-6
+    assert v["bitwise"] is True or "fast" in extra
+    assert d["config"]["arith_build"] == ("fast" if "fast" in extra else "strictx")          # dx = 1/96: not a power of two
+    assert d["strong"]["value"] == d["value"] and d["strong"]["global_grid"] == d["config"]["global_grid"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
@@ -54,3 +60,20 @@ def test_bench_gpus_2_as_typed_starts_its_own_ranks():
     else:
         assert d["config"]["transport"].startswith("RCCL") and d["config"]["rccl_ranks"] == 2
     assert 0 < d["roofline"]["frac"] <= 1.0 and "cpu_baseline" not in d
+    # the schedule certifies itself (one pass of the slab schedule against {single sweep; update_halo!(Pr)} per iteration) …
+    assert d["config"]["verified"] is True and d["config"]["verify"]["bitwise"] is True
+    # … and the same GLOBAL grid split in z is measured next to the weak headline (BASELINE: "512³ grid, 1/2/4/8 MI355X")
+    st = d["strong"]
+    assert st["scaling"] == "strong" and st["planes_per_rank"] == 49 and st["global_grid"] == [96, 96, 96]
+    assert st["value"] > 0 and st["verified"] is True and st["finite"] is True
+
+
+def test_bench_exits_nonzero_when_the_self_check_fails():
+    """config.verified is load-bearing: with NS3D_BENCH_SABOTAGE=1 the checker perturbs one value of the reference side and the
+    run must print verified: false and exit with a non-zero status."""
+    env = dict(os.environ, NS3D_BENCH_SABOTAGE="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--grid", "96", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["verified"] is False and d["config"]["verify"]["bitwise"] is False

@@ -14,9 +14,30 @@ from util import fields, geometry
 pytestmark = pytest.mark.gpu
 
 
+OWN_STREAMS = False
+
+
+@pytest.fixture(autouse=True, params=["torch-stream", "own-streams"])
+def rank_streams(request):
+    """Every test of this module runs twice: with all virtual ranks following PyTorch's current stream of device 0 (one
+    compute stream for everybody: only the communication streams are asynchronous) and with a NON-BLOCKING COMPUTE STREAM
+    PER RANK, where the ev_ready / ev_landed handshake of exchange_begin / exchange_end (ns3d_mgpu.cpp) is what orders one
+    rank's sweeps against its neighbours' pulls — as it is between the devices of a multi-GPU node."""
+    global OWN_STREAMS
+    import torch
+    OWN_STREAMS = request.param == "own-streams"
+    if OWN_STREAMS:
+        torch.cuda.synchronize()
+    yield
+    torch.cuda.synchronize()
+    OWN_STREAMS = False
+
+
 def _mg(P, nx, ny, nz, mode="strict"):
+    import torch
     from navierstokes3d_amd.mgpu import MultiGpu
-    return MultiGpu.create([0] * P, nx, ny, nz, mode)
+    torch.cuda.synchronize()            # uploads made on PyTorch's stream are complete before any rank stream reads them
+    return MultiGpu.create([0] * P, nx, ny, nz, mode, own_streams=OWN_STREAMS)
 
 
 @pytest.mark.parametrize("P", [2, 3])
@@ -183,7 +204,7 @@ def test_pt_solve_on_a_cartesian_topology_equals_global_pt_solve(hip, dims, dtyp
     from navierstokes3d_amd.mgpu import MultiGpu
     from oracle.driver_ref import cart_coords
     P = dims[0] * dims[1] * dims[2]
-    mg = MultiGpu.create([0] * P, *n, "strict", dims=dims)
+    mg = MultiGpu.create([0] * P, *n, "strict", dims=dims, own_streams=OWN_STREAMS)
 
     def cut(A, r, shrink):
         c = cart_coords(r, dims)
@@ -213,7 +234,7 @@ def test_driver_on_mgpu_grid_vs_oracle_virtual_ranks(hip, P, fused, temporal):
     from oracle.driver_ref import run_navierstokes3D_ref
     nx, nt = 32, 2
     p0 = multi_params(nx)
-    mg = MultiGpu.create([0] * P, p0.nx, p0.ny, p0.nz, "strict")
+    mg = MultiGpu.create([0] * P, p0.nx, p0.ny, p0.nz, "strict", own_streams=OWN_STREAMS)
     out = run_navierstokes3D(nx=nx, nt=nt, mode="strict", fused=fused, temporal=temporal,
                              grid=MgpuGrid(mg, p0.nx, p0.ny, p0.nz), return_info=True)
     info = out[-1]
@@ -252,7 +273,7 @@ def test_update_halo_and_gather_on_a_cartesian_topology(hip, dims):
     P = dims[0] * dims[1] * dims[2]
     nx, ny, nz = 13, 9, 7
     kinds = ["c", "vx", "vy", "vz", "s", "i"]
-    mg = MultiGpu.create([0] * P, nx, ny, nz, "strict", dims=dims)
+    mg = MultiGpu.create([0] * P, nx, ny, nz, "strict", dims=dims, own_streams=OWN_STREAMS)
     assert mg.dims == dims and mg.P == P and mg.coords == [cart_coords(r, dims) for r in range(P)]
     assert mg.n_g() == tuple(dims[d] * ((nx, ny, nz)[d] - 2) + 2 for d in range(3))
     grid = MgpuGrid(mg, nx, ny, nz)
@@ -294,7 +315,7 @@ def test_driver_on_a_cartesian_topology_vs_oracle_virtual_ranks(hip, dims, nx, s
     nt, cap = 2, 300
     p0 = multi_params(nx, dims=dims, **shape)
     assert (p0.nx_g, p0.ny_g, p0.nz_g) == (26, 16, 16)
-    mg = MultiGpu.create([0] * P, p0.nx, p0.ny, p0.nz, "strict", dims=dims)
+    mg = MultiGpu.create([0] * P, p0.nx, p0.ny, p0.nz, "strict", dims=dims, own_streams=OWN_STREAMS)
     grid = MgpuGrid(mg, p0.nx, p0.ny, p0.nz)
     out = run_navierstokes3D(nx=nx, nt=nt, mode="strict", fused=fused, grid=grid, niter_cap=cap, return_info=True, shape=shape)
     info = out[-1]

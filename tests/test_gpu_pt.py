@@ -714,3 +714,118 @@ def test_planned_passes_on_odd_large_grids(hip, grid, dtype):
     assert depth in (2, 3, 4)
     assert torch.equal(Pa.view(bits), Pb.view(bits)) and torch.equal(Da.view(bits), Db.view(bits)), (grid, dtype, depth)
     ctx.close()
+
+
+def _timed_instance_properties(hip, oracle, n, dtype):
+    """The kernel instance bench.py TIMES, at the size it is timed on: cavity_params spacings (dx = 1/n with n a power of two →
+    the `strictp` arithmetic build), four iterations per pass.  (a) ns3d_plan_pt on these arguments, then ONE pass of
+    ns3d_pt_sweepn(4) with the planner's tile shape and with each built-in shape the planner may return (fp64: 2800 chunked /
+    2891 one round / 2300 / 2391; fp32: 2400 / 2491) against FOUR launches of the one-thread-per-cell sweep on the whole grid,
+    bit for bit, compared on the device.  (b) locality — four iterations on planes [a+4, b−4) depend only on planes [a, b) —
+    lets the oracle's unfused loop (update_dPrdτ!; update_Pr!; set_bc_Pr!, multi.jl:459-463) check a 30-plane sub-slab."""
+    import torch
+    from navierstokes3d_amd.params import cavity_params
+    c = cavity_params(n)
+    nx, ny, nz = c.nx, c.ny, c.nz
+    g = dict(dx=c.dx, dy=c.dy, dz=c.dz, rho=c.rho, dt=c.dt, dtau=c.dtau, damp=c.damp, g=0.0)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(20260301)
+    tdt, bits = (torch.float64, torch.int64) if dtype == "f64" else (torch.float32, torch.int32)
+    zeros = lambda shape: hip.zeros(shape, tdt)
+
+    def rnd_dev(scale, *shape):
+        t = zeros(shape)
+        t.permute(2, 1, 0).uniform_(-scale, scale, generator=gen)
+        return t
+
+    P0, D0, R = rnd_dev(1.0, nx, ny, nz), rnd_dev(1.0, nx - 2, ny - 2, nz - 2), rnd_dev(1e-3, nx, ny, nz)
+    ctx = hip.Context(0, "strict")
+    assert ctx.arith_build(g["dx"], g["dy"], g["dz"]) == "strictp"
+    p = _params(hip, P0, g, 0, False, 0.0)                  # bench.py: all-Neumann, no outlet plane
+    # reference: four single sweeps, one thread per cell
+    ctx.set_pt_variant(100)
+    Pb, Pc, Db = hip.clone(P0), zeros((nx, ny, nz)), hip.clone(D0)
+    for _ in range(4):
+        hip.pt_sweep(Pb, Pc, Db, R, p, 1, nz - 1, ctx=ctx)
+        Pb, Pc = Pc, Pb
+    ctx.set_pt_variant(0)
+    del Pc
+    Pa, Da = zeros((nx, ny, nz)), zeros((nx - 2, ny - 2, nz - 2))
+    hip.plan_pt(P0, Pa, D0, Da, R, p, ctx=ctx)
+    planned = ctx.last_ptn_variant()
+    shapes = [planned] + ([2800, 2891, 2300, 2391] if dtype == "f64" else [2400, 2491])
+    for v in shapes:
+        if v <= 0:
+            continue
+        ctx.set_ptn_variant(v)
+        Pa.zero_(); Da.zero_()
+        hip.pt_sweepn(4, P0, Pa, D0, Da, R, p, ctx=ctx)
+        torch.cuda.synchronize()
+        assert ctx.last_ptn_variant() == v
+        assert torch.equal(Pa.view(bits), Pb.view(bits)), "Pr differs after a four-iteration pass, variant %d, %r" % (v, n)
+        assert torch.equal(Da.view(bits), Db.view(bits)), "dPrdτ differs after a four-iteration pass, variant %d, %r" % (v, n)
+    # (b) the oracle on planes [a, b): four iterations are exact on [a+4, b−4)
+    mid = nz // 2
+    a, b = mid - 16, mid + 14
+    Ps, Ds, Rs = hip.to_numpy(P0[:, :, a:b]), hip.to_numpy(D0[:, :, a:b - 2]), hip.to_numpy(R[:, :, a:b])
+    _oracle_iters(oracle, Ps, Ds, Rs, g, 4, 0, False, 0.0)
+    assert np.array_equal(hip.to_numpy(Pa[:, :, a + 4:b - 4]), Ps[:, :, 4:-4])
+    assert np.array_equal(hip.to_numpy(Da[:, :, a + 3:b - 5]), Ds[:, :, 3:-3])          # dPrdτ index = plane − 1
+    ctx.close()
+    del P0, D0, R, Pa, Da, Pb, Db
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("n", [512, 1024])
+def test_timed_kernel_instance_at_its_own_size(hip, oracle, n, dtype):
+    """the exact instance behind the headline number (strictp k_pt_sweepN<T,4,…>, its tile remap and
+    one-round chunking) pinned at 512³ (BASELINE configs[2]) and 1024³ (configs[4])."""
+    _timed_instance_properties(hip, oracle, n, dtype)
+
+
+def test_graph_cache_ignores_struct_padding(hip, oracle):
+    """ns3d_pt_params has four bytes of padding after owns_outlet; a C caller's stack struct (or Julia's
+    Ref(PtParams(…))) leaves them indeterminate.  The HIP-graph cache of ns3d_pt_solve must hit all the same: with different
+    garbage in the padding on every call the context keeps holding the same few graphs (one per buffer parity) instead of
+    re-capturing one per call."""
+    import ctypes as C
+    import torch
+    from navierstokes3d_amd import lib as L
+    nx, ny, nz = 24, 15, 15
+    g = geometry(nx, ny, nz)
+    Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 91)
+    rhs *= 1e-3
+    ctx = hip.Context(0, "strict")
+    ctx.set_graph_mode(1)
+    drhs = hip.from_numpy(rhs)
+    assert C.sizeof(L.PtParams) == 104 and L.PtParams.outlet_val.offset == 80 and L.PtParams.owns_outlet.offset == 72
+    counts = []
+    Rp = np.zeros((nx - 2, ny - 2, nz - 2), order="F")
+    Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
+    it_ref, errs_ref = oracle.pt_solve(Pr, d, rhs, Rp, g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, True,
+                                       0.0, g["g"], -1.0, 40, 8, 0.36, 1000.0)
+    for call in range(6):
+        dPr, dd = hip.from_numpy(Pr0), hip.from_numpy(d0)
+        p = _params(hip, dPr, g, 0, True, 0.0)
+        C.memset(C.addressof(p) + 76, 0x11 * (call + 1), 4)              # the padding bytes
+        it, errs = hip.pt_solve(dPr, dd, drhs, p, -1.0, 40, 8, 0.36, 1000.0, ctx=ctx)
+        torch.cuda.synchronize()
+        assert it == it_ref and errs == errs_ref
+        assert np.array_equal(hip.to_numpy(dPr), Pr) and np.array_equal(hip.to_numpy(dd), d)
+        counts.append(int(ctx.lib.ns3d_cached_graphs(ctx.handle)))
+        del dPr, dd
+    assert counts[0] >= 1
+    # fresh tensors may land on new addresses (a legitimately different key); what must NOT happen is one capture per call
+    # with the SAME buffers — so repeat on fixed buffers
+    dPr, dd = hip.from_numpy(Pr0), hip.from_numpy(d0)
+    base = None
+    for call in range(5):
+        dPr.copy_(hip.from_numpy(Pr0)); dd.copy_(hip.from_numpy(d0))
+        p = _params(hip, dPr, g, 0, True, 0.0)
+        C.memset(C.addressof(p) + 76, 0x7F - call, 4)
+        hip.pt_solve(dPr, dd, drhs, p, -1.0, 40, 8, 0.36, 1000.0, ctx=ctx)
+        torch.cuda.synchronize()
+        n = int(ctx.lib.ns3d_cached_graphs(ctx.handle))
+        base = n if base is None else base
+        assert n == base, (call, n, base)
+    ctx.close()
