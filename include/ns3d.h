@@ -290,6 +290,9 @@ int ns3d_max_g(ns3d_mgpu *m, const double *local_max, double *out);    /* NaN-pr
  * or four pay on this grid; every rank uses the same depth. */
 int ns3d_mgpu_set_temporal(ns3d_mgpu *m, int depth);
 int ns3d_mgpu_pass_depth(const ns3d_mgpu *m);
+/* ghost planes per seam of the loaded solve state: (deepest pass allowed) - 1 after ns3d_slab_load, pass depth - 1 once
+ * ns3d_slab_plan has agreed on the iterations per pass; -1 when nothing is loaded */
+int ns3d_mgpu_ghost_depth(const ns3d_mgpu *m);
 /* The pseudo-transient state of a z-slab rank lives in library-owned buffers extended by the ghost planes temporal
  * blocking needs: load → iterate / residual → store; ns3d_pt_solve_slab is the whole inner loop multi.jl:458-471
  * (load, plan, iterate with a global residual check every nchk iterations, store).  Iterates are bit-identical to the

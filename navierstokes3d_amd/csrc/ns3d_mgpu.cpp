@@ -98,7 +98,8 @@ static_assert(sizeof(ncclUniqueId) == NS3D_UNIQUE_ID_BYTES, "NS3D_UNIQUE_ID_BYTE
 
 // ---- one z-slab rank driven by this process ----------------------------------------------------------------------
 struct SlabState {                // deep-ghost pseudo-transient state (library-owned)
-    void *P[2] = {nullptr, nullptr}, *D[2] = {nullptr, nullptr}, *R = nullptr;
+    void *P[2] = {nullptr, nullptr}, *D[2] = {nullptr, nullptr}, *R = nullptr;      // working bases (plane 0 of the CURRENT ghost depth)
+    void *Pa[2] = {nullptr, nullptr}, *Da[2] = {nullptr, nullptr}, *Ra = nullptr;   // the allocations (ghost depth at load)
     size_t bytes_P = 0, bytes_D = 0;
     int ip = 0, id = 0;           // current Pr / dPrdτ buffer
     int glo = 0, ghi = 0, nze = 0;
@@ -112,6 +113,7 @@ struct MRank {
     ns3d_ctx *ctx = nullptr;
     hipStream_t comm = nullptr;                    // halo traffic (high priority)
     hipEvent_t ev_ready = nullptr, ev_landed = nullptr;
+    hipEvent_t ev_pass = nullptr;                  // slab_pass: everything the compute stream held when the pass began
     SlabState st;
     void *cbuf = nullptr;                          // solve_cart: the second pressure buffer
     size_t cbuf_bytes = 0;
@@ -134,6 +136,7 @@ struct ns3d_mgpu {
     ncclComm_t comm = nullptr;
     int rccl_ranks = 0;
     int depth = 4;                // most PT iterations a pass may advance = ghost depth + 1 (1: single sweeps, plain one-plane halo)
+    bool serial_seams = false;    // A/B switch (NS3D_SLAB_SERIAL_SEAMS=1): the round-2 schedule, seam sweeps ahead of the interior on one stream
     int pass_depth = 2;           // iterations per pass actually used (ns3d_slab_plan may raise it to `depth`; same on every rank)
     // loaded solve
     bool loaded = false;
@@ -158,19 +161,21 @@ int cart_rank(const int c[3], const int dims[3]) { return (c[0] * dims[1] + c[1]
 
 // Post the exchange of `blocks[l]` (same count and sizes on every rank): everything up to "the ghosts have landed" is
 // enqueued on the communication streams, ordered after what the compute streams hold NOW.
-int exchange_begin(ns3d_mgpu *m, const std::vector<std::vector<Block>> &blocks, int dim = 2)
+// sends_on_comm: what is sent was produced ON the communication streams (slab_pass sweeps the seam planes there), so "ready"
+// is a point of those streams instead of the compute streams
+int exchange_begin(ns3d_mgpu *m, const std::vector<std::vector<Block>> &blocks, int dim = 2, bool sends_on_comm = false)
 {
     const int n = (int)m->loc.size();
     if (m->P == 1) return NS3D_OK;
     for (int l = 0; l < n; ++l) {
         MRank &r = m->loc[l];
         ns3d_device_guard g(r.device);
-        HIPCHK(0, hipEventRecord(r.ev_ready, compute(r)));
+        HIPCHK(0, hipEventRecord(r.ev_ready, sends_on_comm ? r.comm : compute(r)));
     }
     if (m->rccl) {
         MRank &r = m->loc[0];
         ns3d_device_guard g(r.device);
-        HIPCHK(0, hipStreamWaitEvent(r.comm, r.ev_ready, 0));
+        if (!sends_on_comm) HIPCHK(0, hipStreamWaitEvent(r.comm, r.ev_ready, 0));
         NCCLCHK(g_rccl.GroupStart());
         const int lo = r.nbr[dim][0], hi = r.nbr[dim][1];
         for (const Block &b : blocks[0]) {
@@ -193,7 +198,7 @@ int exchange_begin(ns3d_mgpu *m, const std::vector<std::vector<Block>> &blocks, 
         MRank &r = m->loc[l];
         const int lo = r.nbr[dim][0], hi = r.nbr[dim][1];
         ns3d_device_guard g(r.device);
-        HIPCHK(0, hipStreamWaitEvent(r.comm, r.ev_ready, 0));
+        if (!sends_on_comm) HIPCHK(0, hipStreamWaitEvent(r.comm, r.ev_ready, 0));
         if (lo >= 0) HIPCHK(0, hipStreamWaitEvent(r.comm, m->loc[lo].ev_ready, 0));
         if (hi >= 0) HIPCHK(0, hipStreamWaitEvent(r.comm, m->loc[hi].ev_ready, 0));
         for (size_t q = 0; q < blocks[l].size(); ++q) {
@@ -241,12 +246,12 @@ void free_slab(MRank &r)
 {
     ns3d_device_guard g(r.device);
     for (int q = 0; q < 2; ++q) {
-        if (r.st.P[q]) (void)hipFree(r.st.P[q]);
-        if (r.st.D[q]) (void)hipFree(r.st.D[q]);
-        r.st.P[q] = r.st.D[q] = nullptr;
+        if (r.st.Pa[q]) (void)hipFree(r.st.Pa[q]);
+        if (r.st.Da[q]) (void)hipFree(r.st.Da[q]);
+        r.st.P[q] = r.st.D[q] = r.st.Pa[q] = r.st.Da[q] = nullptr;
     }
-    if (r.st.R) (void)hipFree(r.st.R);
-    r.st.R = nullptr;
+    if (r.st.Ra) (void)hipFree(r.st.Ra);
+    r.st.R = r.st.Ra = nullptr;
     r.st.bytes_P = r.st.bytes_D = 0;
 }
 
@@ -269,6 +274,7 @@ int init_rank(ns3d_mgpu *m, MRank &r, int rank, int device, int flags)
     HIPCHK(0, hipStreamCreateWithPriority(&r.comm, hipStreamNonBlocking, hi));
     HIPCHK(0, hipEventCreateWithFlags(&r.ev_ready, hipEventDisableTiming));
     HIPCHK(0, hipEventCreateWithFlags(&r.ev_landed, hipEventDisableTiming));
+    HIPCHK(0, hipEventCreateWithFlags(&r.ev_pass, hipEventDisableTiming));
     return NS3D_OK;
 }
 
@@ -286,6 +292,7 @@ ns3d_mgpu *new_mgpu(const int *dims, int nx, int ny, int nz, int flags, const ch
     m->nx = nx; m->ny = ny; m->nz = nz; m->flags = flags;
     if (const char *ev = std::getenv("NS3D_SLAB_DEPTH")) m->depth = std::max(1, std::min(4, std::atoi(ev)));
     m->pass_depth = std::min(2, m->depth);
+    if (const char *ev = std::getenv("NS3D_SLAB_SERIAL_SEAMS")) m->serial_seams = std::atoi(ev) != 0;
     return m;
 }
 
@@ -344,7 +351,13 @@ int slab_exchange(ns3d_mgpu *m, int ip_of_all, int id_of_all, bool wait)
     return wait ? exchange_end(m) : NS3D_OK;
 }
 
-// one pass: `its` (1 … depth) PT iterations on every local rank, seam planes first, exchange behind the interior sweep
+// one pass: `its` (1 … depth) PT iterations on every local rank.  The seam-adjacent output planes are swept on the rank's
+// high-priority COMMUNICATION stream, their exchange follows them there in stream order, and the interior sweep runs on the
+// compute stream AT THE SAME TIME (the three sweeps read the same input buffers and write disjoint planes): no launch of a pass
+// waits for the tail of another one, and the exchange starts as soon as the thin seam sweeps are done.  (Until round 3 the seam
+// sweeps ran on the compute stream ahead of the interior: two more kernel boundaries per pass, 1.5× the global solve's time on
+// 66-plane slabs.)  Ordering: the communication stream first waits for everything the compute stream held when the pass began
+// (the previous pass's interior planes, and through its exchange_end the neighbours' pulls of the planes this pass overwrites).
 template <class T>
 int slab_pass(ns3d_mgpu *m, int its)
 {
@@ -352,34 +365,42 @@ int slab_pass(ns3d_mgpu *m, int its)
     const int idd_out = its >= 2 ? idd ^ 1 : idd;
     struct Rng { int lo_end, hi_beg; };
     std::vector<Rng> rng(m->loc.size());
-    auto sweep = [&](MRank &r, int a, int b) -> int {
+    auto sweep = [&](MRank &r, hipStream_t st, int a, int b) -> int {
         if (b <= a) return NS3D_OK;
         const ns3d_pt_params pe = ext_params(m, r);
         ns3d_device_guard g(r.device);
         hipError_t e;
         if (its >= 2)
-            e = ns3d_enqueue_pass<T>(r.ctx, compute(r), its, (const T *)r.st.P[ip], (T *)r.st.P[ip ^ 1], (const T *)r.st.D[idd],
+            e = ns3d_enqueue_pass<T>(r.ctx, st, its, (const T *)r.st.P[ip], (T *)r.st.P[ip ^ 1], (const T *)r.st.D[idd],
                                      (T *)r.st.D[idd_out], (const T *)r.st.R, &pe, a, b);
         else
-            e = ns3d_enqueue_pt1<T>(r.ctx, compute(r), (const T *)r.st.P[ip], (T *)r.st.P[ip ^ 1], (T *)r.st.D[idd],
+            e = ns3d_enqueue_pt1<T>(r.ctx, st, (const T *)r.st.P[ip], (T *)r.st.P[ip ^ 1], (T *)r.st.D[idd],
                                     (const T *)r.st.R, &pe, a, b);
         return e == hipSuccess ? NS3D_OK : fail(NS3D_ERR_HIP, "slab sweep launch: %s", hipGetErrorString(e));
     };
     int rc;
+    const bool split = m->P > 1 && !m->serial_seams;
     for (size_t l = 0; l < m->loc.size(); ++l) {
         MRank &r = m->loc[l];
         const Ext<T> e(m, r);
         const int np = m->G + 1;                                    // planes the neighbour needs
         rng[l].lo_end = has_lower(m, r) ? std::min(e.k0 + np, e.k1) : e.k0;
         rng[l].hi_beg = has_upper(m, r) ? std::max(e.k1 - np, rng[l].lo_end) : e.k1;
-        if ((rc = sweep(r, e.k0, rng[l].lo_end))) return rc;
-        if ((rc = sweep(r, rng[l].hi_beg, e.k1))) return rc;
+        hipStream_t seam = compute(r);
+        if (split) {
+            ns3d_device_guard g(r.device);
+            HIPCHK(0, hipEventRecord(r.ev_pass, compute(r)));
+            HIPCHK(0, hipStreamWaitEvent(r.comm, r.ev_pass, 0));
+            seam = r.comm;
+        }
+        if ((rc = sweep(r, seam, e.k0, rng[l].lo_end))) return rc;
+        if ((rc = sweep(r, seam, rng[l].hi_beg, e.k1))) return rc;
     }
     std::vector<std::vector<Block>> blocks;
     for (MRank &r : m->loc) blocks.push_back(ghost_blocks<T>(m, r, ip ^ 1, idd_out));
-    if ((rc = exchange_begin(m, blocks))) return rc;
+    if ((rc = exchange_begin(m, blocks, 2, split))) return rc;
     for (size_t l = 0; l < m->loc.size(); ++l)
-        if ((rc = sweep(m->loc[l], rng[l].lo_end, rng[l].hi_beg))) return rc;
+        if ((rc = sweep(m->loc[l], compute(m->loc[l]), rng[l].lo_end, rng[l].hi_beg))) return rc;
     if ((rc = exchange_end(m))) return rc;
     for (MRank &r : m->loc) { r.st.ip = ip ^ 1; r.st.id = idd_out; }
     return NS3D_OK;
@@ -464,15 +485,17 @@ int slab_load(ns3d_mgpu *m, const T *const *Pr, const T *const *D, const T *cons
             HIPCHK(0, hipStreamSynchronize(r.comm));
             free_slab(r);
             for (int q = 0; q < 2; ++q) {
-                HIPCHK(0, hipMalloc(&r.st.P[q], bp));
-                HIPCHK(0, hipMalloc(&r.st.D[q], bd));
-                HIPCHK(0, hipMemsetAsync(r.st.P[q], 0, bp, s));
-                HIPCHK(0, hipMemsetAsync(r.st.D[q], 0, bd, s));
+                HIPCHK(0, hipMalloc(&r.st.Pa[q], bp));
+                HIPCHK(0, hipMalloc(&r.st.Da[q], bd));
+                HIPCHK(0, hipMemsetAsync(r.st.Pa[q], 0, bp, s));
+                HIPCHK(0, hipMemsetAsync(r.st.Da[q], 0, bd, s));
             }
-            HIPCHK(0, hipMalloc(&r.st.R, bp));
-            HIPCHK(0, hipMemsetAsync(r.st.R, 0, bp, s));
+            HIPCHK(0, hipMalloc(&r.st.Ra, bp));
+            HIPCHK(0, hipMemsetAsync(r.st.Ra, 0, bp, s));
             r.st.bytes_P = bp; r.st.bytes_D = bd;
         }
+        for (int q = 0; q < 2; ++q) { r.st.P[q] = r.st.Pa[q]; r.st.D[q] = r.st.Da[q]; }
+        r.st.R = r.st.Ra;
         r.st.glo = e.glo; r.st.ghi = e.ghi; r.st.nze = e.nze; r.st.ip = r.st.id = 0;
         HIPCHK(0, hipMemcpyAsync((T *)r.st.P[0] + e.plane * e.glo, Pr[l], e.plane * e.nz * sizeof(T), hipMemcpyDeviceToDevice, s));
         HIPCHK(0, hipMemcpyAsync((T *)r.st.D[0] + e.dplane * e.glo, D[l], e.dplane * (e.nz - 2) * sizeof(T), hipMemcpyDeviceToDevice, s));
@@ -550,6 +573,27 @@ int slab_plan(ns3d_mgpu *m)
         depth = (int)~r.ctx->key_host[3];
     }
     m->pass_depth = std::max(1, std::min(depth, m->G + 1));
+    // The ghost depth was fixed at load time from the DEEPEST pass allowed (m->depth); when the ranks settle for fewer iterations
+    // per pass (exact-division arithmetic, thin slabs) the outer ghost planes are dead weight: every pass would sweep G+1 seam
+    // planes per side and exchange (G+1) + G planes where pass_depth + (pass_depth−1) suffice.  Dropping them is a change of
+    // base: the buffers keep their allocation, plane 0 moves inwards by the difference on the sides that have a neighbour.
+    const int Gnew = m->pass_depth - 1;
+    if (m->pass_depth >= 2 && Gnew < m->G) {
+        for (MRank &r : m->loc) {
+            const Ext<T> e(m, r);
+            const size_t off = has_lower(m, r) ? (size_t)(m->G - Gnew) : 0;
+            for (int q = 0; q < 2; ++q) {
+                r.st.P[q] = (T *)r.st.P[q] + e.plane * off;
+                r.st.D[q] = (T *)r.st.D[q] + e.dplane * off;
+            }
+            r.st.R = (T *)r.st.R + e.plane * off;
+        }
+        m->G = Gnew;
+        for (MRank &r : m->loc) {
+            const Ext<T> e(m, r);
+            r.st.glo = e.glo; r.st.ghi = e.ghi; r.st.nze = e.nze;
+        }
+    }
     return NS3D_OK;
 }
 
@@ -990,6 +1034,7 @@ void ns3d_mgpu_destroy(ns3d_mgpu *m)
         if (r.cbuf) (void)hipFree(r.cbuf);
         if (r.ev_ready) (void)hipEventDestroy(r.ev_ready);
         if (r.ev_landed) (void)hipEventDestroy(r.ev_landed);
+        if (r.ev_pass) (void)hipEventDestroy(r.ev_pass);
         if (r.comm) (void)hipStreamDestroy(r.comm);
         if (r.ctx) ns3d_destroy(r.ctx);
     }
@@ -1027,6 +1072,7 @@ int ns3d_mgpu_n_g(const ns3d_mgpu *m, int *n_g_out)
 const char *ns3d_mgpu_transport(const ns3d_mgpu *m) { return !m ? "" : (m->rccl ? "rccl" : "peer"); }
 int ns3d_mgpu_rccl_ranks(const ns3d_mgpu *m) { return m ? m->rccl_ranks : -1; }
 int ns3d_mgpu_pass_depth(const ns3d_mgpu *m) { return m ? m->pass_depth : -1; }
+int ns3d_mgpu_ghost_depth(const ns3d_mgpu *m) { return (m && m->loaded) ? m->G : -1; }
 
 int ns3d_mgpu_set_temporal(ns3d_mgpu *m, int depth)
 {

@@ -90,6 +90,7 @@ MGPU_SYMBOLS = {
     "ns3d_mgpu_transport": (C.c_char_p, [_P]),
     "ns3d_mgpu_rccl_ranks": (_I, [_P]),
     "ns3d_mgpu_pass_depth": (_I, [_P]),
+    "ns3d_mgpu_ghost_depth": (_I, [_P]),
     "ns3d_mgpu_sync": (_I, [_P]),
     "ns3d_max_g": (_I, [_P, C.POINTER(_D), C.POINTER(_D)]),
     "ns3d_mgpu_set_temporal": (_I, [_P, _I]),

@@ -218,6 +218,10 @@ class MultiGpu:
     def pass_depth(self):
         return int(self.lib.ns3d_mgpu_pass_depth(self.handle))
 
+    def ghost_depth(self):
+        """Ghost planes per seam of the loaded solve state (pass depth − 1 once ns3d_slab_plan has run)."""
+        return int(self.lib.ns3d_mgpu_ghost_depth(self.handle))
+
     def slab_iterate(self, n):
         L.check(self.lib.ns3d_slab_iterate(self.handle, int(n)))
 

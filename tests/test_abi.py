@@ -133,3 +133,27 @@ def test_header_is_plain_c_and_a_c_host_links(L, tmp_path):
     if not torch.cuda.is_available():
         r = subprocess.run([exe], capture_output=True, text=True)
         assert r.returncode == 3 and "ns3d_create failed" in r.stderr and "no CPU path" in r.stderr
+
+
+def test_fake_rccl_double_exports_what_load_rccl_resolves():
+    """tests/fake_rccl (the test double behind tests/test_gpu_fake_rccl.py) builds here and exports exactly the ten nccl* symbols
+    ns3d_mgpu.cpp's load_rccl() resolves with dlsym — read from the source, so the two cannot drift apart."""
+    import ctypes
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "navierstokes3d_amd", "csrc", "ns3d_mgpu.cpp")).read()
+    m = re.search(r"SYM\(GetUniqueId\)(.*?)#undef SYM", src, re.S)
+    names = ["ncclGetUniqueId"] + ["nccl" + n for n in re.findall(r"SYM\((\w+)\)", m.group(1))]
+    assert len(names) == 10
+    so = os.path.join(root, "tests", "fake_rccl", "libfake_rccl.so")
+    cpp = os.path.join(root, "tests", "fake_rccl", "fake_rccl.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(cpp):
+        subprocess.check_call(["hipcc", "-O2", "-shared", "-fPIC", "-std=c++17", cpp, "-o", so, "-lrt", "-lpthread"])
+    import torch  # noqa: F401 — the HIP runtime the double links against is the one PyTorch ships
+    lib = ctypes.CDLL(so)
+    for n in names:
+        assert hasattr(lib, n), n
+    buf = ctypes.create_string_buffer(128)
+    assert lib.ncclGetUniqueId(buf) == 0 and buf.raw.startswith(b"/fake_rccl_")
+    assert lib.fake_rccl_marker() == 1

@@ -141,6 +141,44 @@ def test_slab_state_equals_global_solve(hip, P, depth, shape, n_iters, dtype):
     mg.close()
 
 
+@pytest.mark.parametrize("P,shape,pass_depth,n_iters", [(2, (40, 21, 10), 2, 9), (3, (70, 12, 7), 2, 7), (3, (33, 9, 9), 3, 10),
+                                                       (4, (24, 15, 6), 0, 8)])
+def test_ghost_depth_follows_the_planned_pass_depth(hip, P, shape, pass_depth, n_iters):
+    """ADVICE r2: the state is loaded with ghosts for the deepest pass allowed (set_temporal(4): three ghost planes per seam);
+    when the ranks then settle for fewer iterations per pass (forced here through the contexts; 0 = whatever the planner says on
+    a grid this small: two) ns3d_slab_plan drops the outer ghost planes — thinner seam sweeps, pass_depth + pass_depth − 1 planes
+    per exchange — and the iterates stay those of the single-device solve of the global grid, bit for bit."""
+    nx, ny, nz = shape
+    nz_g = P * (nz - 2) + 2
+    g = geometry(nx, ny, nz_g)
+    Pg, Dg, Rg = fields(nx, ny, nz_g, ["c", "i", "c"], 977)
+    bc = (True, 0.25, 0.0)
+    Pref, Dref = _global_solve(hip, Pg, Dg, Rg, g, n_iters, bc, np.float64)
+    mg = _mg(P, nx, ny, nz)
+    mg.set_temporal(4)
+    for c in mg.contexts:
+        c.set_pt_depth(pass_depth)
+    Pr = [hip.from_numpy(Pg[:, :, r * (nz - 2):r * (nz - 2) + nz]) for r in range(P)]
+    D = [hip.from_numpy(Dg[:, :, r * (nz - 2):r * (nz - 2) + nz - 2]) for r in range(P)]
+    R = [hip.from_numpy(Rg[:, :, r * (nz - 2):r * (nz - 2) + nz]) for r in range(P)]
+    p = hip.pt_params(Pr[0], g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, *bc)
+    mg.slab_load(Pr, D, R, p)
+    assert mg.ghost_depth() == min(4, nz - 2) - 1
+    planned = mg.slab_plan()
+    assert planned == (pass_depth if pass_depth else 2) and mg.ghost_depth() == planned - 1
+    mg.slab_iterate(n_iters)
+    assert mg.slab_plan() == planned and mg.ghost_depth() == planned - 1          # planning again changes nothing
+    mg.slab_iterate(1)
+    mg.slab_store(Pr, D)
+    mg.sync()
+    Pref, Dref = _global_solve(hip, Pg, Dg, Rg, g, n_iters + 1, bc, np.float64)
+    for r in range(P):
+        lo = r * (nz - 2)
+        assert np.array_equal(hip.to_numpy(Pr[r]), Pref[:, :, lo:lo + nz]), "Pr of rank %d" % r
+        assert np.array_equal(hip.to_numpy(D[r]), Dref[:, :, lo:lo + nz - 2]), "dPrdτ of rank %d" % r
+    mg.close()
+
+
 @pytest.mark.parametrize("P", [2, 3])
 def test_pt_solve_slab_equals_global_pt_solve(hip, oracle, P):
     """ns3d_pt_solve_slab = the whole inner loop multi.jl:458-471 over the ranks: same iteration count, same error history
