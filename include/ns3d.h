@@ -179,6 +179,21 @@ typedef struct ns3d_pt_params {
     int ns3d_advect_##S(ns3d_ctx *, T *Vx, const T *Vx_o, T *Vy, const T *Vy_o, T *Vz, const T *Vz_o, T *C,  \
                         const T *C_o, double dt, double dx, double dy, double dz, int nx, int ny, int nz,    \
                         int faithful);                                                                       \
+    /* {Vx_o .= Vx; Vy_o .= Vy; Vz_o .= Vz; C_o .= C; advect!(…)}  multi.jl:475-476 / gpu.jl:141-142 in ONE pass: the caller    \
+     * passes the CURRENT fields (read only) and receives COMPLETE new fields in buffers of its own — every entry is stored, the \
+     * ones advect! leaves alone with the current value — and swaps the roles of the buffers afterwards (the four    \
+     * copies are "avoidable by pointer swap").  Vz_new may be Vz itself in faithful mode (Vz is never advected there).  Same    \
+     * values as ns3d_copy ×4 + ns3d_advect, bit for bit. */                                                 \
+    int ns3d_copy_advect_##S(ns3d_ctx *, T *Vx_new, const T *Vx, T *Vy_new, const T *Vy, T *Vz_new, const T *Vz, T *C_new, \
+                             const T *C, double dt, double dx, double dy, double dz, int nx, int ny, int nz, \
+                             int faithful);                                                                  \
+    /* DIRECT solve of what the pseudo-transient loop multi.jl:458-471 / gpu.jl:126-137 iterates towards (an   \
+     * option OUTSIDE parity: the reference stops at err < 1e-3, this solves the same discrete system to rounding): Pr's      \
+     * interior becomes the solution of ∇²_h Pr = ρ/dt·∇V with the boundary cells of set_bc_Pr! (p->bc_kind, p->owns_outlet,  \
+     * p->outlet_val, p->g), the boundary cells are set accordingly, dPrdτ = 0.  Exact diagonalisation of the box Laplacian   \
+     * (closed-form eigenvectors per direction) by six fp64 MFMA matrix products; fp32 fields are solved in fp64.  Single-rank \
+     * grids (no z halo flags).  All-Neumann problems (no outlet): the zero-mean solution. */                \
+    int ns3d_poisson_direct_##S(ns3d_ctx *, T *Pr, T *dPrdtau, const T *divV, const ns3d_pt_params *p);      \
     /* ---- host sequences of the reference, one call each ---- */                                           \
     /* set_bc_Pr!  multi.jl:175-181 (kind 0, without the halo update) / gpu.jl:281-286 (kind 1) */           \
     int ns3d_set_bc_Pr_##S(ns3d_ctx *, T *Pr, int bc_kind, int owns_outlet, double outlet_val, double dz,    \

@@ -25,6 +25,7 @@ UNITS = [
     ("ns3d_kernels.hip", "ns3d_kernels_strictx.o", ["-DNS3D_MODE_STRICT", "-DNS3D_EXACT_RECIP", "-ffp-contract=off"]),
     ("ns3d_kernels.hip", "ns3d_kernels_strictp.o", ["-DNS3D_MODE_STRICT", "-DNS3D_POW2_RECIP", "-ffp-contract=off"]),
     ("ns3d_kernels.hip", "ns3d_kernels_fast.o", ["-DNS3D_MODE_FAST", "-ffp-contract=fast"]),
+    ("ns3d_direct.hip", "ns3d_direct.o", []),
     ("ns3d_api.cpp", "ns3d_api.o", ["-x", "hip"]),
     ("ns3d_mgpu.cpp", "ns3d_mgpu.o", ["-x", "hip"]),
 ]

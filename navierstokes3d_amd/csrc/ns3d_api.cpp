@@ -142,6 +142,7 @@ void ns3d_destroy(ns3d_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     c->clear_graphs();
+    if (c->direct_plan && c->direct_free) c->direct_free(c->direct_plan);
     if (c->fence) (void)hipEventDestroy(c->fence);
     for (int q = 0; q < 2; ++q)
         if (c->tune_ev[q]) (void)hipEventDestroy(c->tune_ev[q]);
@@ -849,7 +850,18 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
     {                                                                                                        \
         CHECK_CTX(c); CHECK_PTRS(Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, C, C_o); CHECK_GRID(nx, ny, nz, 1);           \
         return finish(c, DISPATCHG(c, dx, dy, dz, advect<T>(c->stream, Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, C, C_o, dt, dx, dy,  \
-                                               dz, nx, ny, nz, faithful)), "advect");                        \
+                                               dz, nx, ny, nz, faithful ? 1 : 0)), "advect");                        \
+    }                                                                                                        \
+    extern "C" int ns3d_copy_advect_##S(ns3d_ctx *c, T *Vx_new, const T *Vx, T *Vy_new, const T *Vy, T *Vz_new, \
+                                        const T *Vz, T *C_new, const T *C, double dt, double dx, double dy,  \
+                                        double dz, int nx, int ny, int nz, int faithful)                     \
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(Vx_new, Vx, Vy_new, Vy, Vz_new, Vz, C_new, C); CHECK_GRID(nx, ny, nz, 1);   \
+        if (Vx_new == Vx || Vy_new == Vy || C_new == C || (!faithful && Vz_new == Vz))                       \
+            return fail(NS3D_ERR_ARG, "ns3d_copy_advect: outputs must be buffers of their own (only Vz_new may be Vz, and only " \
+                                      "in faithful mode, where Vz is never advected)");                      \
+        return finish(c, DISPATCHG(c, dx, dy, dz, advect<T>(c->stream, Vx_new, Vx, Vy_new, Vy, Vz_new, Vz, C_new, C, dt, dx, dy, \
+                                               dz, nx, ny, nz, (faithful ? 1 : 0) | 2)), "copy_advect");     \
     }                                                                                                        \
     extern "C" int ns3d_set_bc_Pr_##S(ns3d_ctx *c, T *Pr, int bc_kind, int owns_outlet, double outlet_val,   \
                                       double dz, int nz_arg, double g, double rho, int nx, int ny, int nz)   \

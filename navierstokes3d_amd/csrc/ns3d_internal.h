@@ -41,6 +41,8 @@ struct ns3d_ctx {
         hipGraphExec_t exec;
     };
     std::vector<BlockGraph> graphs;
+    void *direct_plan = nullptr;            // ns3d_direct.hip: eigenvector matrices and scratch of the direct Poisson solve
+    void (*direct_free)(void *) = nullptr;
     void clear_graphs()
     {
         for (auto &g : graphs) (void)hipGraphExecDestroy(g.exec);

@@ -680,8 +680,9 @@ __global__ __launch_bounds__(256) void k_advect(T *__restrict__ Vx, const T *__r
                                                 const T *__restrict__ Vy_o, T *__restrict__ Vz,
                                                 const T *__restrict__ Vz_o, T *__restrict__ C,
                                                 const T *__restrict__ C_o, T dt, Geo<T> g, int nx, int ny, int nz,
-                                                int faithful)
+                                                int flags)
 {
+    const int faithful = flags & 1, through = flags & 2;     // through: see advect() below
     const int ix = blockIdx.x * blockDim.x + threadIdx.x + 1;
     const int iy = blockIdx.y * blockDim.y + threadIdx.y + 1;
     const int iz = blockIdx.z * blockDim.z + threadIdx.z + 1;
@@ -711,21 +712,26 @@ __global__ __launch_bounds__(256) void k_advect(T *__restrict__ Vx, const T *__r
         if (faithful) backtrack<T>(Vy, Vy_o, cx, cy, cz, dt, g, ix, iy, iz, nx, ny + 1, nz);
         else backtrack<T>(Vz, Vz_o, cx, cy, cz, dt, g, ix, iy, iz, nx, ny, nz + 1);
         backtrack<T>(C, C_o, ex, ey, ez, dt, g, ix, iy, iz, nx, ny, nz);
+        if (through && faithful && Vz != Vz_o) Vz[IX3(ix - 1, iy - 1, iz - 1, nx, ny)] = VZO(ix, iy, iz);
         return;
     }
+    bool wx_ = false, wy_ = false, wz_ = false;
     if (ix > 1 && ix < nx + 1 && iy <= ny && iz <= nz) { // multi.jl:218-223
+        wx_ = true;
         vxc = VXO(ix, iy, iz);
         vyc = (T)0.25 * (((VYO(ix - 1, iy, iz) + VYO(ix - 1, iy + 1, iz)) + VYO(ix, iy, iz)) + VYO(ix, iy + 1, iz));
         vzc = (T)0.25 * (((VZO(ix - 1, iy, iz) + VZO(ix - 1, iy, iz + 1)) + VZO(ix, iy, iz)) + VZO(ix, iy, iz + 1));
         backtrack<T>(Vx, Vx_o, vxc, vyc, vzc, dt, g, ix, iy, iz, nx + 1, ny, nz);
     }
     if (iy > 1 && iy < ny + 1 && ix <= nx && iz <= nz) { // multi.jl:224-229
+        wy_ = true;
         vxc = (T)0.25 * (((VXO(ix, iy - 1, iz) + VXO(ix + 1, iy - 1, iz)) + VXO(ix, iy, iz)) + VXO(ix + 1, iy, iz));
         vyc = VYO(ix, iy, iz);
         vzc = (T)0.25 * (((VZO(ix, iy - 1, iz) + VZO(ix, iy - 1, iz + 1)) + VZO(ix, iy, iz)) + VZO(ix, iy, iz + 1));
         backtrack<T>(Vy, Vy_o, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny + 1, nz);
     }
     if (iz > 1 && iz < nz + 1 && ix <= nx && iy <= ny) { // multi.jl:230-235
+        if (faithful) wy_ = true; else wz_ = true;
         vxc = (T)0.25 * (((VXO(ix, iy, iz - 1) + VXO(ix + 1, iy, iz - 1)) + VXO(ix, iy, iz)) + VXO(ix + 1, iy, iz));
         vyc = (T)0.25 * (((VYO(ix, iy, iz - 1) + VYO(ix, iy + 1, iz - 1)) + VYO(ix, iy, iz)) + VYO(ix, iy + 1, iz));
         vzc = VZO(ix, iy, iz);
@@ -739,6 +745,11 @@ __global__ __launch_bounds__(256) void k_advect(T *__restrict__ Vx, const T *__r
         vyc = (T)0.5 * (VYO(ix, iy, iz) + VYO(ix, iy + 1, iz));
         vzc = (T)0.5 * (VZO(ix, iy, iz) + VZO(ix, iy, iz + 1));
         backtrack<T>(C, C_o, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny, nz);
+    }
+    if (through) {      // the entries no branch stores keep their old values: written through, so that the outputs are complete
+        if (!wx_ && iy <= ny && iz <= nz) Vx[IX3(ix - 1, iy - 1, iz - 1, nx + 1, ny)] = VXO(ix, iy, iz);
+        if (!wy_ && ix <= nx && iz <= nz) Vy[IX3(ix - 1, iy - 1, iz - 1, nx, ny + 1)] = VYO(ix, iy, iz);
+        if (!wz_ && Vz != Vz_o && ix <= nx && iy <= ny) Vz[IX3(ix - 1, iy - 1, iz - 1, nx, ny)] = VZO(ix, iy, iz);
     }
 #undef VXO
 #undef VYO
@@ -780,6 +791,11 @@ struct AdvWin {
         const int off = d == 0 ? so[0] : d == 1 ? so[1] : d == 2 ? so[2] : so[3];
         return L[a * (NSLOT * PLANE) + off + (j - (y0 - 1)) * WX + (i - (x0 - 1))];
     }
+    __device__ __forceinline__ int slot_off(int k) const
+    {
+        const int d = k - (iz - 1);
+        return d == 0 ? so[0] : d == 1 ? so[1] : d == 2 ? so[2] : so[3];
+    }
     __device__ __forceinline__ bool holds(int i1, int i2, int j1, int j2, int k1, int k2) const
     {
         return (i1 >= x0 - 1) & (i2 <= x0 + TX + 1) & (j1 >= y0 - 1) & (j2 <= y0 + TY + 1) & (k1 >= iz - 1) & (k2 <= iz + 2);   // 67 × 11 × 4
@@ -803,8 +819,13 @@ __device__ __forceinline__ void backtrack_win(T *__restrict__ A, const T *__rest
     const T wz = (ddz > (T)0 ? (T)1 : (T)0) - fmod1(ddz);
     T v111, v211, v112, v212, v121, v221, v122, v222;      // A_o[ix·, iy·, iz·]
     if (w.holds(ix1, ix2, iy1, iy2, iz1, iz2)) {
-        v111 = w.get(a, ix1, iy1, iz1); v211 = w.get(a, ix2, iy1, iz1); v112 = w.get(a, ix1, iy1, iz2); v212 = w.get(a, ix2, iy1, iz2);
-        v121 = w.get(a, ix1, iy2, iz1); v221 = w.get(a, ix2, iy2, iz1); v122 = w.get(a, ix1, iy2, iz2); v222 = w.get(a, ix2, iy2, iz2);
+        // one base address and three deltas instead of eight full index computations (two ring-slot look-ups instead of eight)
+        const int o1 = w.slot_off(iz1), o2 = w.slot_off(iz2);
+        const int base = a * (AdvWin<T>::NSLOT * AdvWin<T>::PLANE) + (iy1 - (w.y0 - 1)) * AdvWin<T>::WX + (ix1 - (w.x0 - 1));
+        const int ex = ix2 - ix1, ey = (iy2 - iy1) * AdvWin<T>::WX;          // 0 where the clamp at the array end bites
+        typename AdvWin<T>::lds_ptr q1 = w.L + base + o1, q2 = w.L + base + o2;
+        v111 = q1[0]; v211 = q1[ex]; v121 = q1[ey]; v221 = q1[ey + ex];
+        v112 = q2[0]; v212 = q2[ex]; v122 = q2[ey]; v222 = q2[ey + ex];
     } else {
 #define AO(i_, j_, k_) A_o[IX3((i_)-1, (j_)-1, (k_)-1, sx, sy)]
         v111 = AO(ix1, iy1, iz1); v211 = AO(ix2, iy1, iz1); v112 = AO(ix1, iy1, iz2); v212 = AO(ix2, iy1, iz2);
@@ -824,9 +845,10 @@ template <class T>
 __global__ __launch_bounds__(512) void k_advect_win(T *__restrict__ Vx, const T *__restrict__ Vx_o, T *__restrict__ Vy,
                                                     const T *__restrict__ Vy_o, T *__restrict__ Vz, const T *__restrict__ Vz_o,
                                                     T *__restrict__ C, const T *__restrict__ C_o, T dt, Geo<T> g, int nx, int ny,
-                                                    int nz, int faithful, int kz)
+                                                    int nz, int flags, int kz)
 {
     typedef AdvWin<T> W;
+    const int faithful = flags & 1, through = flags & 2;
     extern __shared__ __align__(16) unsigned char advect_lds_raw[];
     T *L = reinterpret_cast<T *>(advect_lds_raw);
     const int tid = threadIdx.y * W::TX + threadIdx.x;
@@ -878,19 +900,23 @@ __global__ __launch_bounds__(512) void k_advect_win(T *__restrict__ Vx, const T 
         w.set_plane(iz);
         if (ix <= nx + 1 && iy <= ny + 1) {
             T vxc, vyc, vzc;
+            bool wx_ = false, wy_ = false, wz_ = false;
             if (ix > 1 && ix < nx + 1 && iy <= ny && iz <= nz) { // multi.jl:218-223
+                wx_ = true;
                 vxc = VXO(ix, iy, iz);
                 vyc = (T)0.25 * (((VYO(ix - 1, iy, iz) + VYO(ix - 1, iy + 1, iz)) + VYO(ix, iy, iz)) + VYO(ix, iy + 1, iz));
                 vzc = (T)0.25 * (((VZO(ix - 1, iy, iz) + VZO(ix - 1, iy, iz + 1)) + VZO(ix, iy, iz)) + VZO(ix, iy, iz + 1));
                 backtrack_win<T>(Vx, Vx_o, w, 0, vxc, vyc, vzc, dt, g, ix, iy, iz, nx + 1, ny, nz);
             }
             if (iy > 1 && iy < ny + 1 && ix <= nx && iz <= nz) { // multi.jl:224-229
+                wy_ = true;
                 vxc = (T)0.25 * (((VXO(ix, iy - 1, iz) + VXO(ix + 1, iy - 1, iz)) + VXO(ix, iy, iz)) + VXO(ix + 1, iy, iz));
                 vyc = VYO(ix, iy, iz);
                 vzc = (T)0.25 * (((VZO(ix, iy - 1, iz) + VZO(ix, iy - 1, iz + 1)) + VZO(ix, iy, iz)) + VZO(ix, iy, iz + 1));
                 backtrack_win<T>(Vy, Vy_o, w, 1, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny + 1, nz);
             }
             if (iz > 1 && iz < nz + 1 && ix <= nx && iy <= ny) { // multi.jl:230-235 (sic: back-tracks Vy again in the reference)
+                if (faithful) wy_ = true; else wz_ = true;
                 vxc = (T)0.25 * (((VXO(ix, iy, iz - 1) + VXO(ix + 1, iy, iz - 1)) + VXO(ix, iy, iz)) + VXO(ix + 1, iy, iz));
                 vyc = (T)0.25 * (((VYO(ix, iy, iz - 1) + VYO(ix, iy + 1, iz - 1)) + VYO(ix, iy, iz)) + VYO(ix, iy + 1, iz));
                 vzc = VZO(ix, iy, iz);
@@ -903,6 +929,11 @@ __global__ __launch_bounds__(512) void k_advect_win(T *__restrict__ Vx, const T 
                 vzc = (T)0.5 * (VZO(ix, iy, iz) + VZO(ix, iy, iz + 1));
                 backtrack_win<T>(C, C_o, w, 3, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny, nz);
             }
+            if (through) {      // entries no branch stores: old value written through (complete outputs, see advect())
+                if (!wx_ && iy <= ny && iz <= nz) Vx[IX3(ix - 1, iy - 1, iz - 1, nx + 1, ny)] = VXO(ix, iy, iz);
+                if (!wy_ && ix <= nx && iz <= nz) Vy[IX3(ix - 1, iy - 1, iz - 1, nx, ny + 1)] = VYO(ix, iy, iz);
+                if (!wz_ && Vz != Vz_o && ix <= nx && iy <= ny) Vz[IX3(ix - 1, iy - 1, iz - 1, nx, ny)] = VZO(ix, iy, iz);
+            }
         }
         publish(iz + 3, nxt);
         __syncthreads();
@@ -912,11 +943,16 @@ __global__ __launch_bounds__(512) void k_advect_win(T *__restrict__ Vx, const T 
 #undef VZO
 }
 
+// faithful: bit 0 = the reference's third branch (back-tracks Vy again, never Vz); bit 1 = WRITE-THROUGH: every entry of Vx, Vy,
+// C (and of Vz unless Vz == Vz_o) is stored — the entries advect! leaves alone with the old field's value — so that
+// {X_o .= X; advect!} (multi.jl:475-476) becomes ONE pass with the roles of the buffers swapped afterwards instead of four
+// copies plus one pass ("avoidable by pointer swap").  Same values bit for bit.
 template <class T>
 hipError_t advect(hipStream_t s, T *Vx, const T *Vx_o, T *Vy, const T *Vy_o, T *Vz, const T *Vz_o, T *C,
                   const T *C_o, double dt, double dx, double dy, double dz, int nx, int ny, int nz, int faithful)
 {
-    static const bool windowed = !(std::getenv("NS3D_ADVECT_GLOBAL") && *std::getenv("NS3D_ADVECT_GLOBAL") == '1');
+    const char *glob = std::getenv("NS3D_ADVECT_GLOBAL");       // once per time step: read per call (A/B and tests flip it)
+    const bool windowed = !(glob && *glob == '1');
     if (!windowed) {                                        // the one-thread-per-cell global gather (A/B, fallback)
         hipLaunchKernelGGL(k_advect<T>, grid3(nx + 1, ny + 1, nz + 1, BLK3), BLK3, 0, s, Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, C,
                            C_o, (T)dt, make_geo<T>(dx, dy, dz), nx, ny, nz, faithful);

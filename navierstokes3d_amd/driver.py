@@ -136,14 +136,19 @@ def pt_loop_fused_slab(ctx, grid, f, p, pt, niter, do_print=False, scratch=None)
 
 def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=10, *, mode="strict", fused=True,
                        temporal=True, dtype=torch.float64, faithful=True, grid=None, device=None, niter_cap=None,
-                       return_info=False, shape=None):
+                       return_info=False, shape=None, pressure="pt"):
     """run_navierstokes3D (multi.jl:287-536).  nx is the LOCAL streamwise size (ny = nz = ceil(0.6 nx) local).
     `grid` decides the decomposition: None = one rank; a halo.ZSlabGrid = this process is one z-slab rank of an
     initialised torch.distributed group; a mgpu.MgpuGrid = the C-ABI grid (this process drives every local rank of an
     ns3d_mgpu: all P of them in the one-process form, one under RCCL) — z-slabs, or any Cartesian topology with
     fused=False (ImplicitGlobalGrid's own default is MultiGpu.dims_create(P), e.g. (2,2,2) for 8 ranks).
     `shape` (dict: ny, nz, ly_lx, lz_lx) overrides the literals multi.jl:302-303,323-324 for grids the reference cannot
-    produce without editing them (BASELINE configs[3]: 512×512×1024 global)."""
+    produce without editing them (BASELINE configs[3]: 512×512×1024 global).
+    pressure="direct" (OUTSIDE PARITY; one rank): the inner loop :458-471 is replaced by ns3d_poisson_direct, the
+    exact solution of the discrete problem that loop stops short of by εit; info.iters is 0 per step and info.errs holds the
+    residual of the solution in the reference's own measure (:466)."""
+    if pressure not in ("pt", "direct"):
+        raise L.Ns3dError("pressure = %r (\"pt\" | \"direct\")" % (pressure,))
     if device is None:
         device = torch.cuda.current_device()
     shape = dict(shape or {})
@@ -229,7 +234,12 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
         if root and do_print:
             print("#it = %d" % it)                                                            # :456
         show = (lambda i, e: print("  #iter = %d, err = %1.3e" % (i, e))) if (root and do_print) else None
-        if not fused:                                                                         # :458-471
+        if pressure == "direct":
+            if P != 1:
+                raise L.Ns3dError("pressure=\"direct\" solves a single rank's closed problem (P = %d ranks here)" % P)
+            K.poisson_direct(fs[0].Pr, fs[0].dPrdtau, fs[0].divV, pts[0], ctx=ctxs[0])
+            done, errs = 0, [K.residual_max(fs[0].Pr, fs[0].divV, pts[0], ctx=ctxs[0]) * (p.ly * p.ly) / p.psc]
+        elif not fused:                                                                       # :458-471
             done, errs = pt_loop_reference(ctxs, grid, fs, ps, niter, do_print)
         elif P == 1:
             done, errs = K.pt_solve(fs[0].Pr, fs[0].dPrdtau, fs[0].divV, pts[0], p.eps, niter, p.nchk, p.ly * p.ly, p.psc,
@@ -255,6 +265,9 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
             K.set_bc_Vel_multi(f.Vx, f.Vy, f.Vz, q.owns_inlet, p.vin, ctx=c)                   # :474 → :157-166
         grid.update_halo(col("Vx"), col("Vy"), col("Vz"))                                     # :167
         for f, c in zip(fs, ctxs):
+            if fused:       # :475-476 in one pass (ns3d_copy_advect): complete new fields into the *_o buffers, then the roles swap
+                _copy_advect_swap(f, p, faithful, c)
+                continue
             K.copy(f.Vx_o, f.Vx, ctx=c); K.copy(f.Vy_o, f.Vy, ctx=c)                          # :475
             K.copy(f.Vz_o, f.Vz, ctx=c); K.copy(f.C_o, f.C, ctx=c)
             K.advect(f.Vx, f.Vx_o, f.Vy, f.Vy_o, f.Vz, f.Vz_o, f.C, f.C_o, p.dt, p.dx, p.dy, p.dz, faithful, ctx=c)  # :476
@@ -267,12 +280,29 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
             if do_save and it % nsave == 0:                                                   # :515-522
                 _save_frame(grid, gathered, iframe)
             iframe += 1
+    if fused and faithful and nt > 0:
+        for f, c in zip(fs, ctxs):
+            K.copy(f.Vz_o, f.Vz, ctx=c)     # the one copy of :475 the swaps skipped (Vz is never advected): same final state
     sync()
     out = _gather_all(grid, fs)                                                               # :528-532
     info.fields = fs[0]
     info.local_fields = fs
     info.ctx = ctxs[0]
     return out + ((info,) if return_info else ())                                             # :535
+
+
+def _copy_advect_swap(f, p, faithful, ctx):
+    """{Vx_o,Vy_o,Vz_o,C_o .= Vx,Vy,Vz,C; advect!} (multi.jl:475-476 / gpu.jl:141-142) without the four copies:
+    ns3d_copy_advect reads the current fields and writes COMPLETE new ones into the *_o buffers, then the names swap — X is
+    the advected field and X_o the previous one, exactly what the copies leave behind.  Vz is never advected in faithful
+    mode (App. B1): it stays where it is, and Vz_o is brought up to date once at the end of the run."""
+    K.copy_advect(f.Vx_o, f.Vx, f.Vy_o, f.Vy, f.Vz if faithful else f.Vz_o, f.Vz, f.C_o, f.C, p.dt, p.dx, p.dy, p.dz, faithful,
+                  ctx=ctx)
+    f.Vx, f.Vx_o = f.Vx_o, f.Vx
+    f.Vy, f.Vy_o = f.Vy_o, f.Vy
+    f.C, f.C_o = f.C_o, f.C
+    if not faithful:
+        f.Vz, f.Vz_o = f.Vz_o, f.Vz
 
 
 def gpu_initial_fields(p):
@@ -302,7 +332,7 @@ def _save_mat(path, f, p, step0):
 
 
 def runme(do_vis=False, do_save=False, *, nx=255, nt=10000, mode="strict", fused=True, dtype=torch.float64,
-          faithful=True, device=None, niter_cap=None, do_print=False, initial=None):
+          faithful=True, device=None, niter_cap=None, do_print=False, initial=None, pressure="pt"):
     """runme (gpu.jl:12-173): single device, gravity, hydrostatic x-planes.  Returns (fields, info).
     nx/nt are literals in the reference (gpu.jl:44,51: 255, 10000) and keyword options here.  do_save writes the MAT files
     of gpu.jl:89,168-170 (step 0 and every nsave = 10 steps); do_vis the heat maps of gpu.jl:90-117,143-167 (frame 0 and
@@ -340,7 +370,10 @@ def runme(do_vis=False, do_save=False, *, nx=255, nt=10000, mode="strict", fused
         K.update_divV(f.divV, f.Vx, f.Vy, f.Vz, p.dx, p.dy, p.dz, ctx=ctx)                    # :124
         if do_print:
             print("#it = %d" % it)                                                            # :125
-        if fused:
+        if pressure == "direct":        # outside parity: the exact solution of what :126-137 iterates towards
+            K.poisson_direct(f.Pr, f.dPrdtau, f.divV, pt, ctx=ctx)
+            done, errs = 0, [K.residual_max(f.Pr, f.divV, pt, ctx=ctx) * (p.ly * p.ly) / p.psc]
+        elif fused:
             done, errs = K.pt_solve(f.Pr, f.dPrdtau, f.divV, pt, p.eps, niter, p.nchk, p.ly * p.ly, p.psc, ctx=ctx)
         else:
             errs, done = [], niter
@@ -362,9 +395,12 @@ def runme(do_vis=False, do_save=False, *, nx=255, nt=10000, mode="strict", fused
         K.correct_V(f.Vx, f.Vy, f.Vz, f.Pr, p.dt, p.rho, p.dx, p.dy, p.dz, ctx=ctx)            # :138
         K.set_cylinder(f.C, f.Vx, f.Vy, f.Vz, *cyl, ctx=ctx)                                  # :139
         K.set_bc_Vel_gpu(f.Vx, f.Vy, f.Vz, ctx=ctx)                                           # :140
-        K.copy(f.Vx_o, f.Vx, ctx=ctx); K.copy(f.Vy_o, f.Vy, ctx=ctx)                          # :141
-        K.copy(f.Vz_o, f.Vz, ctx=ctx); K.copy(f.C_o, f.C, ctx=ctx)
-        K.advect(f.Vx, f.Vx_o, f.Vy, f.Vy_o, f.Vz, f.Vz_o, f.C, f.C_o, p.dt, p.dx, p.dy, p.dz, faithful, ctx=ctx)  # :142
+        if fused:
+            _copy_advect_swap(f, p, faithful, ctx)                                            # :141-142 in one pass
+        else:
+            K.copy(f.Vx_o, f.Vx, ctx=ctx); K.copy(f.Vy_o, f.Vy, ctx=ctx)                      # :141
+            K.copy(f.Vz_o, f.Vz, ctx=ctx); K.copy(f.C_o, f.C, ctx=ctx)
+            K.advect(f.Vx, f.Vx_o, f.Vy, f.Vy_o, f.Vz, f.Vz_o, f.C, f.C_o, p.dt, p.dx, p.dy, p.dz, faithful, ctx=ctx)  # :142
         if do_vis and it % nvis == 0:                                                         # :143-167
             ctx.sync()
             save_frame_gpu(host(), ny, nz, iframe)
@@ -372,6 +408,8 @@ def runme(do_vis=False, do_save=False, *, nx=255, nt=10000, mode="strict", fused
         if do_save and it % nsave == 0:                                                       # :168-170
             ctx.sync()
             _save_mat("out_save/step_%d.mat" % it, f, p, False)
+    if fused and faithful and nt > 0:
+        K.copy(f.Vz_o, f.Vz, ctx=ctx)       # the one copy of :141 the swaps skipped (Vz is never advected): same final state
     ctx.sync()
     info.ctx = ctx
     return f, info

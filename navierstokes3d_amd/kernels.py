@@ -327,6 +327,17 @@ def advect(Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, Cf, C_o, dt, dx, dy, dz, faithful=True,
                        1 if faithful else 0)
 
 
+def copy_advect(Vx_new, Vx, Vy_new, Vy, Vz_new, Vz, C_new, Cf, dt, dx, dy, dz, faithful=True, ctx=None):
+    """{X_o .= X; advect!} (multi.jl:475-476 / gpu.jl:141-142) in one pass: reads the current fields, writes COMPLETE new
+    fields into buffers of their own; the caller swaps the roles afterwards.  Vz_new may be Vz in faithful mode."""
+    nx, ny, nz = Cf.shape
+    _ctx(ctx, Cf).call("copy_advect", Cf, _chk(Vx_new, (nx + 1, ny, nz), "Vx_new"), _chk(Vx, (nx + 1, ny, nz), "Vx"),
+                       _chk(Vy_new, (nx, ny + 1, nz), "Vy_new"), _chk(Vy, (nx, ny + 1, nz), "Vy"),
+                       _chk(Vz_new, (nx, ny, nz + 1), "Vz_new"), _chk(Vz, (nx, ny, nz + 1), "Vz"),
+                       _chk(C_new, (nx, ny, nz), "C_new"), _chk(Cf, None, "C"), *_d(dt, dx, dy, dz), nx, ny, nz,
+                       1 if faithful else 0)
+
+
 # ---- the reference's host sequences, one library call each ----------------------------------------------
 def set_bc_Pr_multi(Pr, owns_outlet, val=0.0, ctx=None):
     """set_bc_Pr!(Pr, xve_g, lx, val) of multi.jl:175-181 with `xve_g == lx/2` passed as a flag; the trailing
@@ -371,6 +382,15 @@ def pt_iterate(Pr, dPrdtau, divV, p, n_iters, ctx=None):
     nx, ny, nz = Pr.shape
     _ctx(ctx, Pr).call("pt_iterate", Pr, _chk(Pr, None, "Pr"), _chk(dPrdtau, (nx - 2, ny - 2, nz - 2), "dPrdtau"),
                        _chk(divV, (nx, ny, nz), "divV"), C.byref(p), int(n_iters))
+
+
+def poisson_direct(Pr, dPrdtau, divV, p, ctx=None):
+    """OUTSIDE PARITY: the discrete pressure-Poisson problem the PT loop multi.jl:458-471 / gpu.jl:126-137 iterates
+    towards, solved directly (exact diagonalisation, six fp64 MFMA matrix products): Pr ← solution with set_bc_Pr!'s boundary
+    cells, dPrdτ ← 0."""
+    nx, ny, nz = Pr.shape
+    _ctx(ctx, Pr).call("poisson_direct", Pr, _chk(Pr, None, "Pr"), _chk(dPrdtau, (nx - 2, ny - 2, nz - 2), "dPrdtau"),
+                       _chk(divV, (nx, ny, nz), "divV"), C.byref(p))
 
 
 def pt_sweep(Pr_in, Pr_out, dPrdtau, divV, p, k0, k1, ctx=None):

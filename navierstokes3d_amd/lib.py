@@ -52,9 +52,11 @@ SIGNATURES = {
     "bc_x_Pr": [_P, _D] + [_I] * 3,
     "copy": [_P, _P, _L],
     "advect": [_P] * 8 + [_D] * 4 + [_I] * 4,
+    "copy_advect": [_P] * 8 + [_D] * 4 + [_I] * 4,
     "set_bc_Pr": [_P, _I, _I, _D, _D, _I, _D, _D] + [_I] * 3,
     "set_bc_Vel": [_P] * 3 + [_I, _I, _D] + [_I] * 3,
     "pt_iterate": [_P] * 3 + [C.POINTER(PtParams), _I],
+    "poisson_direct": [_P] * 3 + [C.POINTER(PtParams)],
     "pt_sweep": [_P] * 4 + [C.POINTER(PtParams), _I, _I],
     "pt_sweep2": [_P] * 5 + [C.POINTER(PtParams), _I, _I],
     "plan_pt": [_P] * 5 + [C.POINTER(PtParams), _I, _I],

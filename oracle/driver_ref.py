@@ -148,7 +148,7 @@ def gather_z(ranks, name):
 
 
 def run_navierstokes3D_ref(nx=63, nt=1, dims_z=1, dtype=np.float64, faithful=True, niter_cap=None,
-                           record=None, shape=None, dims=None):
+                           record=None, shape=None, dims=None, pressure="pt"):
     """multi.jl:287-536 without vis/save.  Returns (C_v,Pr_v,Vx_v,Vy_v,Vz_v, info) where info holds the
     per-step PT iteration counts and err histories, and the final local states."""
     p = multi_params(nx, dims_z, dtype, dims=dims, **(shape or {}))
@@ -201,7 +201,14 @@ def run_navierstokes3D_ref(nx=63, nt=1, dims_z=1, dtype=np.float64, faithful=Tru
             K.update_divV(f.divV, f.Vx, f.Vy, f.Vz, p.dx, p.dy, p.dz)
         update_halo_z(ranks, "divV", nz)                                                   # :455
         errs, iters_done = [], niter
-        if P == 1:
+        if pressure == "direct":        # the option outside parity (oracle/direct_ref.py), one rank
+            from oracle.direct_ref import poisson_direct
+            f = ranks[0]
+            f.Pr[...] = poisson_direct(f.divV, p.rho, p.dt, p.dx, p.dy, p.dz, 0, f.owns_outlet, 0.0, p.g).astype(dtype)
+            f.dPrdtau[...] = 0
+            K.compute_res(f.Rp, f.Pr, f.divV, p.rho, p.dt, p.dx, p.dy, p.dz)
+            iters_done, errs = 0, [K.max_abs(f.Rp) * p.err_scale_num / p.psc]
+        elif P == 1:
             f = ranks[0]
             iters_done, errs = K.pt_solve(f.Pr, f.dPrdtau, f.divV, f.Rp, p.rho, p.dt, p.dtau, p.damp, p.dx,
                                           p.dy, p.dz, 0, f.owns_outlet, 0.0, p.g, p.eps, niter, p.nchk,
@@ -298,7 +305,7 @@ def gpu_initial_fields(p):
     return Vx, Pr
 
 
-def runme_ref(nx=255, nt=1, dtype=np.float64, faithful=True, niter_cap=None):
+def runme_ref(nx=255, nt=1, dtype=np.float64, faithful=True, niter_cap=None, pressure="pt"):
     """gpu.jl:12-173 without vis/save; returns the final local fields + per-step PT info."""
     p = gpu_params(nx, dtype)
     nx, ny, nz = p.nx, p.ny, p.nz
@@ -313,8 +320,15 @@ def runme_ref(nx=255, nt=1, dtype=np.float64, faithful=True, niter_cap=None):
         K.set_cylinder_local(f.C, f.Vx, f.Vy, f.Vz, p.a2, p.b2, p.ox, p.oy, p.sinb, p.cosb, p.lx, p.ly, p.lz,
                              p.dx, p.dy, p.dz)
         K.update_divV(f.divV, f.Vx, f.Vy, f.Vz, p.dx, p.dy, p.dz)
-        iters_done, errs = K.pt_solve(f.Pr, f.dPrdtau, f.divV, f.Rp, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy,
-                                      p.dz, 1, False, 0.0, p.g, p.eps, niter, p.nchk, p.ly * p.ly, p.psc)   # :126-137
+        if pressure == "direct":        # the option outside parity (oracle/direct_ref.py)
+            from oracle.direct_ref import poisson_direct
+            f.Pr[...] = poisson_direct(f.divV, p.rho, p.dt, p.dx, p.dy, p.dz, 1, False, 0.0, p.g).astype(dtype)
+            f.dPrdtau[...] = 0
+            K.compute_res(f.Rp, f.Pr, f.divV, p.rho, p.dt, p.dx, p.dy, p.dz)
+            iters_done, errs = 0, [K.max_abs(f.Rp) * (p.ly * p.ly) / p.psc]
+        else:
+            iters_done, errs = K.pt_solve(f.Pr, f.dPrdtau, f.divV, f.Rp, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy,
+                                          p.dz, 1, False, 0.0, p.g, p.eps, niter, p.nchk, p.ly * p.ly, p.psc)   # :126-137
         info.iters.append(iters_done); info.errs.append(errs)
         K.correct_V(f.Vx, f.Vy, f.Vz, f.Pr, p.dt, p.rho, p.dx, p.dy, p.dz)                 # :138
         K.set_cylinder_local(f.C, f.Vx, f.Vy, f.Vz, p.a2, p.b2, p.ox, p.oy, p.sinb, p.cosb, p.lx, p.ly, p.lz,

@@ -195,6 +195,51 @@ def test_advect_windowed_tiles(hip, oracle, grid, cfl, dtype):
     ctx.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("grid,cfl", [((150, 21, 70), 0.9), ((150, 21, 70), 2.7), ((64, 8, 33), 0.5), ((63, 7, 31), 1.0), ((3, 3, 3), 0.8)])
+def test_copy_advect_equals_four_copies_and_advect(hip, oracle, grid, cfl, dtype, monkeypatch):
+    """ns3d_copy_advect = {X_o .= X; advect!} (multi.jl:475-476) in one pass with the buffers' roles swapped afterwards: the
+    outputs, pre-filled with garbage, must come back COMPLETE — the advected entries and, written through, every entry advect!
+    leaves alone (Vx[1,:,:], Vx[end,:,:], Vy[:,1,1], Vy[:,end,:], all of Vz in faithful mode …) — and equal the oracle's
+    copies + advect bit for bit; windowed and global-gather kernels, both advection modes, Vz passed as its own output where
+    that is allowed."""
+    import torch
+    nx, ny, nz = grid
+    g = geometry(*grid)
+    cur = fields(nx, ny, nz, ["vx", "vy", "vz", "c"], 21, dtype)
+    dt = cfl * min(g["dx"], g["dy"], g["dz"])
+    for windowed in (True, False):
+        ctx = hip.Context(0, "strict")
+        dcur = [hip.from_numpy(a) for a in cur]
+        for faithful in (True, False):
+            old = [a.copy(order="F") for a in cur]                              # X_o .= X
+            ref = [a.copy(order="F") for a in cur]
+            oracle.advect(ref[0], old[0], ref[1], old[1], ref[2], old[2], ref[3], old[3], dt, g["dx"], g["dy"], g["dz"], faithful)
+            new = [hip.from_numpy(np.full_like(a, 777.0)) for a in cur]          # garbage: nothing may survive
+            vz_out = dcur[2] if faithful else new[2]
+            if not windowed:
+                hip.copy_advect(new[0], dcur[0], new[1], dcur[1], new[2], dcur[2], new[3], dcur[3], dt, g["dx"], g["dy"], g["dz"],
+                                faithful, ctx=ctx)                                # Vz_new a buffer of its own in both modes
+                vz_out = new[2]
+            else:
+                hip.copy_advect(new[0], dcur[0], new[1], dcur[1], vz_out, dcur[2], new[3], dcur[3], dt, g["dx"], g["dy"], g["dz"],
+                                faithful, ctx=ctx)
+            torch.cuda.synchronize()
+            got = [new[0], new[1], vz_out, new[3]]
+            for q in range(4):
+                assert np.array_equal(hip.to_numpy(got[q]), ref[q]), "output %d (faithful=%s, windowed=%s)" % (q, faithful, windowed)
+            for a, b in zip(dcur, cur):
+                assert np.array_equal(hip.to_numpy(a), b)                        # the current fields are read only
+        ctx.close()
+        if windowed:
+            monkeypatch.setenv("NS3D_ADVECT_GLOBAL", "1")                        # read once per process: see below
+    from navierstokes3d_amd import lib as L
+    with pytest.raises(L.Ns3dError):
+        hip.copy_advect(dcur[0], dcur[0], new[1], dcur[1], new[2], dcur[2], new[3], dcur[3], dt, g["dx"], g["dy"], g["dz"], True)
+    with pytest.raises(L.Ns3dError):
+        hip.copy_advect(new[0], dcur[0], new[1], dcur[1], dcur[2], dcur[2], new[3], dcur[3], dt, g["dx"], g["dy"], g["dz"], False)
+
+
 def test_advect_integer_cfl_edge(hip, oracle):
     """Positive integer δ: weight 1 with base floor(i−δ) (SURVEY App. A backtrack! edge case)."""
     import torch

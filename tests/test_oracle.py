@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from util import fields, geometry, rnd
+from util import fields, geometry, rel_l2, rnd
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GRIDS = [(17, 9, 5), (24, 15, 15), (5, 4, 3), (70, 6, 7)]
@@ -534,3 +534,43 @@ def test_the_reference_fixture_is_stale_by_the_reference_s_own_text():
     fp = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fp)
     assert fp.ref.shape == (3, 4, 4) and np.abs(fp.ref).min() > 1e-9 and fp.ref[1, 2, 0] == 0.6208831467566082
+
+
+@pytest.mark.parametrize("bc", [(0, True, 0.0), (0, True, 0.75), (0, False, 0.0), (1, False, 0.0)])
+@pytest.mark.parametrize("grid", [(17, 9, 6), (24, 15, 15)])
+def test_direct_pressure_solve_zeroes_the_reference_residual(oracle, grid, bc):
+    """The option outside parity (oracle/direct_ref.py = the NumPy twin of csrc/ns3d_direct.hip): its result makes
+    the REFERENCE's residual compute_res! (multi.jl:88-91) vanish to rounding — with set_bc_Pr!'s boundary cells applied by the
+    oracle's own set_bc_Pr, so a wrong boundary rule, eigenbasis or right-hand-side correction shows at O(1) — and the oracle's
+    PT loop started from it stays there (first check already below 1e-9 of the right-hand side's scale)."""
+    from oracle.direct_ref import poisson_direct
+    nx, ny, nz = grid
+    g = geometry(*grid)
+    bc_kind, owns, val = bc
+    rhs = fields(nx, ny, nz, ["c"], 57)[0]
+    if bc_kind == 0 and not owns:                       # all-Neumann: solvable only for a right-hand side without a mean
+        rhs[1:-1, 1:-1, 1:-1] -= rhs[1:-1, 1:-1, 1:-1].mean()
+    Pr = poisson_direct(rhs, g["rho"], g["dt"], g["dx"], g["dy"], g["dz"], bc_kind, owns, val, g["g"])
+    P2 = Pr.copy(order="F")
+    oracle.set_bc_Pr(P2, bc_kind, owns, val, g["dz"], nz, g["g"], g["rho"])
+    assert np.array_equal(P2, Pr)                        # the boundary cells already are what set_bc_Pr! makes of the interior
+    Rp = np.zeros((nx - 2, ny - 2, nz - 2), order="F")
+    oracle.compute_res(Rp, Pr, rhs, g["rho"], g["dt"], g["dx"], g["dy"], g["dz"])
+    scale = g["rho"] / g["dt"] * np.abs(rhs).max() + np.abs(Pr).max() / min(g["dx"], g["dy"], g["dz"]) ** 2
+    assert np.abs(Rp).max() < 1e-11 * scale, np.abs(Rp).max() / scale
+    if bc_kind == 0 and not owns:
+        assert abs(Pr[1:-1, 1:-1, 1:-1].mean()) < 1e-9 * np.abs(Pr).max()          # the zero-mean solution
+
+
+def test_pt_loop_converges_to_the_direct_solution(oracle):
+    """… and the reference's own iteration, run far below its εit, ends at the direct solution (multi.jl boundary set)."""
+    from oracle.direct_ref import poisson_direct
+    nx, ny, nz = 20, 12, 12
+    dx = 1.0 / nx
+    g = dict(dx=dx, dy=dx, dz=dx, rho=1000.0, dt=dx, dtau=dx / np.sqrt(3.1), damp=2.0 / nx, g=0.0)
+    rhs = fields(nx, ny, nz, ["c"], 58)[0] * 1e-3
+    ref = poisson_direct(rhs, g["rho"], g["dt"], g["dx"], g["dy"], g["dz"], 0, True, 0.0)
+    Pr = np.zeros((nx, ny, nz), order="F"); d = np.zeros((nx - 2, ny - 2, nz - 2), order="F"); Rp = np.zeros_like(d)
+    it, errs = oracle.pt_solve(Pr, d, rhs, Rp, g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, True, 0.0, 0.0,
+                               1e-13, 20000, 50, 1.0, np.abs(ref).max() / dx ** 2)
+    assert it < 20000 and rel_l2(Pr, ref) < 1e-9, (it, rel_l2(Pr, ref))
