@@ -369,12 +369,20 @@ function gather!(A_inn::Array, A_v; root::Integer = 0)
         return nothing
     end
     # ImplicitGlobalGrid requires size(A_v) == dims .* size(A_inn) and errors otherwise; multi.jl's Vz pair (nz-1 planes per
-    # rank into dims[3]·(nz-2)+1) violates that for more than one z rank — the reference itself cannot gather Vz there
+    # rank into dims[3]·(nz-2)+1) violates that for more than one z rank — the reference itself cannot gather Vz there (the
+    # unmodified multi.jl therefore cannot return its staggered fields on more than one rank in the staggered dimension).
+    # The verdict is the ROOT's (only it holds A_v) and every rank must hear it BEFORE the collective: a root that throws while
+    # the others already sit in MPI.Gather! leaves them blocked for good.
+    ok = Ref{Cint}(1)
+    if GRID[].me == root
+        ok[] = size(A_v) == dims .* size(A_inn) ? 1 : 0
+    end
+    MPI.Bcast!(ok, root, MPI.COMM_WORLD)
+    ok[] == 1 || error("gather!: size(A_v) must be dims .* size(A_inn) (rank $(GRID[].me): local block $(size(A_inn)), dims $(dims))")
     if GRID[].me != root
         MPI.Gather!(A_inn, nothing, root, MPI.COMM_WORLD)
         return nothing
     end
-    size(A_v) == dims .* size(A_inn) || error("gather!: size(A_v) must be dims .* size(A_inn)")
     n = length(A_inn)
     if dims[1] == 1 && dims[2] == 1
         MPI.Gather!(A_inn, MPI.UBuffer(vec(A_v), n), root, MPI.COMM_WORLD)

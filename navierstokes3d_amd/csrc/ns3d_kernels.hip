@@ -1968,6 +1968,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
             const int kp = min(max(k1 + 2, 0), nz - 1);
             const int ka = min(max(k1 + 1, 1), nz - 2);
             const T *__restrict__ Pn = P + (idx_t)kp * sz;
+#ifdef NS3D_LOAD_PRIO       // A/B: the waves that are about to issue the next step's loads go first
+            __builtin_amdgcn_s_setprio(3);
+#endif
 #pragma unroll
             for (int r = 0; r < CPT; ++r) {
                 p0n[r] = Pn[poff[r]];
@@ -1977,6 +1980,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
             if (hasA) hAn = Pn[offA];
             if (hasB) hBn = Pn[offB];
             if (hasC) hCn = Pn[offC];
+#ifdef NS3D_LOAD_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         };
         if constexpr (EARLY) issue_next();
         // ---------------- level 1 at plane k1 ----------------
@@ -2202,315 +2208,10 @@ static hipError_t launch_sweepN(hipStream_t s, SweepArgs<T> &a, int kz)
     }
 }
 
-// =========================================================================================================
-// NL PT iterations per pass WITHOUT redundant tiles  —  k_pt_coop  (round 3)
-//
-// k_pt_sweepN pays for keeping its workgroups independent: tiles overlap by 2(NL−1) columns and rows, so at NL = 4 only 68 %
-// of the lanes of a 64×24 tile produce output and the pass fetches 1.4× what it must (the overlap rows rarely hit the L2: the
-// workgroups drift apart in z).  Here the tiles do NOT overlap: the x/y neighbours of level ℓ on a tile's edge come from the
-// NEIGHBOURING WORKGROUP, which publishes the edge rows/columns of every intermediate plane it produces to a small scratch
-// area in global memory (a few MB: it lives in the L2s / the Infinity Cache) — every lane produces output, and a pass moves
-// what it must plus the one-cell ring of P⁰.  For that the workgroups of a launch must be resident together (cooperative
-// launch: tiles ≤ CUs × workgroups per CU; 512²: 8×32 tiles of 64×16 columns = 256 workgroups of 1024 threads, one per CU) and
-// the exchange must never be waited for: level ℓ runs LAG = 3 planes behind level ℓ−1 (k_pt_sweepN: one), so an edge published
-// at the end of step s is fetched during step s+2 and used in step s+3 — two whole steps for the flag and the data to cross
-// the chip, and a neighbour may fall a step behind without stalling anybody.
-//   registers (one column per thread): P⁰[k1−1..k1+1]; ∇V[k1 … k1−LAG(NL−1)]; per level ℓ < NL: Pˡ[kℓ₊₁−1], dˡ of LAG planes
-//   LDS: plane k1 of P⁰ with its ring (double-buffered); per level ℓ < NL the LAG+1 planes of Pˡ in flight, each with its ring
-//        (own values written when produced, ring values when fetched); the own-column z neighbours of level ℓ+1 are read
-//        from there too.  One __syncthreads() per step.
-//   global: H[tile][level][slot s mod 8][S row | N row | W column | E column], flag[tile] = epoch + steps completed.
-// Halo values and flags move as relaxed agent-scope atomics (sc1: coherent across the XCDs' L2s per access, no cache-wide
-// write-back or invalidate); a wave's edge stores are complete (s_waitcnt) before the barrier that precedes the flag store.
-// Every cell is computed by exactly the expression tree of the single sweep: bit-identical to NL k_pt_sweep launches.
-// Spins are bounded: a neighbour that never arrives sets an error word (checked by the launcher under NS3D_COOP_CHECK) and
-// the workgroup runs on, so the grid always drains.
-// =========================================================================================================
-template <class T>
-struct CoopArgs {
-    SweepArgs<T> a;
-    unsigned long long *H;         // halo scratch: two 64-bit words per published element
-    unsigned *err;                 // bit 0: a bounded wait expired
-    unsigned long long epoch;
-    int ntx, nty;
-};
-// A published element is TWO words written and read with relaxed agent-scope atomics (sc1: coherent across the XCDs' L2s per
-// access): w1 = the value's bits, w2 = w1 ^ key(step).  The reader accepts the pair only if w1 ^ w2 is the key of the step it is
-// waiting for — an old pair, or one old and one new word, fails the test — so no flag, no fence and no wait for a store's
-// acknowledgement is needed, and a single round trip fetches an edge (a flag followed by the data would be two in a row).
-__device__ __forceinline__ unsigned long long coop_key(unsigned long long step_id) { return (step_id + 1ull) * 0x9E3779B97F4A7C15ull; }
-__device__ __forceinline__ unsigned long long coop_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
-__device__ __forceinline__ unsigned long long coop_bits(float v) { return (unsigned long long)__float_as_uint(v); }
-__device__ __forceinline__ void coop_unbits(unsigned long long b, double &v) { v = __longlong_as_double((long long)b); }
-__device__ __forceinline__ void coop_unbits(unsigned long long b, float &v) { v = __uint_as_float((unsigned)b); }
-template <class T> __device__ __forceinline__ void coop_publish(unsigned long long *p, T v, unsigned long long key)
-{
-    const unsigned long long w = coop_bits(v);
-    __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(p + 1, w ^ key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <class T, int NL, int TY>
-__global__ __launch_bounds__(64 * TY) void k_pt_coop(CoopArgs<T> ca)
-{
-    constexpr int TX = 64, PX = TX + 2, LAG = 3, NB = LAG + 1, R = 8, EDGE = 2 * TX + 2 * TY, NRQ = LAG * (NL - 1) + 1;
-    static_assert(NL >= 2 && NL <= 4 && TY >= 4 && TY <= 16, "shape");
-    __shared__ T L0[2][(TY + 2) * PX];
-    __shared__ T LN[NL - 1][NB][(TY + 2) * PX];
-    const SweepArgs<T> &a = ca.a;
-    const int nx = a.nx, ny = a.ny, nz = a.nz;
-    const Geo<T> &g = a.g;
-    const int nb = gridDim.x, b = blockIdx.x;
-    const int q = nb >> 3, rem = nb & 7, xcd = b & 7, loc = b >> 3;
-    const int tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
-    const int ntx = ca.ntx, nty = ca.nty;
-    const int tx_t = tile % ntx, ty_t = tile / ntx;
-    const int ox = 1 + tx_t * TX, oy = 1 + ty_t * TY;
-    const int kb = a.k0, ke = a.k1;
-    const int lx = threadIdx.x, ly = threadIdx.y, tid = ly * TX + lx;
-    const int gi = ox + lx, gj = oy + ly;
-    const bool act = (gi <= nx - 2) && (gj <= ny - 2);
-    const int ci = min(gi, nx - 1), cj = min(gj, ny - 1), cii = min(gi, nx - 2), cjj = min(gj, ny - 2);
-    const idx_t sz = (idx_t)nx * ny, dsz = (idx_t)(nx - 2) * (ny - 2);
-    const int poff = cj * nx + ci, roff = cjj * nx + cii, doff = (cjj - 1) * (nx - 2) + (cii - 1);
-    const bool xlo_adj = (gi == 1), xhi_adj = (gi == nx - 2), ylo_adj = (gj == 1), yhi_adj = (gj == ny - 2);
-    const bool has_W = tx_t > 0, has_E = tx_t < ntx - 1, has_S = ty_t > 0, has_N = ty_t < nty - 1;
-    const int ctr = (ly + 1) * PX + lx + 1;
-    // P⁰ ring duties, as in k_pt_sweepN: row below (A), row above (B), the two columns beside the tile (C)
-    const bool hasA = (ly == 0), hasB = (ly == TY - 1), hasC = (tid < 2 * TY);
-    const int offA = (oy - 1) * nx + ci, offB = min(oy + TY, ny - 1) * nx + ci;
-    const int cside = tid / TY, crow = tid % TY;
-    const int offC = min(oy + crow, ny - 1) * nx + (cside ? min(ox + TX, nx - 1) : ox - 1);
-    const int ldsA = lx + 1, ldsB = (TY + 1) * PX + lx + 1, ldsC = (crow + 1) * PX + (cside ? TX + 1 : 0);
-    // Edge duties of the intermediate levels, one element per thread and step each way: thread tid < (NL−1)·EDGE PUBLISHES element
-    // `re` of MY edge block of level rl (read back from the LDS plane written in the previous step) and FETCHES the element of a
-    // neighbour's edge block that lands on the same side's ring cell.  Edge block: [S row | N row | W column | E column].
-    const bool ring = tid < (NL - 1) * EDGE;
-    const int rl = ring ? tid / EDGE : 0, re = ring ? tid % EDGE : 0;
-    int rnb = -1, rsrc = 0, rlds = 0, rown = 0;            // neighbour tile, element of ITS block, my ring cell, my own edge cell
-    bool rpub = false;
-    if (ring) {
-        if (re < TX) { rown = PX + re + 1; rpub = has_S; if (has_S) rnb = tile - ntx; rsrc = TX + re; rlds = re + 1; }                     // S: ring ← its N edge
-        else if (re < 2 * TX) { rown = TY * PX + (re - TX) + 1; rpub = has_N; if (has_N) rnb = tile + ntx; rsrc = re - TX; rlds = (TY + 1) * PX + (re - TX) + 1; }
-        else if (re < 2 * TX + TY) { const int r = re - 2 * TX; rown = (r + 1) * PX + 1; rpub = has_W; if (has_W) rnb = tile - 1; rsrc = 2 * TX + TY + r; rlds = (r + 1) * PX; }
-        else { const int r = re - 2 * TX - TY; rown = (r + 1) * PX + TX; rpub = has_E; if (has_E) rnb = tile + 1; rsrc = 2 * TX + r; rlds = (r + 1) * PX + TX + 1; }
-    }
-    unsigned long long *__restrict__ Hpub = ca.H + 2 * (((size_t)tile * (NL - 1) + rl) * R * EDGE + re);
-    const unsigned long long *__restrict__ Hget = ca.H + 2 * (((size_t)max(rnb, 0) * (NL - 1) + rl) * R * EDGE + rsrc);
-
-    const T *__restrict__ P = a.Pin;
-    const T *__restrict__ RHS = a.RHS;
-    const T *__restrict__ Din = a.Din;
-    T *__restrict__ D = a.D;
-
-    T p0m, p0c, p0p, d0;
-    T rq[NRQ];                     // ∇V at planes k1, k1−1, …
-    T pm[NL - 1];                  // Pˡ at plane kℓ₊₁−1
-    T dq[NL - 1][LAG];             // dˡ produced 1 … LAG steps ago
-    T hA = (T)0, hB = (T)0, hC = (T)0;
-#pragma unroll
-    for (int j = 0; j < NRQ; ++j) rq[j] = (T)0;
-#pragma unroll
-    for (int l = 0; l < NL - 1; ++l) {
-        pm[l] = (T)0;
-#pragma unroll
-        for (int j = 0; j < LAG; ++j) dq[l][j] = (T)0;
-    }
-    const int kfirst = kb - (NL - 1);
-    {
-        const int k1 = kfirst;
-        const T *__restrict__ Pm = P + (idx_t)min(max(k1 - 1, 0), nz - 1) * sz;
-        const T *__restrict__ Pc = P + (idx_t)min(max(k1, 0), nz - 1) * sz;
-        const T *__restrict__ Pp = P + (idx_t)min(max(k1 + 1, 0), nz - 1) * sz;
-        const int ka = min(max(k1, 1), nz - 2);
-        p0m = Pm[poff]; p0c = Pc[poff]; p0p = Pp[poff];
-        d0 = Din[(idx_t)(ka - 1) * dsz + doff];
-        rq[0] = RHS[(idx_t)ka * sz + roff];
-        L0[0][ctr] = p0c;
-        if (hasA) L0[0][ldsA] = Pc[offA];
-        if (hasB) L0[0][ldsB] = Pc[offB];
-        if (hasC) L0[0][ldsC] = Pc[offC];
-        if (hasA) hA = Pp[offA];
-        if (hasB) hB = Pp[offB];
-        if (hasC) hC = Pp[offC];
-    }
-    __syncthreads();
-    const int nsteps = (ke - kb) + (NL - 1) * (LAG + 1);
-    int cur = 0;
-    for (int s = 0; s < nsteps; ++s) {
-        const int k1 = kfirst + s;
-        // ---- (1) publish the edges of the planes produced in step s−1 (read back from LDS), keyed with that step ----
-#ifndef NS3D_COOP_EXP
-#define NS3D_COOP_EXP 0         // A/B builds: 1 = no exchange at all (wrong results: what the exchange costs)
-#endif
-        if (NS3D_COOP_EXP != 1 && ring && rpub && s >= 1) {
-            const int kpl = kfirst + (s - 1) - LAG * rl;                     // plane level rl+1 produced in step s−1
-            coop_publish<T>(Hpub + 2 * (size_t)(((s - 1) & (R - 1)) * EDGE), LN[rl][(kpl + 64) & (NB - 1)][rown], coop_key(ca.epoch + (unsigned long long)(s - 1)));
-        }
-        // ---- (2) fetch what the neighbour published for ITS step s−2 (at the top of its step s−1: one step ago); used in step s+1 ----
-        const bool fetch = NS3D_COOP_EXP != 1 && ring && rnb >= 0 && s >= 2;
-        const unsigned long long *__restrict__ gp = Hget + 2 * (size_t)(((s - 2) & (R - 1)) * EDGE);
-        const unsigned long long want = coop_key(ca.epoch + (unsigned long long)(s - 2));
-        unsigned long long w1 = 0ull, w2 = 0ull;
-        if (NS3D_COOP_EXP != 2 && fetch) {
-            w1 = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            w2 = __hip_atomic_load(gp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // ---- loads of the next step: plane k1+2 of P⁰ (+ ring), d⁰ / ∇V of plane k1+1 ----
-        T p0n, d0n, r0n, hAn = (T)0, hBn = (T)0, hCn = (T)0;
-        {
-            const int kp = min(max(k1 + 2, 0), nz - 1), ka = min(max(k1 + 1, 1), nz - 2);
-            const T *__restrict__ Pn = P + (idx_t)kp * sz;
-            p0n = Pn[poff];
-            d0n = Din[(idx_t)(ka - 1) * dsz + doff];
-            r0n = RHS[(idx_t)ka * sz + roff];
-            if (hasA) hAn = Pn[offA];
-            if (hasB) hBn = Pn[offB];
-            if (hasC) hCn = Pn[offC];
-        }
-        if (NS3D_COOP_EXP == 2 && fetch) {      // A/B: the coherent loads behind the streaming ones (the counter returns in order)
-            w1 = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            w2 = __hip_atomic_load(gp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // ---- level 1 at plane k1 ----
-        T fresh, dnew;
-        {
-            const T *__restrict__ l0 = L0[cur];
-            const T c = p0c;
-            const T w = l0[ctr - 1], e = l0[ctr + 1], sv = l0[ctr - PX], nv = l0[ctr + PX];
-            const T res = NS3D_HAS_SLOW_PATH ? poisson_rhs_slow<T>(c, w, e, sv, nv, p0m, p0p, rq[0], a.rho_dt, g)
-                                             : poisson_rhs_nochk<T>(c, w, e, sv, nv, p0m, p0p, rq[0], a.rho_dt, g);
-            dnew = d0 * a.one_m_damp + a.dtau * res;
-            fresh = c + a.dtau * dnew;
-        }
-        // ---- levels 2 … NL, each LAG planes behind the previous one; the plane just produced goes to LDS ----
-#pragma unroll
-        for (int l = 1; l <= NL; ++l) {
-            const int kl = k1 - LAG * (l - 1);                  // plane of `fresh` / `dnew` (level l)
-            if (l < NL) LN[l - 1][(kl + 64) & (NB - 1)][ctr] = fresh;
-            else {
-                if (act && kl >= kb && kl < ke) {                // the output level
-                    D[(idx_t)(kl - 1) * dsz + doff] = dnew;
-                    T *__restrict__ po = a.Pout + (idx_t)kl * sz + gj * nx + gi;
-                    *po = fresh;
-                    if (xlo_adj) po[-1] = xface_val<T>(a, false, fresh, kl);
-                    if (xhi_adj) po[1] = xface_val<T>(a, true, fresh, kl);
-                }
-                break;
-            }
-            // level l+1 at plane kn = kl − LAG: x/y neighbours, centre and top from LDS (written ≥ 1 step ago), bottom from pm
-            const int kn = kl - LAG;
-            const T *__restrict__ lc = LN[l - 1][(kn + 64) & (NB - 1)];
-            const T c = lc[ctr];
-            T w = lc[ctr - 1], e = lc[ctr + 1], sv = lc[ctr - PX], nv = lc[ctr + PX];
-            T tv = LN[l - 1][(kn + 1 + 64) & (NB - 1)][ctr], bv = pm[l - 1];
-            if (xlo_adj) w = xface_val<T>(a, false, c, kn);
-            if (xhi_adj) e = xface_val<T>(a, true, c, kn);
-            if (ylo_adj) sv = c;
-            if (yhi_adj) nv = c;
-            if (kn == 1) bv = c;
-            if (kn == nz - 2) tv = c;
-            const T res = NS3D_HAS_SLOW_PATH ? poisson_rhs_slow<T>(c, w, e, sv, nv, bv, tv, rq[LAG * l], a.rho_dt, g)
-                                             : poisson_rhs_nochk<T>(c, w, e, sv, nv, bv, tv, rq[LAG * l], a.rho_dt, g);
-            const T out_d = dq[l - 1][LAG - 1] * a.one_m_damp + a.dtau * res;
-            const T out_p = c + a.dtau * out_d;
-            pm[l - 1] = c;
-#pragma unroll
-            for (int j = LAG - 1; j >= 1; --j) dq[l - 1][j] = dq[l - 1][j - 1];
-            dq[l - 1][0] = dnew;
-            fresh = out_p; dnew = out_d;
-        }
-        // ---- ∇V ring, level-1 streams, plane k1+1 of P⁰ ----
-#pragma unroll
-        for (int j = NRQ - 1; j >= 1; --j) rq[j] = rq[j - 1];
-        rq[0] = r0n; d0 = d0n;
-        T *__restrict__ n0 = L0[cur ^ 1];
-        n0[ctr] = p0p;
-        if (hasA) n0[ldsA] = hA;
-        if (hasB) n0[ldsB] = hB;
-        if (hasC) n0[ldsC] = hC;
-        p0m = p0c; p0c = p0p; p0p = p0n;
-        hA = hAn; hB = hBn; hC = hCn;
-        // ---- the fetched edge: ring of the plane level rl+2 works on in step s+1 (its centre was written in step s−2) ----
-        if (fetch) {
-            if (__builtin_expect((w1 ^ w2) != want, 0)) {       // the neighbour is more than a step behind (or the pair is in flight)
-                unsigned spins = 0;
-                do {
-                    __builtin_amdgcn_s_sleep(1);
-                    w1 = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    w2 = __hip_atomic_load(gp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (++spins > (1u << 22)) { atomicOr(ca.err, 1u); break; }
-                } while ((w1 ^ w2) != want);
-            }
-            T rv;
-            coop_unbits(w1, rv);
-            LN[rl][(kfirst + s - 2 - LAG * rl + 64) & (NB - 1)][rlds] = rv;
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-}
-
-// halo scratch of the cooperative kernel: one per (device, stream) — two launches in flight on one device must not share it
-struct CoopScratch {
-    int device; hipStream_t stream; void *H; unsigned *err; size_t bytes_H; unsigned long long launches;
-};
-static CoopScratch *coop_scratch(hipStream_t s, size_t bytes_H)
-{
-    static std::vector<CoopScratch> pool;
-    static std::mutex mtx;
-    std::lock_guard<std::mutex> lock(mtx);
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    CoopScratch *c = nullptr;
-    for (auto &q : pool)
-        if (q.device == dev && q.stream == s) c = &q;
-    if (!c) {
-        if (pool.capacity() < 64) pool.reserve(64);         // pointers handed out stay valid
-        if (pool.size() >= 64) return nullptr;
-        pool.push_back({dev, s, nullptr, nullptr, 0, 0ull});
-        c = &pool.back();
-    }
-    if (c->bytes_H < bytes_H) {
-        if (c->H) { (void)hipStreamSynchronize(s); (void)hipFree(c->H); c->H = nullptr; c->bytes_H = 0; }
-        if (hipMalloc(&c->H, bytes_H + 64) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        if (hipMemset(c->H, 0, bytes_H + 64) != hipSuccess) { (void)hipGetLastError(); return nullptr; }   // no pair is valid for any step
-        c->err = (unsigned *)((char *)c->H + bytes_H);
-        c->bytes_H = bytes_H;
-    }
-    return c;
-}
-
-template <class T, int NL, int TY>
-static hipError_t launch_coop(hipStream_t s, SweepArgs<T> &a)
-{
-    constexpr int TX = 64, R = 8, EDGE = 2 * TX + 2 * TY;
-    const int nk = a.k1 - a.k0;
-    const int ntx = (a.nx - 2 + TX - 1) / TX, nty = (a.ny - 2 + TY - 1) / TY, tiles = ntx * nty;
-    if (nk < 1 || nk > 60000) return hipErrorInvalidValue;
-    static const int per_cu = workgroups_per_cu((const void *)k_pt_coop<T, NL, TY>, 64 * TY);
-    if (tiles > device_cus() * per_cu) return hipErrorInvalidValue;         // the workgroups must be resident together
-    CoopScratch *cs = coop_scratch(s, (size_t)tiles * (NL - 1) * R * EDGE * 2 * sizeof(unsigned long long));
-    if (!cs) return hipErrorOutOfMemory;
-    CoopArgs<T> ca;
-    ca.a = a; ca.a.kz = nk;
-    ca.H = (unsigned long long *)cs->H; ca.err = cs->err;
-    ca.epoch = (++cs->launches) << 16;          // keys of earlier launches (and of the zeroed scratch) never match this one's
-    ca.ntx = ntx; ca.nty = nty;
-    void *kargs[] = {(void *)&ca};
-    hipError_t e = hipLaunchCooperativeKernel((const void *)k_pt_coop<T, NL, TY>, dim3((unsigned)tiles), dim3(TX, TY, 1), kargs, 0, s);
-    if (e != hipSuccess) return e;
-    e = launch_faces<T>(s, a);
-    static const bool check = std::getenv("NS3D_COOP_CHECK") && *std::getenv("NS3D_COOP_CHECK") == '1';
-    if (check && e == hipSuccess) {
-        unsigned err = 0;
-        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
-        if ((e = hipMemcpy(&err, cs->err, sizeof err, hipMemcpyDeviceToHost)) != hipSuccess) return e;
-        if (err) { (void)hipMemset(cs->err, 0, sizeof err); return hipErrorLaunchTimeOut; }     // a bounded wait expired
-    }
-    return e;
-}
-
+// (Round 3 tried the opposite of overlapped tiles — tiles WITHOUT overlap whose workgroups exchange the edges of every intermediate
+// plane through the L2, cooperative launch, level ℓ three planes behind level ℓ−1 so that an edge has two steps to cross the
+// chip: bit-identical, 2.16 ms per four-iteration pass at 512³ against 1.45 for k_pt_sweepN, 1.36 with the exchange compiled
+// out.  Not kept: profiles/r3_coop_ab.log, DESIGN.md §4.3, commit "experiment: k_pt_coop".)
 // `nlev` fused PT iterations (Pin,Din) → (Pout,Dout) for the output planes [k0,k1).  variant = shape*100 + kz:
 // shape 1: 64×32 columns (one wave wide, 8 high, 4 rows per thread), 2: 128×16, 6: 64×16 with 256-thread workgroups (two per
 // CU); +10: loads of the next step issued before level 1 (EARLY); 22: fp32 64×48 with 768 threads; 23 / 28 (EARLY / not): 64×24
@@ -2548,9 +2249,6 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
     case 28: NS3D_SWN(NLV, 1, 12, 2, false);                                                                     \
     case 11: NS3D_SWN(NLV, 1, 8, 4, true);                                                                  \
     case 12: NS3D_SWN(NLV, 2, 4, 4, true);                                                                  \
-    case 30: return launch_coop<T, NLV, 16>(s, a);  /* no redundant tiles: 64×16 columns, 1024 threads, halo exchange between workgroups */ \
-    case 31: return launch_coop<T, NLV, 12>(s, a);  /* 64×12, 768 threads */                               \
-    case 32: return launch_coop<T, NLV, 8>(s, a);   /* 64×8, 512 threads (two workgroups per CU) */         \
     default: return hipErrorInvalidValue;                                                                   \
     }
     switch (nlev) {

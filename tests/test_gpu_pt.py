@@ -830,71 +830,3 @@ def test_graph_cache_ignores_struct_padding(hip, oracle):
         assert n == base, (call, n, base)
     ctx.close()
 
-
-os_environ_coop = __import__("os").environ.setdefault("NS3D_COOP_CHECK", "1")      # bounded waits of k_pt_coop report instead of passing silently
-
-
-@pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("grid", [(70, 21, 13), (131, 37, 35), (200, 160, 66), (66, 18, 40), (512, 512, 64), (300, 200, 150)])
-@pytest.mark.parametrize("shape", [30, 31, 32])
-def test_pt_coop_without_redundant_tiles_equals_single_sweeps(hip, oracle, grid, shape, dtype):
-    """k_pt_coop (variants 3000 / 3100 / 3200: 64×16, 64×12, 64×8 columns per workgroup, NO overlap between tiles: the x/y
-    neighbours of levels 2…NL on a tile's edge come from the neighbouring workgroup through the halo scratch): 2, 3 and 4
-    iterations per pass, whole grid and plane sub-ranges (a slab rank's seam / interior launches), both boundary sets, against
-    NL one-thread-per-cell sweeps on the device, bit for bit; the smallest grid also against the oracle's unfused loop."""
-    import torch
-    nx, ny, nz = grid
-    g = geometry(nx, ny, nz)
-    if nx >= 200:
-        g["dx"], g["dy"], g["dz"] = 2.0 ** -8, 2.0 ** -7, 2.0 ** -8        # strictp arithmetic on the larger grids
-    tdt, bits, npdt = (torch.float64, torch.int64, np.float64) if dtype == "f64" else (torch.float32, torch.int32, np.float32)
-    gen = torch.Generator(device="cuda"); gen.manual_seed(4242)
-
-    def rnd_dev(*shp):
-        t = hip.zeros(shp, tdt)
-        t.permute(2, 1, 0).uniform_(-1.0, 1.0, generator=gen)
-        return t
-
-    P0, D0, R = rnd_dev(nx, ny, nz), rnd_dev(nx - 2, ny - 2, nz - 2), rnd_dev(nx, ny, nz)
-    ctx = hip.Context(0, "strict")
-    ty = {30: 16, 31: 12, 32: 8}[shape]
-    tiles = -(-(nx - 2) // 64) * -(-(ny - 2) // ty)
-    if tiles > torch.cuda.get_device_properties(0).multi_processor_count:
-        # possibly more tiles than workgroups the chip holds at once (that depends on the instantiation's registers and LDS): the
-        # cooperative form then refuses (and the planner keeps k_pt_sweepN); where it accepts, the results are checked below
-        from navierstokes3d_amd import lib as L
-        ctx.set_ptn_variant(shape * 100)
-        try:
-            hip.pt_sweepn(4, P0, hip.zeros((nx, ny, nz), tdt), D0, hip.zeros((nx - 2, ny - 2, nz - 2), tdt), R, _params(hip, P0, g, 0, True, 0.75), ctx=ctx)
-        except L.Ns3dError:
-            ctx.close()
-            return
-    for bc in ((0, True, 0.75), (1, False, 0.0)):
-        p = _params(hip, P0, g, *bc)
-        for nlev in (4, 3, 2):
-            ctx.set_pt_variant(100)
-            Pb, Pc, Db = hip.clone(P0), hip.zeros((nx, ny, nz), tdt), hip.clone(D0)
-            for _ in range(nlev):
-                hip.pt_sweep(Pb, Pc, Db, R, p, 1, nz - 1, ctx=ctx)
-                Pb, Pc = Pc, Pb
-            ctx.set_pt_variant(0)
-            ctx.set_ptn_variant(shape * 100)
-            Pa, Da = hip.zeros((nx, ny, nz), tdt), hip.zeros((nx - 2, ny - 2, nz - 2), tdt)
-            hip.pt_sweepn(nlev, P0, Pa, D0, Da, R, p, ctx=ctx)
-            torch.cuda.synchronize()
-            assert torch.equal(Pa.view(bits), Pb.view(bits)), ("Pr", grid, shape, nlev, bc)
-            assert torch.equal(Da.view(bits), Db.view(bits)), ("dPrdτ", grid, shape, nlev, bc)
-            # a plane sub-range leaves the other planes alone and reproduces its own
-            if nz >= 13:
-                k0, k1 = 3, nz - 4
-                Pq, Dq = hip.zeros((nx, ny, nz), tdt), hip.zeros((nx - 2, ny - 2, nz - 2), tdt)
-                hip.pt_sweepn(nlev, P0, Pq, D0, Dq, R, p, k0, k1, ctx=ctx)
-                torch.cuda.synchronize()
-                assert torch.equal(Pq[:, :, k0:k1].view(bits), Pb[:, :, k0:k1].view(bits)), ("Pr range", grid, shape, nlev)
-                assert torch.equal(Dq[:, :, k0 - 1:k1 - 1].view(bits), Db[:, :, k0 - 1:k1 - 1].view(bits))
-                assert not Pq[:, :, :k0].any() and not Pq[:, :, k1:].any() and not Dq[:, :, :k0 - 1].any() and not Dq[:, :, k1 - 1:].any()
-    if grid == (70, 21, 13):
-        Ph, Dh, Rh = hip.to_numpy(P0), hip.to_numpy(D0), hip.to_numpy(R)
-        _oracle_iters(oracle, Ph, Dh, Rh, g, 2, 1, False, 0.0)
-        assert np.array_equal(hip.to_numpy(Pa), Ph) and np.array_equal(hip.to_numpy(Da), Dh)      # the last pass above: 2 levels, gpu.jl set
-    ctx.close()
