@@ -2122,7 +2122,11 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
 #pragma unroll
         for (int r = 0; r < CPT; ++r) { p0m[r] = p0c[r]; p0c[r] = p0p[r]; p0p[r] = p0n[r]; }
         hA = hAn; hB = hBn; hC = hCn;
+#ifdef NS3D_NO_STEP_BARRIER     // A/B (WRONG results): what the one barrier per z-step costs a CU that holds a single workgroup
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the wave's own LDS traffic only
+#else
         __syncthreads();
+#endif
         cur ^= 1;
     };
     // The z rings rotate every step (≈ 16 register-pair moves per row, a quarter of a step's vector instructions); with the
