@@ -203,6 +203,20 @@ function advect!(Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, C, C_o, dt, dx, dy, dz; faithful:
                 _ctx(), ptr(Vx), ptr(Vx_o), ptr(Vy), ptr(Vy_o), ptr(Vz), ptr(Vz_o), ptr(C), ptr(C_o),
                 dt, dx, dy, dz, nx, ny, nz, faithful ? 1 : 0))
 end
+"""
+    copy_advect!(Vx_new, Vx, Vy_new, Vy, Vz_new, Vz, C_new, C, dt, dx, dy, dz; faithful = true)
+
+Optional, same results as `Vx_o .= Vx; …; advect!(…)` (multi.jl:475-476 / gpu.jl:141-142) without the four copies: reads the CURRENT
+fields, writes COMPLETE new fields into buffers of their own (the entries `advect!` leaves alone written through); the caller swaps
+the names afterwards (`Vx, Vx_o = Vx_o, Vx` …).  `Vz_new` may be `Vz` itself in faithful mode (Vz is never advected there).
+"""
+function copy_advect!(Vx_new, Vx, Vy_new, Vy, Vz_new, Vz, C_new, C, dt, dx, dy, dz; faithful::Bool = true)
+    nx, ny, nz = _cint3(C); _sync()
+    check(ccall((:ns3d_copy_advect_f64, libns3d), Cint,
+                (Ptr{Cvoid}, PF, PF, PF, PF, PF, PF, PF, PF, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint, Cint, Cint),
+                _ctx(), ptr(Vx_new), ptr(Vx), ptr(Vy_new), ptr(Vy), ptr(Vz_new), ptr(Vz), ptr(C_new), ptr(C),
+                dt, dx, dy, dz, nx, ny, nz, faithful ? 1 : 0))
+end
 
 # boundary-plane kernels: the array's own extents are passed (they act on Pr, Vx, Vy and Vz alike)
 "bc_x!  multi.jl:108-112 / gpu.jl:221-225"
@@ -262,6 +276,20 @@ function pt_solve!(Pr, dPrdτ, ∇V, ρ, dt, dτ, damp, dx, dy, dz; bc_kind = 0,
                  Ref{Cint}),
                 _ctx(), ptr(Pr), ptr(dPrdτ), ptr(∇V), p, εit, niter, nchk, ly^2, psc, it, hist, cap, nchecks))
     return Int(it[]), hist[1:nchecks[]]
+end
+"""
+    poisson_direct!(Pr, dPrdτ, ∇V, ρ, dt, dx, dy, dz; bc_kind, owns_outlet, g)
+
+OUTSIDE PARITY (an option the reference does not have): instead of iterating multi.jl:458-471 / gpu.jl:126-137 to `err < εit`, solve
+the discrete problem that loop converges to — `∇²Pr = ρ/dt·∇V` with set_bc_Pr!'s boundary cells — directly (`ns3d_poisson_direct_f64`:
+exact diagonalisation of the box Laplacian, six fp64 matrix products on the matrix cores).  `Pr` gets the solution and its boundary
+cells, `dPrdτ` zeros.  One rank.  255×153×153: ≈ 1 ms against ≈ 60 ms for the loop's 2 280 iterations.
+"""
+function poisson_direct!(Pr, dPrdτ, ∇V, ρ, dt, dx, dy, dz; bc_kind = 0, owns_outlet = true, g = 0.0)
+    nx, ny, nz = _cint3(Pr)
+    p = Ref(PtParams(ρ, dt, 0.0, 0.0, dx, dy, dz, nx, ny, nz, bc_kind, owns_outlet ? 1 : 0, 0.0, g, 0, 0)); _sync()
+    check(ccall((:ns3d_poisson_direct_f64, libns3d), Cint, (Ptr{Cvoid}, PF, PF, PF, Ref{PtParams}),
+                _ctx(), ptr(Pr), ptr(dPrdτ), ptr(∇V), p))
 end
 """
     pt_solve_slab!(Pr, dPrdτ, ∇V, ρ, dt, dτ, damp, dx, dy, dz; …) -> (iters, errs)
