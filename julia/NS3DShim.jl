@@ -283,7 +283,7 @@ end
 OUTSIDE PARITY (an option the reference does not have): instead of iterating multi.jl:458-471 / gpu.jl:126-137 to `err < εit`, solve
 the discrete problem that loop converges to — `∇²Pr = ρ/dt·∇V` with set_bc_Pr!'s boundary cells — directly (`ns3d_poisson_direct_f64`:
 exact diagonalisation of the box Laplacian, six fp64 matrix products on the matrix cores).  `Pr` gets the solution and its boundary
-cells, `dPrdτ` zeros.  One rank.  255×153×153: ≈ 1 ms against ≈ 60 ms for the loop's 2 280 iterations.
+cells, `dPrdτ` zeros.  One rank.  255×153×153: ≈ 0.6 ms against ≈ 60 ms for the loop's 2 280 iterations.
 """
 function poisson_direct!(Pr, dPrdτ, ∇V, ρ, dt, dx, dy, dz; bc_kind = 0, owns_outlet = true, g = 0.0)
     nx, ny, nz = _cint3(Pr)

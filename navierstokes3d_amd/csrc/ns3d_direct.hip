@@ -18,7 +18,9 @@
 // Cost: 4·(mx+my+mz) flops per cell — 10 GFLOP at 255×153×153, 0.8 TFLOP at 512³.
 // fp32 fields are solved in fp64 internally (the Laplacian's condition number ~n² eats seven digits at n = 255).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "ns3d_internal.h"
@@ -90,11 +92,110 @@ __global__ __launch_bounds__(256) void k_gemm_f64(GemmArgs g)
             }
 }
 
+// The same product with both operands staged through LDS (round 3, second version): a 256-thread workgroup owns 128 (i) × 64 (j)
+// of C, a wave 64×32 = 4×2 MFMA tiles (32 accumulator registers of f64), K in stages of 16: while the MFMAs of a stage run, the
+// next stage's 128×16 and 16×64 operand tiles are in flight from global memory into registers, then written to the other LDS
+// buffer — one barrier per stage.  Tiles lie in LDS as [k][i] / [k][j] with the pitch padded by two elements: a fragment read
+// (16 consecutive i or j for each of 4 consecutive k) and both store patterns (threads running along k where k is the contiguous
+// direction in memory, along i / j otherwise) stay within two-way bank conflicts.  Per stage a wave issues 32 MFMAs (2 048 flop
+// each) for 24 LDS reads; every element of the large operand is fetched once per workgroup column.
+__global__ __launch_bounds__(256) void k_gemm_f64_lds(GemmArgs g)
+{
+    constexpr int TI = 128, TJ = 64, KT = 16, PA = TI + 2, PB = TJ + 2;
+    __shared__ double As[2][KT * PA];
+    __shared__ double Bs[2][KT * PB];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wi = wave & 1, wj = wave >> 1;
+    const int ti = (int)blockIdx.x * TI, tj = (int)blockIdx.y * TJ;
+    const double *__restrict__ A = g.A + (long)blockIdx.z * g.batchA;
+    const double *__restrict__ B = g.B + (long)blockIdx.z * g.batchB;
+    double *__restrict__ C = g.C + (long)blockIdx.z * g.batchC;
+    const int r = lane & 15, kq = lane >> 4;
+    // which element of a tile this thread moves (eight of A, four of B per stage): along k where k is contiguous in memory
+    const bool a_kfast = g.sak == 1 && g.sai != 1, b_kfast = g.sbk == 1 && g.sbj != 1;
+    int ai[8], ak[8], bj[4], bk[4];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if (a_kfast) { ak[q] = tid & 15; ai[q] = (tid >> 4) + 16 * q; }
+        else { ai[q] = tid & 127; ak[q] = (tid >> 7) + 2 * q; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (b_kfast) { bk[q] = tid & 15; bj[q] = (tid >> 4) + 16 * q; }
+        else { bj[q] = tid & 63; bk[q] = (tid >> 6) + 4 * q; }
+    }
+    f64x4 acc[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) acc[u][v] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    double ra[8], rb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = ti + ai[q], k = k0 + ak[q];
+            const bool ok = i < g.M && k < g.K;
+            const double v = A[(long)(ok ? i : 0) * g.sai + (long)(ok ? k : 0) * g.sak];
+            ra[q] = ok ? v : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = tj + bj[q], k = k0 + bk[q];
+            const bool ok = j < g.N && k < g.K;
+            const double v = B[(long)(ok ? k : 0) * g.sbk + (long)(ok ? j : 0) * g.sbj];
+            rb[q] = ok ? v : 0.0;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) As[buf][ak[q] * PA + ai[q]] = ra[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Bs[buf][bk[q] * PB + bj[q]] = rb[q];
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < g.K; k0 += KT) {
+        const bool more = k0 + KT < g.K;
+        if (more) fetch(k0 + KT);
+        const double *__restrict__ as = As[cur], *__restrict__ bs = Bs[cur];
+#pragma unroll
+        for (int kk = 0; kk < KT / 4; ++kk) {
+            double av[4], bv[2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) av[u] = as[(4 * kk + kq) * PA + wi * 64 + 16 * u + r];
+#pragma unroll
+            for (int v = 0; v < 2; ++v) bv[v] = bs[(4 * kk + kq) * PB + wj * 32 + 16 * v + r];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[v], av[u], acc[u][v], 0, 0, 0);
+        }
+        if (more) stash(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = ti + wi * 64 + 16 * u + r, j = tj + wj * 32 + 16 * v + kq + 4 * q;
+                if (i < g.M && j < g.N) C[(long)i * g.sci + (long)j * g.scj] = acc[u][v][q];
+            }
+}
+
 hipError_t gemm(hipStream_t s, const double *A, const double *B, double *C, int M, int N, int K, long sai, long sak, long sbk,
                 long sbj, long sci, long scj, int batch = 1, long bA = 0, long bB = 0, long bC = 0)
 {
     GemmArgs g{A, B, C, M, N, K, sai, sak, sbk, sbj, sci, scj, bA, bB, bC};
-    hipLaunchKernelGGL(k_gemm_f64, dim3((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64), (unsigned)batch), dim3(256), 0, s, g);
+    static const bool simple_only = std::getenv("NS3D_GEMM_SIMPLE") && *std::getenv("NS3D_GEMM_SIMPLE") == '1';     // A/B
+    if (M >= 32 && N >= 16 && !simple_only)
+        hipLaunchKernelGGL(k_gemm_f64_lds, dim3((unsigned)((M + 127) / 128), (unsigned)((N + 63) / 64), (unsigned)batch), dim3(256), 0, s, g);
+    else
+        hipLaunchKernelGGL(k_gemm_f64, dim3((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64), (unsigned)batch), dim3(256), 0, s, g);
     return hipGetLastError();
 }
 
@@ -164,6 +265,8 @@ void eig1d(int m, double d, int kind, std::vector<double> &V, std::vector<double
     if (kind == 0) lam[0] = 0.0;
 }
 
+struct Eig1d { int m, kind; double d; std::vector<double> V, lam; };
+
 struct DirectPlan {
     int nx = 0, ny = 0, nz = 0, xkind = -1;
     double dx = 0, dy = 0, dz = 0;
@@ -198,8 +301,24 @@ int ensure_plan(ns3d_ctx *c, const ns3d_pt_params *p, int xkind, DirectPlan **ou
     const double d[3] = {p->dx, p->dy, p->dz};
     const int kind[3] = {xkind, 0, 0};
     for (int q = 0; q < 3; ++q) {
+        // the eigenbases depend on (extent, spacing, boundary kind) only: computed once per process (contexts come and go, one
+        // per driver call), uploaded per context
+        static std::vector<Eig1d> cache;
+        static std::mutex mtx;
         std::vector<double> V, lam;
-        eig1d(m[q], d[q], kind[q], V, lam);
+        {
+            std::lock_guard<std::mutex> lock(mtx);
+            const Eig1d *hit = nullptr;
+            for (const Eig1d &e : cache)
+                if (e.m == m[q] && e.d == d[q] && e.kind == kind[q]) hit = &e;
+            if (!hit) {
+                if (cache.size() >= 32) cache.clear();
+                cache.push_back({m[q], kind[q], d[q], {}, {}});
+                eig1d(m[q], d[q], kind[q], cache.back().V, cache.back().lam);
+                hit = &cache.back();
+            }
+            V = hit->V; lam = hit->lam;
+        }
         HIPCHK(c, hipMalloc((void **)&pl->V[q], V.size() * sizeof(double)));
         HIPCHK(c, hipMalloc((void **)&pl->lam[q], lam.size() * sizeof(double)));
         HIPCHK(c, hipMemcpy(pl->V[q], V.data(), V.size() * sizeof(double), hipMemcpyHostToDevice));

@@ -33,7 +33,7 @@ python3 tools/collect_traffic.py --out $O/${TAG}_traffic_512.json --runs 4:2300,
 python3 tools/collect_traffic.py --out $O/${TAG}_traffic_512_f32.json --runs 4:2400,4:2200,3:100,2:1100 --modes strict --dtype f32 2>&1 | tail -3
 python3 tools/kernel_rates.py > $O/${TAG}_kernel_rates_512.jsonl 2>/dev/null; grep -c kernel $O/${TAG}_kernel_rates_512.jsonl
 python3 tools/run_config.py --script multi --nx 63 --nt 20 > $O/${TAG}_config_a_63x38x38.json 2>/dev/null; tail -c 300 $O/${TAG}_config_a_63x38x38.json; echo
-python3 tools/run_config.py --script multi --nx 255 --nt 3 --compare-fast > $O/${TAG}_config_b_multi_255x153x153.json 2>/dev/null; tail -c 300 $O/${TAG}_config_b_multi_255x153x153.json; echo
+python3 tools/run_config.py --script multi --nx 255 --nt 3 --compare-fast --compare-direct > $O/${TAG}_config_b_multi_255x153x153.json 2>/dev/null; tail -c 300 $O/${TAG}_config_b_multi_255x153x153.json; echo
 python3 tools/run_config.py --script gpu --nx 255 --nt 3 > $O/${TAG}_config_b_gpujl_255x153x153.json 2>/dev/null; tail -c 300 $O/${TAG}_config_b_gpujl_255x153x153.json; echo
 python3 tools/cart_rates.py > $O/${TAG}_cart_rates.jsonl 2> $O/${TAG}_cart_rates.err; cat $O/${TAG}_cart_rates.jsonl
 # pressure solve: the reference's PT loop against the direct solve (outside parity), the reference's own grids

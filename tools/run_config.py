@@ -21,14 +21,14 @@ from navierstokes3d_amd import kernels as K  # noqa: E402
 from navierstokes3d_amd.driver import run_navierstokes3D, runme  # noqa: E402
 
 
-def run(script, nx, nt, mode, temporal=True):
+def run(script, nx, nt, mode, temporal=True, pressure="pt"):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if script == "multi":
-        out = run_navierstokes3D(nx=nx, nt=nt, mode=mode, temporal=temporal, return_info=True)
+        out = run_navierstokes3D(nx=nx, nt=nt, mode=mode, temporal=temporal, return_info=True, pressure=pressure)
         info, fields = out[-1], dict(zip(("C", "Pr", "Vx", "Vy", "Vz"), out[:5]))
     else:
-        f, info = runme(nx=nx, nt=nt, mode=mode)
+        f, info = runme(nx=nx, nt=nt, mode=mode, pressure=pressure)
         fields = {n: K.to_numpy(getattr(f, n)) for n in ("C", "Pr", "Vx", "Vy", "Vz")}
     torch.cuda.synchronize()
     return time.perf_counter() - t0, info, fields
@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--nt", type=int, default=3)
     ap.add_argument("--mode", default="strict")
     ap.add_argument("--compare-fast", action="store_true")
+    ap.add_argument("--compare-direct", action="store_true",
+                    help="also run with pressure=\"direct\" (outside parity): seconds per step, and how far its fields are from the PT run's")
     a = ap.parse_args()
     run(a.script, a.nx, 1, a.mode)           # warm-up on the same grid (library load, allocator, one-time tile tuning)
     wall, info, fields = run(a.script, a.nx, a.nt, a.mode)
@@ -60,6 +62,17 @@ def main():
             rel[n] = float(np.sqrt(np.sum((fields_f[n] - fields[n]) ** 2)) / den) if den > 0 else 0.0
         res["fast"] = {"pt_iters_per_step": info_f.iters, "same_iteration_counts": info_f.iters == info.iters,
                        "wall_s": wall_f, "rel_l2_vs_strict": rel}
+    if a.compare_direct:
+        run(a.script, a.nx, 1, a.mode, pressure="direct")
+        wall_d, info_d, fields_d = run(a.script, a.nx, a.nt, a.mode, pressure="direct")
+        vn = np.sqrt(sum(np.sum(fields[n].astype(np.float64) ** 2) for n in ("Vx", "Vy", "Vz")))
+        rel = {}
+        for n in fields:
+            den = vn if n.startswith("V") else np.sqrt(np.sum(fields[n].astype(np.float64) ** 2))
+            rel[n] = float(np.sqrt(np.sum((fields_d[n] - fields[n]) ** 2)) / den) if den > 0 else 0.0
+        res["direct"] = {"wall_s": wall_d, "s_per_step": wall_d / a.nt, "speedup_per_step": wall / wall_d,
+                         "err_per_step": [e[-1] for e in info_d.errs], "rel_l2_vs_pt_run": rel,
+                         "finite": bool(all(np.isfinite(v).all() for v in fields_d.values()))}
     print(json.dumps(res))
 
 
