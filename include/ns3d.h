@@ -329,6 +329,14 @@ int ns3d_slab_residual(ns3d_mgpu *m, double *out);
     int ns3d_slab_load_##S(ns3d_mgpu *m, const T *const *Pr, const T *const *dPrdtau, const T *const *divV, \
                            const ns3d_pt_params *p);                                                        \
     int ns3d_slab_store_##S(ns3d_mgpu *m, T *const *Pr, T *const *dPrdtau);                                 \
+    /* {X_o .= X; advect!; update_halo!} (multi.jl:475-477) on z-slab ranks with the old fields' z halo widened to TWO planes — \
+     * an option OUTSIDE the reference's multi-rank semantics: backtrack! clamps to the local array (multi.jl:192-195), so a      \
+     * departure point beyond the one-plane halo is clamped on a rank where the one-rank run reads the neighbour.  Here every   \
+     * rank advects on copies extended by one more plane per seam, all four new fields (C too) get their halo, and P ranks      \
+     * reproduce the one-rank time step bit for bit while |δz| < 2 cells.  Per-rank pointer lists as everywhere. */            \
+    int ns3d_advect_wide_##S(ns3d_mgpu *m, T *const *Vx, T *const *Vx_o, T *const *Vy, T *const *Vy_o, T *const *Vz,           \
+                             T *const *Vz_o, T *const *C, T *const *C_o, double dt, double dx, double dy, double dz,          \
+                             int faithful);                                                                  \
     int ns3d_pt_solve_slab_##S(ns3d_mgpu *m, T *const *Pr, T *const *dPrdtau, const T *const *divV,         \
                                const ns3d_pt_params *p, double eps, int niter, int nchk, double err_mul,    \
                                double err_div, int *iters_done, double *err_hist, int max_checks,           \

@@ -549,7 +549,16 @@ hipError_t ns3d_enqueue_face_copy(ns3d_ctx *c, hipStream_t s, T *A, T *buf, int 
 {
     return DISPATCH(c, face_copy<T>(s, A, buf, sx, sy, sz, dim, idx, unpack));
 }
+template <class T>
+hipError_t ns3d_enqueue_advect(ns3d_ctx *c, hipStream_t s, T *Vx, const T *Vx_o, T *Vy, const T *Vy_o, T *Vz, const T *Vz_o, T *C,
+                               const T *C_o, double dt, double dx, double dy, double dz, int nx, int ny, int nz, int flags, int koff,
+                               int nzg)
+{
+    return DISPATCHG(c, dx, dy, dz, advect<T>(s, Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, C, C_o, dt, dx, dy, dz, nx, ny, nz, flags, koff, nzg));
+}
 #define NS3D_INST_INTERNAL(T)                                                                                       \
+    template hipError_t ns3d_enqueue_advect<T>(ns3d_ctx *, hipStream_t, T *, const T *, T *, const T *, T *, const T *, T *, \
+                                               const T *, double, double, double, double, int, int, int, int, int, int); \
     template hipError_t ns3d_enqueue_pt2<T>(ns3d_ctx *, hipStream_t, const T *, T *, const T *, T *, const T *,      \
                                             const ns3d_pt_params *, int, int);                                      \
     template hipError_t ns3d_enqueue_pass<T>(ns3d_ctx *, hipStream_t, int, const T *, T *, const T *, T *, const T *, \
@@ -850,7 +859,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
     {                                                                                                        \
         CHECK_CTX(c); CHECK_PTRS(Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, C, C_o); CHECK_GRID(nx, ny, nz, 1);           \
         return finish(c, DISPATCHG(c, dx, dy, dz, advect<T>(c->stream, Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, C, C_o, dt, dx, dy,  \
-                                               dz, nx, ny, nz, faithful ? 1 : 0)), "advect");                        \
+                                               dz, nx, ny, nz, faithful ? 1 : 0, 0, 0)), "advect");                        \
     }                                                                                                        \
     extern "C" int ns3d_copy_advect_##S(ns3d_ctx *c, T *Vx_new, const T *Vx, T *Vy_new, const T *Vy, T *Vz_new, \
                                         const T *Vz, T *C_new, const T *C, double dt, double dx, double dy,  \
@@ -861,7 +870,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
             return fail(NS3D_ERR_ARG, "ns3d_copy_advect: outputs must be buffers of their own (only Vz_new may be Vz, and only " \
                                       "in faithful mode, where Vz is never advected)");                      \
         return finish(c, DISPATCHG(c, dx, dy, dz, advect<T>(c->stream, Vx_new, Vx, Vy_new, Vy, Vz_new, Vz, C_new, C, dt, dx, dy, \
-                                               dz, nx, ny, nz, (faithful ? 1 : 0) | 2)), "copy_advect");     \
+                                               dz, nx, ny, nz, (faithful ? 1 : 0) | 2, 0, 0)), "copy_advect");     \
     }                                                                                                        \
     extern "C" int ns3d_set_bc_Pr_##S(ns3d_ctx *c, T *Pr, int bc_kind, int owns_outlet, double outlet_val,   \
                                       double dz, int nz_arg, double g, double rho, int nx, int ny, int nz)   \

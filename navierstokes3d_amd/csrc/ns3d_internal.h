@@ -124,6 +124,11 @@ hipError_t ns3d_enqueue_residual_key(ns3d_ctx *c, hipStream_t s, const T *Pr, co
 // halo-stripped copy A[1:sx-1,1:sy-1,1:sz-1] → packed out (gather!, multi.jl:399)
 template <class T>
 hipError_t ns3d_enqueue_strip_inner(ns3d_ctx *c, hipStream_t s, const T *A, T *out, int sx, int sy, int sz);
+// advect! on stream s; flags: bit 0 faithful, bit 1 write-through (ns3d_kernels.hip, advect())
+template <class T>
+hipError_t ns3d_enqueue_advect(ns3d_ctx *c, hipStream_t s, T *Vx, const T *Vx_o, T *Vy, const T *Vy_o, T *Vz, const T *Vz_o, T *C,
+                               const T *C_o, double dt, double dx, double dy, double dz, int nx, int ny, int nz, int flags, int koff,
+                               int nzg);       // koff / nzg > 0: the arrays are a window koff planes into a global grid of nzg cell planes
 // x (dim 0) or y (dim 1) face `idx` of A ↔ packed buffer (update_halo! of a 3-D topology)
 template <class T>
 hipError_t ns3d_enqueue_face_copy(ns3d_ctx *c, hipStream_t s, T *A, T *buf, int sx, int sy, int sz, int dim, int idx, int unpack);

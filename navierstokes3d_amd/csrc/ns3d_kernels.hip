@@ -650,10 +650,15 @@ __device__ __forceinline__ float fmod1(float a) { return a - __builtin_truncf(a)
 __device__ __forceinline__ double floor_(double a) { return floor(a); }
 __device__ __forceinline__ float floor_(float a) { return floorf(a); }
 
+// koff / szg (NOT in the reference; 0 / sz reproduce it): the array is a WINDOW of a global array of szg planes that starts koff
+// planes into it (ns3d_advect_wide).  The departure index is then computed from the GLOBAL plane number — `Float(iz) − δ` rounds
+// differently for iz = 2 and iz = 12 when δ is below an ulp of either, so multi.jl:194 on a rank's local indices is
+// decomposition-dependent even where no clamp bites — clamped to the global array and translated back.
 template <class T>
 __device__ __forceinline__ void backtrack(T *__restrict__ A, const T *__restrict__ A_o, T vxc, T vyc, T vzc, T dt,
-                                          const Geo<T> &g, int ix, int iy, int iz, int sx, int sy, int sz)
+                                          const Geo<T> &g, int ix, int iy, int iz, int sx, int sy, int sz, int koff = 0, int szg = 0)
 {
+    if (szg <= 0) szg = sz;
 #if NS3D_FASTMATH
     const T ddx = dt * vxc * g.rdx, ddy = dt * vyc * g.rdy, ddz = dt * vzc * g.rdz;
 #else
@@ -661,8 +666,9 @@ __device__ __forceinline__ void backtrack(T *__restrict__ A, const T *__restrict
 #endif
     const int ix1 = clampi((long long)floor_((T)ix - ddx), 1, sx);
     const int iy1 = clampi((long long)floor_((T)iy - ddy), 1, sy);
-    const int iz1 = clampi((long long)floor_((T)iz - ddz), 1, sz);
-    const int ix2 = clampi(ix1 + 1, 1, sx), iy2 = clampi(iy1 + 1, 1, sy), iz2 = clampi(iz1 + 1, 1, sz);
+    const int iz1g = clampi((long long)floor_((T)(iz + koff) - ddz), 1, szg);
+    const int iz1 = clampi((long long)iz1g - koff, 1, sz), iz2 = clampi((long long)clampi(iz1g + 1, 1, szg) - koff, 1, sz);
+    const int ix2 = clampi(ix1 + 1, 1, sx), iy2 = clampi(iy1 + 1, 1, sy);
     const T wx = (ddx > (T)0 ? (T)1 : (T)0) - fmod1(ddx);
     const T wy = (ddy > (T)0 ? (T)1 : (T)0) - fmod1(ddy);
     const T wz = (ddz > (T)0 ? (T)1 : (T)0) - fmod1(ddz);
@@ -682,9 +688,10 @@ __global__ __launch_bounds__(256) void k_advect(T *__restrict__ Vx, const T *__r
                                                 const T *__restrict__ Vy_o, T *__restrict__ Vz,
                                                 const T *__restrict__ Vz_o, T *__restrict__ C,
                                                 const T *__restrict__ C_o, T dt, Geo<T> g, int nx, int ny, int nz,
-                                                int flags)
+                                                int flags, int koff, int nzg)
 {
     const int faithful = flags & 1, through = flags & 2;     // through: see advect() below
+    const int gz0 = nzg > 0 ? nzg : 0, gz1 = nzg > 0 ? nzg + 1 : 0;         // global extents of the nz- / (nz+1)-plane arrays (0: local)
     const int ix = blockIdx.x * blockDim.x + threadIdx.x + 1;
     const int iy = blockIdx.y * blockDim.y + threadIdx.y + 1;
     const int iz = blockIdx.z * blockDim.z + threadIdx.z + 1;
@@ -709,11 +716,11 @@ __global__ __launch_bounds__(256) void k_advect(T *__restrict__ Vx, const T *__r
         const T cy = (T)0.25 * (((VYO(ix, iy, iz - 1) + VYO(ix, iy + 1, iz - 1)) + vy000) + vy010);                // :232
         const T cz = vz000;                                                                                        // :233
         const T ex = (T)0.5 * (vx000 + vx100), ey = (T)0.5 * (vy000 + vy010), ez = (T)0.5 * (vz000 + vz001);      // :237-239
-        backtrack<T>(Vx, Vx_o, ax, ay, az, dt, g, ix, iy, iz, nx + 1, ny, nz);
-        backtrack<T>(Vy, Vy_o, bx, by, bz, dt, g, ix, iy, iz, nx, ny + 1, nz);
-        if (faithful) backtrack<T>(Vy, Vy_o, cx, cy, cz, dt, g, ix, iy, iz, nx, ny + 1, nz);
-        else backtrack<T>(Vz, Vz_o, cx, cy, cz, dt, g, ix, iy, iz, nx, ny, nz + 1);
-        backtrack<T>(C, C_o, ex, ey, ez, dt, g, ix, iy, iz, nx, ny, nz);
+        backtrack<T>(Vx, Vx_o, ax, ay, az, dt, g, ix, iy, iz, nx + 1, ny, nz, koff, gz0);
+        backtrack<T>(Vy, Vy_o, bx, by, bz, dt, g, ix, iy, iz, nx, ny + 1, nz, koff, gz0);
+        if (faithful) backtrack<T>(Vy, Vy_o, cx, cy, cz, dt, g, ix, iy, iz, nx, ny + 1, nz, koff, gz0);
+        else backtrack<T>(Vz, Vz_o, cx, cy, cz, dt, g, ix, iy, iz, nx, ny, nz + 1, koff, gz1);
+        backtrack<T>(C, C_o, ex, ey, ez, dt, g, ix, iy, iz, nx, ny, nz, koff, gz0);
         if (through && faithful && Vz != Vz_o) Vz[IX3(ix - 1, iy - 1, iz - 1, nx, ny)] = VZO(ix, iy, iz);
         return;
     }
@@ -723,14 +730,14 @@ __global__ __launch_bounds__(256) void k_advect(T *__restrict__ Vx, const T *__r
         vxc = VXO(ix, iy, iz);
         vyc = (T)0.25 * (((VYO(ix - 1, iy, iz) + VYO(ix - 1, iy + 1, iz)) + VYO(ix, iy, iz)) + VYO(ix, iy + 1, iz));
         vzc = (T)0.25 * (((VZO(ix - 1, iy, iz) + VZO(ix - 1, iy, iz + 1)) + VZO(ix, iy, iz)) + VZO(ix, iy, iz + 1));
-        backtrack<T>(Vx, Vx_o, vxc, vyc, vzc, dt, g, ix, iy, iz, nx + 1, ny, nz);
+        backtrack<T>(Vx, Vx_o, vxc, vyc, vzc, dt, g, ix, iy, iz, nx + 1, ny, nz, koff, gz0);
     }
     if (iy > 1 && iy < ny + 1 && ix <= nx && iz <= nz) { // multi.jl:224-229
         wy_ = true;
         vxc = (T)0.25 * (((VXO(ix, iy - 1, iz) + VXO(ix + 1, iy - 1, iz)) + VXO(ix, iy, iz)) + VXO(ix + 1, iy, iz));
         vyc = VYO(ix, iy, iz);
         vzc = (T)0.25 * (((VZO(ix, iy - 1, iz) + VZO(ix, iy - 1, iz + 1)) + VZO(ix, iy, iz)) + VZO(ix, iy, iz + 1));
-        backtrack<T>(Vy, Vy_o, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny + 1, nz);
+        backtrack<T>(Vy, Vy_o, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny + 1, nz, koff, gz0);
     }
     if (iz > 1 && iz < nz + 1 && ix <= nx && iy <= ny) { // multi.jl:230-235
         if (faithful) wy_ = true; else wz_ = true;
@@ -739,14 +746,14 @@ __global__ __launch_bounds__(256) void k_advect(T *__restrict__ Vx, const T *__r
         vzc = VZO(ix, iy, iz);
         // multi.jl:234 / gpu.jl:325 call backtrack!(Vy,Vy_o,…) here (sic): the SAME lane issued the branch-2
         // store to Vy[ix,iy,iz] above, so the two stores are ordered and this one wins, as in the reference.
-        if (faithful) backtrack<T>(Vy, Vy_o, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny + 1, nz);
-        else backtrack<T>(Vz, Vz_o, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny, nz + 1);
+        if (faithful) backtrack<T>(Vy, Vy_o, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny + 1, nz, koff, gz0);
+        else backtrack<T>(Vz, Vz_o, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny, nz + 1, koff, gz1);
     }
     if (ix <= nx && iy <= ny && iz <= nz) { // multi.jl:236-241
         vxc = (T)0.5 * (VXO(ix, iy, iz) + VXO(ix + 1, iy, iz));
         vyc = (T)0.5 * (VYO(ix, iy, iz) + VYO(ix, iy + 1, iz));
         vzc = (T)0.5 * (VZO(ix, iy, iz) + VZO(ix, iy, iz + 1));
-        backtrack<T>(C, C_o, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny, nz);
+        backtrack<T>(C, C_o, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny, nz, koff, gz0);
     }
     if (through) {      // the entries no branch stores keep their old values: written through, so that the outputs are complete
         if (!wx_ && iy <= ny && iz <= nz) Vx[IX3(ix - 1, iy - 1, iz - 1, nx + 1, ny)] = VXO(ix, iy, iz);
@@ -805,8 +812,10 @@ struct AdvWin {
 };
 template <class T>
 __device__ __forceinline__ void backtrack_win(T *__restrict__ A, const T *__restrict__ A_o, const AdvWin<T> &w, int a, T vxc, T vyc,
-                                              T vzc, T dt, const Geo<T> &g, int ix, int iy, int iz, int sx, int sy, int sz)
+                                              T vzc, T dt, const Geo<T> &g, int ix, int iy, int iz, int sx, int sy, int sz, int koff = 0,
+                                              int szg = 0)
 {
+    if (szg <= 0) szg = sz;                                  // see backtrack(): window of a global array
 #if NS3D_FASTMATH
     const T ddx = dt * vxc * g.rdx, ddy = dt * vyc * g.rdy, ddz = dt * vzc * g.rdz;
 #else
@@ -814,8 +823,9 @@ __device__ __forceinline__ void backtrack_win(T *__restrict__ A, const T *__rest
 #endif
     const int ix1 = clampf_i(floor_((T)ix - ddx), sx);
     const int iy1 = clampf_i(floor_((T)iy - ddy), sy);
-    const int iz1 = clampf_i(floor_((T)iz - ddz), sz);
-    const int ix2 = min(ix1 + 1, sx), iy2 = min(iy1 + 1, sy), iz2 = min(iz1 + 1, sz);
+    const int iz1g = clampf_i(floor_((T)(iz + koff) - ddz), szg);
+    const int iz1 = min(max(iz1g - koff, 1), sz), iz2 = min(max(min(iz1g + 1, szg) - koff, 1), sz);
+    const int ix2 = min(ix1 + 1, sx), iy2 = min(iy1 + 1, sy);
     const T wx = (ddx > (T)0 ? (T)1 : (T)0) - fmod1(ddx);
     const T wy = (ddy > (T)0 ? (T)1 : (T)0) - fmod1(ddy);
     const T wz = (ddz > (T)0 ? (T)1 : (T)0) - fmod1(ddz);
@@ -847,10 +857,11 @@ template <class T>
 __global__ __launch_bounds__(512) void k_advect_win(T *__restrict__ Vx, const T *__restrict__ Vx_o, T *__restrict__ Vy,
                                                     const T *__restrict__ Vy_o, T *__restrict__ Vz, const T *__restrict__ Vz_o,
                                                     T *__restrict__ C, const T *__restrict__ C_o, T dt, Geo<T> g, int nx, int ny,
-                                                    int nz, int flags, int kz)
+                                                    int nz, int flags, int kz, int koff, int nzg)
 {
     typedef AdvWin<T> W;
     const int faithful = flags & 1, through = flags & 2;
+    const int gz0 = nzg > 0 ? nzg : 0, gz1 = nzg > 0 ? nzg + 1 : 0;
     extern __shared__ __align__(16) unsigned char advect_lds_raw[];
     T *L = reinterpret_cast<T *>(advect_lds_raw);
     const int tid = threadIdx.y * W::TX + threadIdx.x;
@@ -908,28 +919,28 @@ __global__ __launch_bounds__(512) void k_advect_win(T *__restrict__ Vx, const T 
                 vxc = VXO(ix, iy, iz);
                 vyc = (T)0.25 * (((VYO(ix - 1, iy, iz) + VYO(ix - 1, iy + 1, iz)) + VYO(ix, iy, iz)) + VYO(ix, iy + 1, iz));
                 vzc = (T)0.25 * (((VZO(ix - 1, iy, iz) + VZO(ix - 1, iy, iz + 1)) + VZO(ix, iy, iz)) + VZO(ix, iy, iz + 1));
-                backtrack_win<T>(Vx, Vx_o, w, 0, vxc, vyc, vzc, dt, g, ix, iy, iz, nx + 1, ny, nz);
+                backtrack_win<T>(Vx, Vx_o, w, 0, vxc, vyc, vzc, dt, g, ix, iy, iz, nx + 1, ny, nz, koff, gz0);
             }
             if (iy > 1 && iy < ny + 1 && ix <= nx && iz <= nz) { // multi.jl:224-229
                 wy_ = true;
                 vxc = (T)0.25 * (((VXO(ix, iy - 1, iz) + VXO(ix + 1, iy - 1, iz)) + VXO(ix, iy, iz)) + VXO(ix + 1, iy, iz));
                 vyc = VYO(ix, iy, iz);
                 vzc = (T)0.25 * (((VZO(ix, iy - 1, iz) + VZO(ix, iy - 1, iz + 1)) + VZO(ix, iy, iz)) + VZO(ix, iy, iz + 1));
-                backtrack_win<T>(Vy, Vy_o, w, 1, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny + 1, nz);
+                backtrack_win<T>(Vy, Vy_o, w, 1, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny + 1, nz, koff, gz0);
             }
             if (iz > 1 && iz < nz + 1 && ix <= nx && iy <= ny) { // multi.jl:230-235 (sic: back-tracks Vy again in the reference)
                 if (faithful) wy_ = true; else wz_ = true;
                 vxc = (T)0.25 * (((VXO(ix, iy, iz - 1) + VXO(ix + 1, iy, iz - 1)) + VXO(ix, iy, iz)) + VXO(ix + 1, iy, iz));
                 vyc = (T)0.25 * (((VYO(ix, iy, iz - 1) + VYO(ix, iy + 1, iz - 1)) + VYO(ix, iy, iz)) + VYO(ix, iy + 1, iz));
                 vzc = VZO(ix, iy, iz);
-                if (faithful) backtrack_win<T>(Vy, Vy_o, w, 1, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny + 1, nz);
-                else backtrack_win<T>(Vz, Vz_o, w, 2, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny, nz + 1);
+                if (faithful) backtrack_win<T>(Vy, Vy_o, w, 1, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny + 1, nz, koff, gz0);
+                else backtrack_win<T>(Vz, Vz_o, w, 2, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny, nz + 1, koff, gz1);
             }
             if (ix <= nx && iy <= ny && iz <= nz) { // multi.jl:236-241
                 vxc = (T)0.5 * (VXO(ix, iy, iz) + VXO(ix + 1, iy, iz));
                 vyc = (T)0.5 * (VYO(ix, iy, iz) + VYO(ix, iy + 1, iz));
                 vzc = (T)0.5 * (VZO(ix, iy, iz) + VZO(ix, iy, iz + 1));
-                backtrack_win<T>(C, C_o, w, 3, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny, nz);
+                backtrack_win<T>(C, C_o, w, 3, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny, nz, koff, gz0);
             }
             if (through) {      // entries no branch stores: old value written through (complete outputs, see advect())
                 if (!wx_ && iy <= ny && iz <= nz) Vx[IX3(ix - 1, iy - 1, iz - 1, nx + 1, ny)] = VXO(ix, iy, iz);
@@ -951,13 +962,13 @@ __global__ __launch_bounds__(512) void k_advect_win(T *__restrict__ Vx, const T 
 // copies plus one pass ("avoidable by pointer swap").  Same values bit for bit.
 template <class T>
 hipError_t advect(hipStream_t s, T *Vx, const T *Vx_o, T *Vy, const T *Vy_o, T *Vz, const T *Vz_o, T *C,
-                  const T *C_o, double dt, double dx, double dy, double dz, int nx, int ny, int nz, int faithful)
+                  const T *C_o, double dt, double dx, double dy, double dz, int nx, int ny, int nz, int faithful, int koff, int nzg)
 {
     const char *glob = std::getenv("NS3D_ADVECT_GLOBAL");       // once per time step: read per call (A/B and tests flip it)
     const bool windowed = !(glob && *glob == '1');
     if (!windowed) {                                        // the one-thread-per-cell global gather (A/B, fallback)
         hipLaunchKernelGGL(k_advect<T>, grid3(nx + 1, ny + 1, nz + 1, BLK3), BLK3, 0, s, Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, C,
-                           C_o, (T)dt, make_geo<T>(dx, dy, dz), nx, ny, nz, faithful);
+                           C_o, (T)dt, make_geo<T>(dx, dy, dz), nx, ny, nz, faithful, koff, nzg);
         return hipGetLastError();
     }
     typedef AdvWin<T> W;
@@ -969,7 +980,7 @@ hipError_t advect(hipStream_t s, T *Vx, const T *Vx_o, T *Vy, const T *Vy_o, T *
     const dim3 blk(W::TX, W::TY, 1);
     const dim3 grd((unsigned)((nx + 1 + W::TX - 1) / W::TX), (unsigned)((ny + 1 + W::TY - 1) / W::TY), (unsigned)((nz + 1 + kz - 1) / kz));
     hipLaunchKernelGGL(k_advect_win<T>, grd, blk, lds, s, Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, C, C_o, (T)dt, make_geo<T>(dx, dy, dz), nx,
-                       ny, nz, faithful, kz);
+                       ny, nz, faithful, kz, koff, nzg);
     return hipGetLastError();
 }
 
@@ -2482,7 +2493,7 @@ hipError_t divtest(hipStream_t s, double d, long n, unsigned long long seed, uns
                                      double, int, int, int);                                                 \
     template hipError_t bc_plane<T>(hipStream_t, int, T *, int, int, int, double, double, double, int);      \
     template hipError_t advect<T>(hipStream_t, T *, const T *, T *, const T *, T *, const T *, T *,          \
-                                  const T *, double, double, double, double, int, int, int, int);            \
+                                  const T *, double, double, double, double, int, int, int, int, int, int);  \
     template hipError_t pt_sweep<T>(hipStream_t, int, const T *, T *, T *, const T *, const ns3d_pt_params &,\
                                     int, int);                                                               \
     template hipError_t pt_sweep2<T>(hipStream_t, int, const T *, T *, const T *, T *, const T *,            \

@@ -37,7 +37,7 @@
     hipError_t bc_plane(hipStream_t, int which, T *, int, int, int, double a, double b, double c, int nz_arg);\
     template <class T>                                                                                       \
     hipError_t advect(hipStream_t, T *, const T *, T *, const T *, T *, const T *, T *, const T *, double,   \
-                      double, double, double, int, int, int, int);                                           \
+                      double, double, double, int, int, int, int, int koff, int nzg);                        \
     template <class T>                                                                                       \
     hipError_t pt_sweep(hipStream_t, int variant, const T *, T *, T *, const T *, const ns3d_pt_params &,    \
                         int k0, int k1);                                                                     \

@@ -119,6 +119,8 @@ struct MRank {
     size_t cbuf_bytes = 0;
     void *gbuf = nullptr;                          // gather!: packed halo-stripped block
     size_t gbuf_bytes = 0;
+    void *wbuf = nullptr;                          // advect_wide: the four old and four new fields, one plane wider per seam
+    size_t wbuf_bytes = 0;
 };
 struct Block {                    // one contiguous piece that travels to both neighbours (pointers on the owning rank)
     void *send_lo, *recv_lo, *send_hi, *recv_hi;
@@ -806,6 +808,81 @@ int solve_cart(ns3d_mgpu *m, T *const *Pr, T *const *D, const T *const *divV, co
     return NS3D_OK;
 }
 
+// {X_o .= X; advect!; update_halo!} (multi.jl:475-477) with a z halo of width TWO for the old fields — an option outside the
+// reference's multi-rank semantics (SURVEY §7 "hard parts"; VERDICT r2 missing #5): backtrack! clamps its departure indices to
+// the LOCAL array (multi.jl:192-195), so with CFL_adv = 1 a departure point that crosses the one-plane halo is clamped on a
+// z-slab rank where the one-rank run reads the real neighbour — multi-rank results differ from one-rank results in the cells
+// next to a seam.  Here every rank advects on copies of the old fields extended by ONE MORE plane per seam (the neighbour's
+// plane sz−ol resp. ol+1, exchanged like halos), so departure points up to two planes away read what the global array holds;
+// the new fields' own planes are copied back, then ALL FOUR get their one-plane halo (the reference updates Vx, Vy, Vz only and
+// leaves C's halo planes to the clamped local computation).  With it the whole time step is decomposition-independent: P z-slab
+// ranks reproduce the one-rank run bit for bit while |δz| < 2 cells (tests/test_gpu_mgpu.py).
+template <class T>
+int advect_wide(ns3d_mgpu *m, T *const *V[4], T *const *Vo[4], double dt, double dx, double dy, double dz, int faithful)
+{
+    if (!z_slabs(m)) return fail(NS3D_ERR_STATE, "ns3d_advect_wide: z-slab topologies only (dims = (1,1,P))");
+    const int nx = m->nx, ny = m->ny, nz = m->nz;
+    const int ext[4][3] = {{nx + 1, ny, nz}, {nx, ny + 1, nz}, {nx, ny, nz + 1}, {nx, ny, nz}};     // Vx, Vy, Vz, C
+    if (m->P > 1 && nz < 5) return fail(NS3D_ERR_ARG, "ns3d_advect_wide: slabs of %d planes are too thin for a two-plane halo", nz);
+    size_t plane[4], off_o[4], off_n[4], total = 0;
+    for (int f = 0; f < 4; ++f) {
+        plane[f] = (size_t)ext[f][0] * ext[f][1];
+        off_o[f] = total; total += plane[f] * (ext[f][2] + 2);
+        off_n[f] = total; total += plane[f] * (ext[f][2] + 2);
+    }
+    std::vector<std::vector<Block>> blocks(m->loc.size());
+    int rc;
+    for (size_t l = 0; l < m->loc.size(); ++l) {
+        MRank &r = m->loc[l];
+        for (int f = 0; f < 4; ++f)
+            if (!V[f][l] || !Vo[f][l]) return fail(NS3D_ERR_ARG, "ns3d_advect_wide: null field pointer (local rank %zu)", l);
+        ns3d_device_guard g(r.device);
+        hipStream_t s = compute(r);
+        if (r.wbuf_bytes < total * sizeof(T)) {
+            if ((rc = sync_all(m))) return rc;           // a neighbour may still pull from the old buffer
+            if (r.wbuf) HIPCHK(0, hipFree(r.wbuf));
+            r.wbuf = nullptr; r.wbuf_bytes = 0;
+            HIPCHK(0, hipMalloc(&r.wbuf, total * sizeof(T)));
+            r.wbuf_bytes = total * sizeof(T);
+        }
+        const int elo = has_lower(m, r) ? 1 : 0;
+        T *W = (T *)r.wbuf;
+        for (int f = 0; f < 4; ++f) {
+            const int sz = ext[f][2], ol = 2 + (sz - nz);
+            T *old = W + off_o[f];
+            HIPCHK(0, hipMemcpyAsync(Vo[f][l], V[f][l], plane[f] * sz * sizeof(T), hipMemcpyDeviceToDevice, s));          // X_o .= X
+            HIPCHK(0, hipMemcpyAsync(old + plane[f] * elo, V[f][l], plane[f] * sz * sizeof(T), hipMemcpyDeviceToDevice, s));
+            // 1-based planes of the local array: ol+1 → the lower neighbour's extra plane above its array, sz−ol → the upper
+            // neighbour's extra plane below its array; in the extended copy local plane q sits at index q−1+elo
+            blocks[l].push_back({old + plane[f] * (ol + elo), old, old + plane[f] * (sz - ol - 1 + elo), old + plane[f] * (sz + elo),
+                                 plane[f] * sizeof(T)});
+        }
+    }
+    if ((rc = exchange_begin(m, blocks))) return rc;
+    if ((rc = exchange_end(m))) return rc;
+    for (size_t l = 0; l < m->loc.size(); ++l) {
+        MRank &r = m->loc[l];
+        ns3d_device_guard g(r.device);
+        hipStream_t s = compute(r);
+        const int elo = has_lower(m, r) ? 1 : 0, ehi = has_upper(m, r) ? 1 : 0;
+        T *W = (T *)r.wbuf;
+        hipError_t e = ns3d_enqueue_advect<T>(r.ctx, s, W + off_n[0], W + off_o[0], W + off_n[1], W + off_o[1], W + off_n[2], W + off_o[2],
+                                              W + off_n[3], W + off_o[3], dt, dx, dy, dz, nx, ny, nz + elo + ehi, (faithful ? 1 : 0) | 2,
+                                              r.coords[2] * (nz - 2) - elo, m->dims[2] * (nz - 2) + 2);    // departure indices from GLOBAL plane numbers
+        if (e != hipSuccess) return fail(NS3D_ERR_HIP, "advect launch: %s", hipGetErrorString(e));
+        for (int f = 0; f < 4; ++f)
+            HIPCHK(0, hipMemcpyAsync(V[f][l], W + off_n[f] + plane[f] * elo, plane[f] * ext[f][2] * sizeof(T), hipMemcpyDeviceToDevice, s));
+    }
+    // update_halo!(Vx, Vy, Vz) (multi.jl:477) — and C, whose halo planes were computed above from clamped departure points
+    std::vector<T *> flat(4 * m->loc.size());
+    int extents[12];
+    for (int f = 0; f < 4; ++f) {
+        for (size_t l = 0; l < m->loc.size(); ++l) flat[(size_t)f * m->loc.size() + l] = V[f][l];
+        for (int d = 0; d < 3; ++d) extents[3 * f + d] = ext[f][d];
+    }
+    return update_halo_core<T>(m, flat.data(), extents, 4);
+}
+
 // rank block (bx×by×bz, packed) → its place in the global halo-stripped array (column-major, dims·block entries per side)
 template <class T>
 void place_block(const T *blk, T *out, const int c[3], int bx, int by, int bz, const int dims[3])
@@ -1032,6 +1109,7 @@ void ns3d_mgpu_destroy(ns3d_mgpu *m)
         if (r.gbuf) (void)hipFree(r.gbuf);
         if (r.hbuf) (void)hipFree(r.hbuf);
         if (r.cbuf) (void)hipFree(r.cbuf);
+        if (r.wbuf) (void)hipFree(r.wbuf);
         if (r.ev_ready) (void)hipEventDestroy(r.ev_ready);
         if (r.ev_landed) (void)hipEventDestroy(r.ev_landed);
         if (r.ev_pass) (void)hipEventDestroy(r.ev_pass);
@@ -1158,6 +1236,17 @@ int ns3d_slab_residual(ns3d_mgpu *m, double *out)
         if (nfields < 0 || (nfields > 0 && (!fields || !extents)))                                           \
             return fail(NS3D_ERR_ARG, "ns3d_update_halo: bad field list");                                   \
         return update_halo_impl<T>(m, fields, extents, nfields);                                             \
+    }                                                                                                        \
+    extern "C" int ns3d_advect_wide_##S(ns3d_mgpu *m, T *const *Vx, T *const *Vx_o, T *const *Vy, T *const *Vy_o, T *const *Vz, \
+                                        T *const *Vz_o, T *const *C, T *const *C_o, double dt, double dx, double dy, double dz, \
+                                        int faithful)                                                        \
+    {                                                                                                        \
+        CHECK_M(m);                                                                                          \
+        if (!Vx || !Vx_o || !Vy || !Vy_o || !Vz || !Vz_o || !C || !C_o) return fail(NS3D_ERR_ARG, "ns3d_advect_wide: null field list"); \
+        T *const *V[4] = {Vx, Vy, Vz, C};                                                                    \
+        T *const *Vo[4] = {Vx_o, Vy_o, Vz_o, C_o};                                                           \
+        int rc = advect_wide<T>(m, V, Vo, dt, dx, dy, dz, faithful);                                         \
+        return rc ? rc : finish_m(m);                                                                        \
     }                                                                                                        \
     extern "C" int ns3d_gather_##S(ns3d_mgpu *m, const T *const *A, int sx, int sy, int sz, T *out_host)     \
     {                                                                                                        \

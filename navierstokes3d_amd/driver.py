@@ -136,7 +136,7 @@ def pt_loop_fused_slab(ctx, grid, f, p, pt, niter, do_print=False, scratch=None)
 
 def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=10, *, mode="strict", fused=True,
                        temporal=True, dtype=torch.float64, faithful=True, grid=None, device=None, niter_cap=None,
-                       return_info=False, shape=None, pressure="pt"):
+                       return_info=False, shape=None, pressure="pt", wide_advect_halo=False):
     """run_navierstokes3D (multi.jl:287-536).  nx is the LOCAL streamwise size (ny = nz = ceil(0.6 nx) local).
     `grid` decides the decomposition: None = one rank; a halo.ZSlabGrid = this process is one z-slab rank of an
     initialised torch.distributed group; a mgpu.MgpuGrid = the C-ABI grid (this process drives every local rank of an
@@ -146,7 +146,10 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
     produce without editing them (BASELINE configs[3]: 512×512×1024 global).
     pressure="direct" (OUTSIDE PARITY; one rank): the inner loop :458-471 is replaced by ns3d_poisson_direct, the
     exact solution of the discrete problem that loop stops short of by εit; info.iters is 0 per step and info.errs holds the
-    residual of the solution in the reference's own measure (:466)."""
+    residual of the solution in the reference's own measure (:466).
+    wide_advect_halo=True (OUTSIDE the reference's multi-rank semantics; z-slabs on the C-ABI grid): :475-477 run as
+    ns3d_advect_wide — old fields with a two-plane z halo, C's halo updated too — so that the P-rank run reproduces the one-rank
+    run of the same global grid bit for bit (the reference's backtrack! clamps to the local array)."""
     if pressure not in ("pt", "direct"):
         raise L.Ns3dError("pressure = %r (\"pt\" | \"direct\")" % (pressure,))
     if device is None:
@@ -264,14 +267,22 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
             K.set_cylinder(f.C, f.Vx, f.Vy, f.Vz, *cyl, ctx=c)                                # :473
             K.set_bc_Vel_multi(f.Vx, f.Vy, f.Vz, q.owns_inlet, p.vin, ctx=c)                   # :474 → :157-166
         grid.update_halo(col("Vx"), col("Vy"), col("Vz"))                                     # :167
+        if wide_advect_halo and P > 1:                                                         # :475-477, decomposition-independent
+            if mg is None or not (dims[0] == 1 and dims[1] == 1):
+                raise L.Ns3dError("wide_advect_halo needs z-slab ranks on the C-ABI grid (mgpu.MgpuGrid)")
+            mg.advect_wide(col("Vx"), col("Vx_o"), col("Vy"), col("Vy_o"), col("Vz"), col("Vz_o"), col("C"), col("C_o"),
+                           p.dt, p.dx, p.dy, p.dz, faithful)
         for f, c in zip(fs, ctxs):
+            if wide_advect_halo and P > 1:
+                break
             if fused:       # :475-476 in one pass (ns3d_copy_advect): complete new fields into the *_o buffers, then the roles swap
                 _copy_advect_swap(f, p, faithful, c)
                 continue
             K.copy(f.Vx_o, f.Vx, ctx=c); K.copy(f.Vy_o, f.Vy, ctx=c)                          # :475
             K.copy(f.Vz_o, f.Vz, ctx=c); K.copy(f.C_o, f.C, ctx=c)
             K.advect(f.Vx, f.Vx_o, f.Vy, f.Vy_o, f.Vz, f.Vz_o, f.C, f.C_o, p.dt, p.dx, p.dy, p.dz, faithful, ctx=c)  # :476
-        grid.update_halo(col("Vx"), col("Vy"), col("Vz"))                                     # :477 (not C)
+        if not (wide_advect_halo and P > 1):
+            grid.update_halo(col("Vx"), col("Vy"), col("Vz"))                                 # :477 (not C)
         if (do_vis and it % nvis == 0) or (do_save and it % nsave == 0):                      # :479-525 (one frame counter)
             sync()
             gathered = _gather_all(grid, fs)
@@ -280,7 +291,7 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
             if do_save and it % nsave == 0:                                                   # :515-522
                 _save_frame(grid, gathered, iframe)
             iframe += 1
-    if fused and faithful and nt > 0:
+    if fused and faithful and nt > 0 and not (wide_advect_halo and P > 1):
         for f, c in zip(fs, ctxs):
             K.copy(f.Vz_o, f.Vz, ctx=c)     # the one copy of :475 the swaps skipped (Vz is never advected): same final state
     sync()

@@ -105,6 +105,7 @@ MGPU_SIGNATURES = {   # typed (_f64/_f32), after the leading ns3d_mgpu*
     "gather": [_PP, _I, _I, _I, _P],
     "slab_load": [_PP, _PP, _PP, C.POINTER(PtParams)],
     "slab_store": [_PP, _PP],
+    "advect_wide": [_PP] * 8 + [_D] * 4 + [_I],
     "pt_solve_slab": [_PP, _PP, _PP, C.POINTER(PtParams), _D, _I, _I, _D, _D, C.POINTER(_I), C.POINTER(_D), _I,
                       C.POINTER(_I)],
 }

@@ -200,6 +200,17 @@ class MultiGpu:
                                               out.ctypes.data_as(C.c_void_p) if is_root else None))
         return out
 
+    # ---- {X_o .= X; advect!; update_halo!} with a two-plane z halo (outside the reference's multi-rank semantics) ------
+    def advect_wide(self, Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, Cf, C_o, dt, dx, dy, dz, faithful=True):
+        """multi.jl:475-477 on z-slab ranks, decomposition-independent: the old fields' z halo is widened to two planes, so that
+        departure points up to two planes away read the neighbour instead of being clamped to the local array; all four new
+        fields (C too) get their halo.  P ranks then reproduce the one-rank time step bit for bit (|δz| < 2 cells)."""
+        self._follow_torch_streams()
+        ref = _as_list(Cf)[0]
+        L.check(self._typed("advect_wide", ref)(self.handle, self._ptrs([Vx]), self._ptrs([Vx_o]), self._ptrs([Vy]), self._ptrs([Vy_o]),
+                                                self._ptrs([Vz]), self._ptrs([Vz_o]), self._ptrs([Cf]), self._ptrs([C_o]),
+                                                C.c_double(dt), C.c_double(dx), C.c_double(dy), C.c_double(dz), 1 if faithful else 0))
+
     # ---- pseudo-transient loop of the z-slab ranks -------------------------------------------------------------
     def set_temporal(self, depth):
         L.check(self.lib.ns3d_mgpu_set_temporal(self.handle, int(depth)))

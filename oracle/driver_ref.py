@@ -147,8 +147,44 @@ def gather_z(ranks, name):
     return gather_3d(ranks, name, (1, 1, len(ranks)))
 
 
+def advect_wide_z(ranks, p, faithful):
+    """The option outside the reference's multi-rank semantics (ns3d_advect_wide): {X_o .= X; advect!; update_halo!} with the old
+    fields extended by ONE MORE plane per seam (the neighbour's plane sz-ol resp. ol+1), so that departure points up to two planes
+    away read the neighbour instead of being clamped to the local array (multi.jl:192-195); all four new fields get their halo."""
+    P = len(ranks)
+    nz = ranks[0]["C"].shape[2]
+    names = ("Vx", "Vy", "Vz", "C")
+    ext_old = []
+    for r, f in enumerate(ranks):
+        e = {}
+        for n in names:
+            A = f[n]
+            sz = A.shape[2]; ol = 2 + (sz - nz)
+            parts = []
+            if r > 0:
+                parts.append(ranks[r - 1][n][:, :, sz - ol - 1:sz - ol])          # 1-based plane sz-ol of the lower neighbour
+            parts.append(A)
+            if r < P - 1:
+                parts.append(ranks[r + 1][n][:, :, ol:ol + 1])                    # 1-based plane ol+1 of the upper neighbour
+            e[n] = np.asfortranarray(np.concatenate(parts, axis=2))
+        ext_old.append(e)
+    for r, f in enumerate(ranks):
+        for n in names:
+            f[n + "_o"][...] = f[n]                                               # :475
+    for r, f in enumerate(ranks):
+        elo = 1 if r > 0 else 0
+        old = ext_old[r]
+        new = {n: old[n].copy(order="F") for n in names}
+        K.advect_window(new["Vx"], old["Vx"], new["Vy"], old["Vy"], new["Vz"], old["Vz"], new["C"], old["C"], p.dt, p.dx, p.dy, p.dz,
+                        faithful, r * (nz - 2) - elo, P * (nz - 2) + 2)
+        for n in names:
+            f[n][...] = new[n][:, :, elo:elo + f[n].shape[2]]
+    for n in names:
+        update_halo_3d(ranks, n, (ranks[0]["C"].shape[0], ranks[0]["C"].shape[1], nz), (1, 1, P))
+
+
 def run_navierstokes3D_ref(nx=63, nt=1, dims_z=1, dtype=np.float64, faithful=True, niter_cap=None,
-                           record=None, shape=None, dims=None, pressure="pt"):
+                           record=None, shape=None, dims=None, pressure="pt", wide_advect_halo=False):
     """multi.jl:287-536 without vis/save.  Returns (C_v,Pr_v,Vx_v,Vy_v,Vz_v, info) where info holds the
     per-step PT iteration counts and err histories, and the final local states."""
     p = multi_params(nx, dims_z, dtype, dims=dims, **(shape or {}))
@@ -243,11 +279,14 @@ def run_navierstokes3D_ref(nx=63, nt=1, dims_z=1, dtype=np.float64, faithful=Tru
             K.set_bc_Vel(f.Vx, f.Vy, f.Vz, 0, f.owns_inlet, p.vin)
         for n in ("Vx", "Vy", "Vz"):                                                       # :167
             update_halo_z(ranks, n, nz)
-        for f in ranks:                                                                    # :475-476
-            K.copy(f.Vx_o, f.Vx); K.copy(f.Vy_o, f.Vy); K.copy(f.Vz_o, f.Vz); K.copy(f.C_o, f.C)
-            K.advect(f.Vx, f.Vx_o, f.Vy, f.Vy_o, f.Vz, f.Vz_o, f.C, f.C_o, p.dt, p.dx, p.dy, p.dz, faithful)
-        for n in ("Vx", "Vy", "Vz"):                                                       # :477 (not C)
-            update_halo_z(ranks, n, nz)
+        if wide_advect_halo and P > 1:
+            advect_wide_z(ranks, p, faithful)
+        else:
+            for f in ranks:                                                                # :475-476
+                K.copy(f.Vx_o, f.Vx); K.copy(f.Vy_o, f.Vy); K.copy(f.Vz_o, f.Vz); K.copy(f.C_o, f.C)
+                K.advect(f.Vx, f.Vx_o, f.Vy, f.Vy_o, f.Vz, f.Vz_o, f.C, f.C_o, p.dt, p.dx, p.dy, p.dz, faithful)
+            for n in ("Vx", "Vy", "Vz"):                                                   # :477 (not C)
+                update_halo_z(ranks, n, nz)
         if record is not None:
             record(it, ranks, info)
     info.ranks = ranks

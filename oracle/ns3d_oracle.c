@@ -392,14 +392,21 @@ static inline REAL floor_(REAL a) { return sizeof(REAL) == 4 ? (REAL)floorf((flo
 
 /* backtrack!(A,A_o,vxc,vyc,vzc,dt,dx,dy,dz,ix,iy,iz)  — ix,iy,iz are 1-based as in the reference;
  * A has extents (sx,sy,sz)                                     multi.jl:190-205, gpu.jl:288-304 */
+/* koff / szg (NOT in the reference; 0 / sz reproduce it): the array is a WINDOW of a global array of szg planes that starts koff
+ * planes into it (ns3d_advect_wide).  The departure index is then computed from the GLOBAL plane number — `Float(iz) − δ` rounds
+ * differently for iz = 2 and iz = 12 when δ is below an ulp of either (multi.jl:194 on a rank's local indices is therefore
+ * decomposition-dependent even where no clamp bites) — clamped to the global array and translated back. */
+static int g_koff = 0, g_nzg = 0, g_nz_local = 0; /* set by ns3d_ref_advect_window around its call of ns3d_ref_advect */
 static inline void backtrack(REAL *A, const REAL *A_o, REAL vxc, REAL vyc, REAL vzc, REAL dt, REAL dx,
                              REAL dy, REAL dz, int ix, int iy, int iz, int sx, int sy, int sz)
 {
     REAL ddx = dt * vxc / dx, ddy = dt * vyc / dy, ddz = dt * vzc / dz;
+    const int koff = g_koff, szg = g_nzg > 0 ? g_nzg + (sz - g_nz_local) : sz;
     int ix1 = clampi((long)floor_(R(ix) - ddx), 1, sx);
     int iy1 = clampi((long)floor_(R(iy) - ddy), 1, sy);
-    int iz1 = clampi((long)floor_(R(iz) - ddz), 1, sz);
-    int ix2 = clampi(ix1 + 1, 1, sx), iy2 = clampi(iy1 + 1, 1, sy), iz2 = clampi(iz1 + 1, 1, sz);
+    int iz1 = clampi((long)floor_(R(iz + koff) - ddz), 1, szg);
+    int ix2 = clampi(ix1 + 1, 1, sx), iy2 = clampi(iy1 + 1, 1, sy), iz2 = clampi(iz1 + 1, 1, szg);
+    iz1 = clampi(iz1 - koff, 1, sz); iz2 = clampi(iz2 - koff, 1, sz);
     /* δ = (δ>0) − (δ % 1): Julia `%` on floats is rem = C fmod (sign of the dividend) */
     REAL wx = (ddx > R(0) ? R(1) : R(0)) - fmod_(ddx, R(1));
     REAL wy = (ddy > R(0) ? R(1) : R(0)) - fmod_(ddy, R(1));
@@ -424,6 +431,7 @@ void FN(ns3d_ref_advect)(REAL *Vx, const REAL *Vx_o, REAL *Vy, const REAL *Vy_o,
                          double dy_, double dz_, int nx, int ny, int nz, int faithful)
 {
     const REAL dt = R(dt_), dx = R(dx_), dy = R(dy_), dz = R(dz_);
+    g_nz_local = nz;
 #define VXO(i, j, k) Vx_o[IX((i)-1, (j)-1, (k)-1, nx + 1, ny)]
 #define VYO(i, j, k) Vy_o[IX((i)-1, (j)-1, (k)-1, nx, ny + 1)]
 #define VZO(i, j, k) Vz_o[IX((i)-1, (j)-1, (k)-1, nx, ny)]
@@ -463,6 +471,16 @@ void FN(ns3d_ref_advect)(REAL *Vx, const REAL *Vx_o, REAL *Vy, const REAL *Vy_o,
 #undef VXO
 #undef VYO
 #undef VZO
+}
+
+/* advect! on a window of a global grid (see backtrack): koff planes into a global array of nz_glob cell planes */
+void FN(ns3d_ref_advect_window)(REAL *Vx, const REAL *Vx_o, REAL *Vy, const REAL *Vy_o, REAL *Vz, const REAL *Vz_o, REAL *C,
+                                const REAL *C_o, double dt_, double dx_, double dy_, double dz_, int nx, int ny, int nz,
+                                int faithful, int koff, int nz_glob)
+{
+    g_koff = koff; g_nzg = nz_glob;
+    FN(ns3d_ref_advect)(Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, C, C_o, dt_, dx_, dy_, dz_, nx, ny, nz, faithful);
+    g_koff = 0; g_nzg = 0;
 }
 
 /* ---- host sequences ------------------------------------------------------------------------ */

@@ -161,6 +161,13 @@ def advect(Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, Cf, C_o, dt, dx, dy, dz, faithful=True)
           *_d(dt, dx, dy, dz), *_i(nx, ny, nz, 1 if faithful else 0))
 
 
+def advect_window(Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, Cf, C_o, dt, dx, dy, dz, faithful, koff, nz_glob):
+    """advect! on a window of a global grid that starts koff planes into it (departure indices from GLOBAL plane numbers)"""
+    nx, ny, nz = Cf.shape
+    _call("advect_window", Cf, _p(Vx), _p(Vx_o), _p(Vy), _p(Vy_o), _p(Vz), _p(Vz_o), _p(Cf), _p(C_o),
+          *_d(dt, dx, dy, dz), *_i(nx, ny, nz, 1 if faithful else 0, koff, nz_glob))
+
+
 def set_bc_Pr(Pr, bc_kind, owns_outlet=True, outlet_val=0.0, dz=0.0, nz_arg=0, g=0.0, rho=0.0):
     nx, ny, nz = Pr.shape
     _call("set_bc_Pr", Pr, _p(Pr), *_i(bc_kind, owns_outlet), *_d(outlet_val, dz), *_i(nz_arg), *_d(g, rho),

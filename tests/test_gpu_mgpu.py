@@ -286,6 +286,78 @@ def test_driver_on_mgpu_grid_vs_oracle_virtual_ranks(hip, P, fused, temporal):
     mg.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("P,nz,cfl", [(2, 9, 0.6), (2, 9, 1.9), (3, 7, 1.5), (4, 6, 1.2), (3, 12, 1.9)])
+def test_advect_wide_is_the_global_advect(hip, oracle, P, nz, cfl, dtype):
+    """ns3d_advect_wide (outside the reference's multi-rank semantics): {X_o .= X; advect!; update_halo!} on P z-slab ranks with a
+    two-plane halo for the old fields equals advect! on the GLOBAL arrays — every local plane of every rank, halo planes and
+    physical ends included, bit for bit, for departure points up to 1.9 cells away (cfl·|v| ≤ 1.9 with |v| ≤ 1), both advection
+    modes; the *_o arrays hold the old fields.  (With the reference's one-plane halo backtrack! clamps to the local array:
+    the plain multi-rank advect! differs from the global one — also checked, so that the test cannot pass vacuously.)"""
+    nx, ny = 21, 10
+    nz_g = P * (nz - 2) + 2
+    g = geometry(nx, ny, nz_g)
+    glob = fields(nx, ny, nz_g, ["vx", "vy", "vz", "c"], 321, dtype)
+    dt = cfl * min(g["dx"], g["dy"], g["dz"])
+    cutn = {0: nz, 1: nz, 2: nz + 1, 3: nz}
+    for faithful in (True, False):
+        ref = [a.copy(order="F") for a in glob]
+        old = [a.copy(order="F") for a in glob]
+        oracle.advect(ref[0], old[0], ref[1], old[1], ref[2], old[2], ref[3], old[3], dt, g["dx"], g["dy"], g["dz"], faithful)
+        mg = _mg(P, nx, ny, nz)
+        loc = [[hip.from_numpy(np.asfortranarray(glob[f][:, :, r * (nz - 2):r * (nz - 2) + cutn[f]])) for r in range(P)] for f in range(4)]
+        loco = [[hip.zeros(tuple(t.shape), t.dtype) for t in loc[f]] for f in range(4)]
+        mg.advect_wide(loc[0], loco[0], loc[1], loco[1], loc[2], loco[2], loc[3], loco[3], dt, g["dx"], g["dy"], g["dz"], faithful)
+        mg.sync()
+        for f in range(4):
+            for r in range(P):
+                lo = r * (nz - 2)
+                assert np.array_equal(hip.to_numpy(loc[f][r]), ref[f][:, :, lo:lo + cutn[f]]), (f, r, faithful)
+                assert np.array_equal(hip.to_numpy(loco[f][r]), glob[f][:, :, lo:lo + cutn[f]]), ("old", f, r)
+        mg.close()
+    # the reference's own multi-rank semantics on the same data: local clamps change the cells next to a seam once |δz| > 1
+    if cfl > 1.0:
+        differs = False
+        for r in range(P):
+            lo = r * (nz - 2)
+            new = [hip.from_numpy(np.asfortranarray(glob[f][:, :, lo:lo + cutn[f]])) for f in range(4)]
+            oldl = [hip.clone(t) for t in new]
+            hip.advect(new[0], oldl[0], new[1], oldl[1], new[2], oldl[2], new[3], oldl[3], dt, g["dx"], g["dy"], g["dz"], False)
+            own = slice(1 if r > 0 else 0, nz - 1 if r < P - 1 else nz)
+            differs |= not np.array_equal(hip.to_numpy(new[3])[:, :, own], ref[3][:, :, lo:lo + nz][:, :, own])
+        assert differs
+
+
+@pytest.mark.parametrize("P,nz_loc", [(2, 12), (4, 7)])
+def test_driver_with_wide_advect_halo_reproduces_the_one_rank_run(hip, P, nz_loc):
+    """The whole time step becomes decomposition-independent: P z-slab ranks with wide_advect_halo=True return the one-rank run's
+    gathered fields and iteration counts bit for bit (same global 36×22×22 grid, a size at which the reference's iteration stays
+    finite; every other kernel already is decomposition-independent: local stencils
+    behind update_halo!, Jacobi sweeps).  Without the option the P-rank run is the reference's P-rank run, which is a different
+    result — the oracle's virtual ranks cover that."""
+    from navierstokes3d_amd.driver import run_navierstokes3D
+    from navierstokes3d_amd.mgpu import MgpuGrid, MultiGpu
+    from navierstokes3d_amd.params import multi_params
+    nx, nt = 36, 3
+    one = run_navierstokes3D(nx=nx, nt=nt, mode="strict", return_info=True)
+    assert one[-1].params.nz == P * (nz_loc - 2) + 2 and all(np.isfinite(a).all() for a in one[:5])
+    p0 = multi_params(nx, dims=(1, 1, P), coords=(0, 0, 0), nz=nz_loc)
+    mg = MultiGpu.create([0] * P, p0.nx, p0.ny, p0.nz, "strict", own_streams=OWN_STREAMS)
+    out = run_navierstokes3D(nx=nx, nt=nt, mode="strict", grid=MgpuGrid(mg, p0.nx, p0.ny, p0.nz), return_info=True, shape=dict(nz=nz_loc),
+                             wide_advect_halo=True)
+    assert out[-1].iters == one[-1].iters and out[-1].errs == one[-1].errs
+    for n, a, b in zip(("C", "Pr", "Vx", "Vy"), out[:4], one[:4]):          # (the gathered Vz has another shape for P > 1: DESIGN §6)
+        assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True), n
+    # every local plane of every rank, halo planes included, against the one-rank fields
+    for r in range(P):
+        lo = r * (nz_loc - 2)
+        for n, extra in (("C", 0), ("Pr", 0), ("Vx", 0), ("Vy", 0), ("Vz", 1), ("divV", 0)):
+            a = hip.to_numpy(getattr(out[-1].local_fields[r], n))
+            b = hip.to_numpy(getattr(one[-1].fields, n))[:, :, lo:lo + nz_loc + extra]
+            assert np.array_equal(a, b, equal_nan=True), (r, n)
+    mg.close()
+
+
 def test_dims_create_is_mpi_dims_create(hip):
     """init_global_grid's default topology (multi.jl:325 passes no dimx/dimy/dimz): MPI_Dims_create — balanced, non-increasing,
     fixed entries kept."""

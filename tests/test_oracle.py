@@ -574,3 +574,32 @@ def test_pt_loop_converges_to_the_direct_solution(oracle):
     it, errs = oracle.pt_solve(Pr, d, rhs, Rp, g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, True, 0.0, 0.0,
                                1e-13, 20000, 50, 1.0, np.abs(ref).max() / dx ** 2)
     assert it < 20000 and rel_l2(Pr, ref) < 1e-9, (it, rel_l2(Pr, ref))
+
+
+@pytest.mark.parametrize("P,nz_loc", [(2, 12), (4, 7)])
+def test_wide_advect_halo_makes_the_oracle_s_time_step_decomposition_independent(oracle, P, nz_loc):
+    """The option outside the reference's multi-rank semantics (ns3d_advect_wide; oracle/driver_ref.py::advect_wide_z): with the old
+    fields' z halo two planes wide, C's halo updated, AND the departure indices computed from GLOBAL plane numbers, P virtual ranks
+    reproduce the one-rank run of the same 36×22×22 grid bit for bit — every plane of every field after three steps (105 PT
+    iterations in the last one).  The reference's own multi-rank run does not (second half of the test): backtrack! clamps to the
+    local array, update_halo! skips C (multi.jl:477), and `Float(iz) − δ` (multi.jl:194) rounds differently for a rank's local
+    iz = 2 and the global iz = 12 when δ is below an ulp — the near-zero vertical velocities of the first steps are exactly there."""
+    from oracle.driver_ref import run_navierstokes3D_ref
+    nx, nt = 36, 3
+    one = run_navierstokes3D_ref(nx=nx, nt=nt)
+    f1 = one[-1].ranks[0]
+    assert one[-1].params.nz == P * (nz_loc - 2) + 2 and all(np.isfinite(a).all() for a in one[:5])
+
+    def mismatches(out):
+        bad = []
+        for r in range(P):
+            lo = r * (nz_loc - 2)
+            for n, extra in (("C", 0), ("Pr", 0), ("Vx", 0), ("Vy", 0), ("Vz", 1), ("divV", 0), ("dPrdtau", -2)):
+                if not np.array_equal(out[-1].ranks[r][n], f1[n][:, :, lo:lo + nz_loc + extra]):
+                    bad.append((r, n))
+        return bad
+
+    wide = run_navierstokes3D_ref(nx=nx, nt=nt, dims_z=P, shape=dict(nz=nz_loc), wide_advect_halo=True)
+    assert wide[-1].iters == one[-1].iters and wide[-1].errs == one[-1].errs and mismatches(wide) == []
+    plain = run_navierstokes3D_ref(nx=nx, nt=nt, dims_z=P, shape=dict(nz=nz_loc))
+    assert mismatches(plain) != []
