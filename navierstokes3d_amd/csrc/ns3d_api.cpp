@@ -120,6 +120,7 @@ ns3d_ctx *ns3d_create(int device, int flags)
     c->last_depth = 0;
     c->tune_ev[0] = c->tune_ev[1] = nullptr;
     c->graph_mode = -1;
+    if (const char *ev = std::getenv("NS3D_GRAPH_MODE")) c->graph_mode = std::atoi(ev);     // A/B without an API call
     c->fence = nullptr;
     c->key_dev = nullptr;
     c->key_host = nullptr;
