@@ -109,6 +109,12 @@ int ns3d_arith_build(const ns3d_ctx *ctx, double dx, double dy, double dz);
 /* ns3d_pt_solve replays each residual-check block (nchk iterations) as one HIP graph: -1 = automatically on
  * launch-bound grids (< 3 M cells), 0 = never, 1 = always.  Same results either way. */
 int ns3d_set_graph_mode(ns3d_ctx *ctx, int mode);
+/* ns3d_pt_iterate / ns3d_pt_solve on launch-bound grids: a whole block of iterations (up to the next residual check) in ONE
+ * cooperative launch that keeps the grid on the chip (k_pt_persist: a cell per thread, faces handed between workgroups through
+ * global memory after every iteration): -1 = automatically where it was measured to win (up to 170 000 cells, nx <= 66, no
+ * explicit depth / tile / graph request) and the workgroups fit the chip together, 0 = never, 1 = wherever they fit.  Same
+ * results either way; a hand-over that never arrives (bounded wait) leaves NaN in Pr and d.  Env NS3D_PT_PERSIST sets the default. */
+int ns3d_set_persist_mode(ns3d_ctx *ctx, int mode);
 int ns3d_cached_graphs(const ns3d_ctx *ctx);      /* residual-check blocks this context holds as instantiated HIP graphs */
 
 /* Parameters of the fused pseudo-transient path (ns3d_pt_iterate / ns3d_pt_solve). */

@@ -121,6 +121,7 @@ ns3d_ctx *ns3d_create(int device, int flags)
     c->tune_ev[0] = c->tune_ev[1] = nullptr;
     c->graph_mode = -1;
     if (const char *ev = std::getenv("NS3D_GRAPH_MODE")) c->graph_mode = std::atoi(ev);     // A/B without an API call
+    if (const char *ev = std::getenv("NS3D_PT_PERSIST")) c->persist_mode = std::atoi(ev);
     c->fence = nullptr;
     c->key_dev = nullptr;
     c->key_host = nullptr;
@@ -203,6 +204,13 @@ int ns3d_set_autotune(ns3d_ctx *c, int on)
 int ns3d_last_pt2_variant(const ns3d_ctx *c) { return c ? c->last_pt2 : -1; }
 int ns3d_last_ptn_variant(const ns3d_ctx *c) { return c ? c->last_ptn : -1; }
 int ns3d_last_pt_depth(const ns3d_ctx *c) { return c ? c->last_depth : -1; }
+int ns3d_set_persist_mode(ns3d_ctx *c, int mode)
+{
+    if (!c) return fail(NS3D_ERR_ARG, "ns3d_set_persist_mode: null context");
+    if (mode < -1 || mode > 1) return fail(NS3D_ERR_ARG, "ns3d_set_persist_mode: %d (-1 auto, 0 off, 1 on)", mode);
+    c->persist_mode = mode;
+    return NS3D_OK;
+}
 int ns3d_cached_graphs(const ns3d_ctx *c) { return c ? (int)c->graphs.size() : -1; }
 int ns3d_arith_build(const ns3d_ctx *c, double dx, double dy, double dz) { return c ? mode_of(c, dx, dy, dz) : -1; }
 
@@ -577,6 +585,8 @@ NS3D_INST_INTERNAL(float)
 #undef NS3D_INST_INTERNAL
 
 template <class T>
+static bool use_persist(const ns3d_ctx *c, const ns3d_pt_params *p);
+template <class T>
 static hipError_t enqueue_iters(ns3d_ctx *c, hipStream_t s, int n, bool two, T *&src, T *&dst, T *&dsrc, T *&ddst,
                                 const T *divV, const ns3d_pt_params *p, bool may_tune);
 
@@ -615,6 +625,17 @@ static hipError_t enqueue_iters(ns3d_ctx *c, hipStream_t s, int n, bool two, T *
                                 const T *divV, const ns3d_pt_params *p, bool may_tune)
 {
     hipError_t e = hipSuccess;
+    // small grids: the whole block of n iterations in one cooperative launch (k_pt_persist), where it applies
+    if (n >= 2 && use_persist<T>(c, p)) {
+        e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_persist<T>(s, src, dst, dsrc, divV, *p, n));
+        if (e == hipSuccess) {
+            T *t = src; src = dst; dst = t;
+            return e;
+        }
+        if (e != hipErrorInvalidValue) return e;     // invalid value: the form does not apply here → the ordinary path
+        (void)hipGetLastError();
+        e = hipSuccess;
+    }
     Plan pl{2, 0, 0, true};
     if (two && n >= 2)
         pl = pick_plan<T>(c, s, mode_of(c, p->dx, p->dy, p->dz), src, dst, dsrc, ddst, divV, p, 1, p->nz - 1, may_tune);
@@ -677,8 +698,25 @@ static int run_block_graph(ns3d_ctx *c, hipStream_t s, int n, bool two, T *&src,
     return NS3D_OK;
 }
 
+// k_pt_persist: the launch-bound regime only (a cell per thread, the grid resident for the whole block)
+template <class T>
+static bool use_persist(const ns3d_ctx *c, const ns3d_pt_params *p)
+{
+    if (c->persist_mode == 0 || p->z_lo_is_halo || p->z_hi_is_halo) return false;
+    if (c->persist_mode < 0) {
+        // an explicit request (graph replay, iterations per pass, a tile shape) wins over the automatic choice
+        if (c->graph_mode > 0 || c->pt_depth > 0 || c->ptn_variant > 0 || c->pt2_variant != 0) return false;
+        // where it was measured to win (profiles/r3_persist_ab.log): up to ≈170 000 cells, one workgroup across x
+        if ((long long)p->nx * p->ny * p->nz > 170ll * 1000 || p->nx > 66) return false;
+    }
+    const hipError_t e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_persist<T>(nullptr, nullptr, nullptr, nullptr, nullptr, *p, 2));
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e == hipSuccess;                                         // the chip holds the whole grid at once
+}
+template <class T>
 static bool use_graphs(const ns3d_ctx *c, const ns3d_pt_params *p, int nchk)
 {
+    if (use_persist<T>(c, p)) return false;                         // one launch per block already (and no capture of a cooperative launch)
     if (c->graph_mode == 0 || nchk < 4) return false;
     if (c->graph_mode > 0) return true;
     return (long long)p->nx * p->ny * p->nz < 3ll * 1000 * 1000;    // launch-bound regime
@@ -699,7 +737,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
     T *dsrc = D, *ddst = nullptr;
     if (two && (rc = ensure_pingpong_d<T>(c, p, &ddst))) return rc;
     // graphs cannot be captured on HIP's null stream: run the loop on the context's own stream, fenced by events
-    const bool graphs = use_graphs(c, p, nchk);
+    const bool graphs = use_graphs<T>(c, p, nchk);
     hipStream_t s = c->stream;
     const bool fenced = graphs && (s == nullptr);
     if (fenced) {

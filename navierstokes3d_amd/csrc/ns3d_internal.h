@@ -26,6 +26,7 @@ struct ns3d_ctx {
     int ptn_variant; // tile shape of the N-iteration sweep (k_pt_sweepN); 0: built-in
     int pt_depth;    // PT iterations per pass in pt_iterate / pt_solve: 0 automatic, 1…4 forced
     int graph_mode;  // HIP-graph replay of residual-check blocks: -1 auto (launch-bound grids), 0 off, 1 on
+    int persist_mode = -1; // k_pt_persist (a whole residual-check block in one cooperative launch): -1 auto (small grids), 0 off, 1 on
     int autotune;    // time the tile shapes of the two-iteration sweep on first use of a grid (pt2_variant == 0 only)
     int last_pt2;    // variant of the latest two-iteration launch (0: built-in choice by grid)
     int last_ptn;    // variant of the latest N-iteration launch

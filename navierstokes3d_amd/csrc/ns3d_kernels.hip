@@ -2326,6 +2326,245 @@ hipError_t pt_sweep2(hipStream_t s, int variant, const T *Pin, T *Pout, const T 
     }
 }
 
+// =========================================================================================================
+// Small grids: n PT iterations in ONE launch  —  k_pt_persist  (round 3)
+//
+// Below ≈1 M cells an iteration is a 3–5 µs launch and nothing else (config A, 63×38×38: 4.2 µs per iteration in blocks of 37,
+// 3.4 in blocks of 370, replayed HIP graph or not).  Here the whole grid stays on the chip for the n iterations of a
+// residual-check block: one cell per thread, a workgroup owns 64×BY×BZ cells (P with a one-cell halo in LDS, double-buffered;
+// d and ∇V in registers), the workgroups are resident together (cooperative launch, at most two to a CU) and after every
+// iteration hand the cells on their faces to the neighbouring workgroups through a small exchange area in global memory:
+// value/key word pairs moved with relaxed agent-scope atomics, accepted only when the pair carries the key of the iteration
+// waited for — no flag, no fence, one hop (0.4–0.55 µs, tools/ab/signal_latency.hip).  Same expression tree per cell as the
+// single sweep, and the first iteration reads the domain's face cells as the caller left them: bit-identical to n k_pt_sweep
+// launches.  Waits are bounded: a neighbour that never arrives sets an error word, the grid drains and the result is poisoned
+// with NaN (NS3D_COOP_CHECK=1: the launch returns an error instead).
+//
+// Measured (profiles/r3_persist_ab.log, fp64 strict, µs per iteration, launches → this kernel): 30×18×18 2.67 → 2.08,
+// 40×24×24 2.81 → 2.19, 63×38×38 3.37 → 2.67, 66×50×50 4.05 → 3.25 in blocks of 370 (3.5–4.9 → 3.0–4.2 in blocks of 37); two
+// workgroups across x or more than ≈170 000 cells lose (130×34×34 3.32 → 4.01, 66×66×66 4.50 → 6.91): what remains per
+// iteration is the arithmetic of the CUs' own cells plus a hand-over that costs 1.5–2 µs once four neighbours' skews chain,
+// not the 0.5 µs of one hop.  So the automatic choice is narrow (ns3d_api.cpp use_persist) and the gain is 14–22 %; the direct
+// solve (ns3d_direct.hip) is the answer where the iteration count itself is the cost.  Smaller workgroups (64×2×2, 64×4×2) are
+// tried first — they spread the cells over more CUs; runs of blocks per XCD instead of round-robin were slower.
+// =========================================================================================================
+template <class T>
+struct PersistArgs {
+    SweepArgs<T> a;
+    unsigned long long *H;
+    unsigned *err;
+    unsigned long long epoch;
+    int nbx, nby, nbz, n_iters, xcds;
+};
+__device__ __forceinline__ unsigned long long xkey(unsigned long long id) { return (id + 1ull) * 0x9E3779B97F4A7C15ull; }
+__device__ __forceinline__ unsigned long long xbits(double v) { return (unsigned long long)__double_as_longlong(v); }
+__device__ __forceinline__ unsigned long long xbits(float v) { return (unsigned long long)__float_as_uint(v); }
+__device__ __forceinline__ void xunbits(unsigned long long b, double &v) { v = __longlong_as_double((long long)b); }
+__device__ __forceinline__ void xunbits(unsigned long long b, float &v) { v = __uint_as_float((unsigned)b); }
+template <class T> __device__ __forceinline__ void xpublish(unsigned long long *p, T v, unsigned long long key)
+{
+    const unsigned long long w = xbits(v);
+    __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 1, w ^ key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T> __device__ __forceinline__ T xfetch(const unsigned long long *p, unsigned long long key, unsigned *err)
+{
+    unsigned long long w1 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long w2 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while ((w1 ^ w2) != key) {
+        __builtin_amdgcn_s_sleep(1);
+        w1 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w2 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++spins > (1u << 22)) { atomicOr(err, 1u); break; }
+    }
+    T v;
+    xunbits(w1, v);
+    return v;
+}
+
+template <class T, int BY, int BZ>
+__global__ __launch_bounds__(64 * BY * BZ) void k_pt_persist(PersistArgs<T> pa)
+{
+    constexpr int BX = 64, PX = BX + 2, PY = BY + 2, PZ = BZ + 2, R = 4;
+    constexpr int FY = BX * BZ, FZ = BX * BY, FX = BY * BZ, FACE = 2 * FY + 2 * FZ + 2 * FX;
+    __shared__ T Lp[2][PX * PY * PZ];
+    const SweepArgs<T> &a = pa.a;
+    const int nx = a.nx, ny = a.ny, nz = a.nz;
+    const Geo<T> &g = a.g;
+    // A/B only (pa.xcds = 8): workgroup blockIdx.x runs on XCD blockIdx.x % 8; give each XCD a contiguous run of blocks
+    int b = blockIdx.x;
+    if (pa.xcds > 1) {
+        const int nb = gridDim.x, x = b % pa.xcds, q = nb / pa.xcds, r = nb % pa.xcds;
+        b = x * q + min(x, r) + b / pa.xcds;
+    }
+    const int bx = b % pa.nbx, by = (b / pa.nbx) % pa.nby, bz = b / (pa.nbx * pa.nby);
+    const int lx = threadIdx.x, ly = threadIdx.y, lz = threadIdx.z;
+    const int gi = 1 + bx * BX + lx, gj = 1 + by * BY + ly, gk = 1 + bz * BZ + lz;
+    const bool act = gi <= nx - 2 && gj <= ny - 2 && gk <= nz - 2;
+    const int ci = min(gi, nx - 2), cj = min(gj, ny - 2), ck = min(gk, nz - 2);
+    const idx_t sy = nx, sz = (idx_t)nx * ny;
+    const idx_t pc = IX3(ci, cj, ck, nx, ny), dc = IX3(ci - 1, cj - 1, ck - 1, nx - 2, ny - 2);
+    const int ctr = ((lz + 1) * PY + (ly + 1)) * PX + lx + 1;
+    const bool xlo_adj = gi == 1, xhi_adj = gi == nx - 2, ylo_adj = gj == 1, yhi_adj = gj == ny - 2, zlo_adj = gk == 1, zhi_adj = gk == nz - 2;
+    // faces this thread sits on that have a neighbouring workgroup behind them
+    const bool fxl = lx == 0 && bx > 0, fxh = lx == BX - 1 && bx < pa.nbx - 1;
+    const bool fyl = ly == 0 && by > 0, fyh = ly == BY - 1 && by < pa.nby - 1;
+    const bool fzl = lz == 0 && bz > 0, fzh = lz == BZ - 1 && bz < pa.nbz - 1;
+    const int oyl = lz * BX + lx, oyh = FY + oyl, ozl = 2 * FY + ly * BX + lx, ozh = ozl + FZ, oxl = 2 * FY + 2 * FZ + lz * BY + ly, oxh = oxl + FX;
+    unsigned long long *__restrict__ Hme = pa.H + 2 * (size_t)b * R * FACE;
+    const int nbxy = pa.nbx * pa.nby;
+    T c = a.Pin[pc], d = a.D[dc];
+    const T rv = a.RHS[pc];
+    Lp[0][ctr] = c;
+    // the initial halo: the cells beyond my faces as the input array holds them
+    if (fxl) Lp[0][ctr - 1] = a.Pin[pc - 1];
+    if (fxh) Lp[0][ctr + 1] = a.Pin[pc + 1];
+    if (fyl) Lp[0][ctr - PX] = a.Pin[pc - sy];
+    if (fyh) Lp[0][ctr + PX] = a.Pin[pc + sy];
+    if (fzl) Lp[0][ctr - PX * PY] = a.Pin[pc - sz];
+    if (fzh) Lp[0][ctr + PX * PY] = a.Pin[pc + sz];
+    // cells on the domain's faces: the first iteration reads them as the caller left them (like the single sweep does); from
+    // the second on they hold what the boundary rule made of the cell beside them, which is recomputed instead of stored
+    const T f_w = xlo_adj ? a.Pin[pc - 1] : (T)0, f_e = xhi_adj ? a.Pin[pc + 1] : (T)0;
+    const T f_s = ylo_adj ? a.Pin[pc - sy] : (T)0, f_n = yhi_adj ? a.Pin[pc + sy] : (T)0;
+    const T f_b = zlo_adj ? a.Pin[pc - sz] : (T)0, f_t = zhi_adj ? a.Pin[pc + sz] : (T)0;
+    __syncthreads();
+    int cur = 0;
+    for (int it = 0; it < pa.n_iters; ++it) {
+        const T *__restrict__ l = Lp[cur];
+        T w = l[ctr - 1], e = l[ctr + 1], sv = l[ctr - PX], nv = l[ctr + PX], bv = l[ctr - PX * PY], tv = l[ctr + PX * PY];
+        const bool first = it == 0;
+        if (xlo_adj) w = first ? f_w : xface_val<T>(a, false, c, gk);
+        if (xhi_adj) e = first ? f_e : xface_val<T>(a, true, c, gk);
+        if (ylo_adj) sv = first ? f_s : c;
+        if (yhi_adj) nv = first ? f_n : c;
+        if (zlo_adj) bv = first ? f_b : c;
+        if (zhi_adj) tv = first ? f_t : c;
+        const T res = poisson_rhs<T>(c, w, e, sv, nv, bv, tv, rv, a.rho_dt, g);
+        d = d * a.one_m_damp + a.dtau * res;
+        c = c + a.dtau * d;
+        T *__restrict__ ln = Lp[cur ^ 1];
+        ln[ctr] = c;
+        const bool last = it + 1 == pa.n_iters;
+        if (!last) {
+            const unsigned long long key = xkey(pa.epoch + (unsigned long long)it);
+            unsigned long long *__restrict__ hp = Hme + 2 * (size_t)((it & (R - 1)) * FACE);
+            if (fyl) xpublish<T>(hp + 2 * oyl, c, key);
+            if (fyh) xpublish<T>(hp + 2 * oyh, c, key);
+            if (fzl) xpublish<T>(hp + 2 * ozl, c, key);
+            if (fzh) xpublish<T>(hp + 2 * ozh, c, key);
+            if (fxl) xpublish<T>(hp + 2 * oxl, c, key);
+            if (fxh) xpublish<T>(hp + 2 * oxh, c, key);
+            const size_t so = 2 * (size_t)((it & (R - 1)) * FACE);
+            // my low-side halo ← the neighbour's high face and vice versa
+            if (fyl) ln[ctr - PX] = xfetch<T>(pa.H + 2 * (size_t)(b - pa.nbx) * R * FACE + so + 2 * oyh, key, pa.err);
+            if (fyh) ln[ctr + PX] = xfetch<T>(pa.H + 2 * (size_t)(b + pa.nbx) * R * FACE + so + 2 * oyl, key, pa.err);
+            if (fzl) ln[ctr - PX * PY] = xfetch<T>(pa.H + 2 * (size_t)(b - nbxy) * R * FACE + so + 2 * ozh, key, pa.err);
+            if (fzh) ln[ctr + PX * PY] = xfetch<T>(pa.H + 2 * (size_t)(b + nbxy) * R * FACE + so + 2 * ozl, key, pa.err);
+            if (fxl) ln[ctr - 1] = xfetch<T>(pa.H + 2 * (size_t)(b - 1) * R * FACE + so + 2 * oxh, key, pa.err);
+            if (fxh) ln[ctr + 1] = xfetch<T>(pa.H + 2 * (size_t)(b + 1) * R * FACE + so + 2 * oxl, key, pa.err);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (act) {
+        // a wait that expired anywhere in the grid: the result is not the iteration's — poison it, so that the residual norm of
+        // the block is NaN and the caller sees a failed solve rather than a plausible field
+        if (__hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) c = d = (T)__builtin_nan("");
+        a.D[dc] = d;
+        store_with_bc<T>(a, gi, gj, gk, c);
+    }
+}
+
+struct PersistScratch { int device; hipStream_t stream; void *H; unsigned *err; size_t bytes; unsigned long long launches; };
+static PersistScratch *persist_scratch(hipStream_t s, size_t bytes)
+{
+    static std::vector<PersistScratch> pool;
+    static std::mutex mtx;
+    std::lock_guard<std::mutex> lock(mtx);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    PersistScratch *c = nullptr;
+    for (auto &q : pool)
+        if (q.device == dev && q.stream == s) c = &q;
+    if (!c) {
+        if (pool.capacity() < 64) pool.reserve(64);
+        if (pool.size() >= 64) return nullptr;
+        pool.push_back({dev, s, nullptr, nullptr, 0, 0ull});
+        c = &pool.back();
+    }
+    if (c->bytes < bytes) {
+        if (c->H) { (void)hipStreamSynchronize(s); (void)hipFree(c->H); c->H = nullptr; c->bytes = 0; }
+        if (hipMalloc(&c->H, bytes + 64) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemset(c->H, 0, bytes + 64) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        c->err = (unsigned *)((char *)c->H + bytes);
+        c->bytes = bytes;
+    }
+    return c;
+}
+
+// n fused PT iterations (Pin, D) → (Pout, D) in one cooperative launch; hipErrorInvalidValue where the form does not apply
+// (z-slab halo planes, more workgroups than the chip holds at once): the caller then takes the launch-per-iteration path
+template <class T, int BY, int BZ>
+static hipError_t pt_persist_shape(hipStream_t s, const SweepArgs<T> &a, int n_iters, bool probe_only)
+{
+    constexpr int BX = 64, R = 4, FACE = 2 * BX * BZ + 2 * BX * BY + 2 * BY * BZ;
+    const int nbx = (a.nx - 2 + BX - 1) / BX, nby = (a.ny - 2 + BY - 1) / BY, nbz = (a.nz - 2 + BZ - 1) / BZ;
+    const long blocks = (long)nbx * nby * nbz;
+    // resident together, by the runtime's own count and never more than two to a CU (every workgroup polls its neighbours)
+    static const int per_cu = [] {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_pt_persist<T, BY, BZ>, 64 * BY * BZ, 0) != hipSuccess) { (void)hipGetLastError(); n = 1; }
+        return max(1, min(2, min(n, workgroups_per_cu((const void *)k_pt_persist<T, BY, BZ>, 64 * BY * BZ))));
+    }();
+    if (blocks > (long)device_cus() * per_cu) return hipErrorInvalidValue;
+    if (probe_only) return hipSuccess;
+    PersistScratch *ps = persist_scratch(s, (size_t)blocks * R * FACE * 2 * sizeof(unsigned long long));
+    if (!ps) return hipErrorOutOfMemory;
+    // NS3D_PERSIST_XCDMAP=1: contiguous runs of blocks per XCD instead of round-robin — measured slower (profiles/r3_persist_ab.log)
+    static const bool remap = std::getenv("NS3D_PERSIST_XCDMAP") && *std::getenv("NS3D_PERSIST_XCDMAP") == '1';
+    PersistArgs<T> pa;
+    pa.a = a; pa.H = (unsigned long long *)ps->H; pa.err = ps->err;
+    pa.epoch = (++ps->launches) << 16;
+    pa.nbx = nbx; pa.nby = nby; pa.nbz = nbz; pa.n_iters = n_iters; pa.xcds = remap ? 8 : 1;
+    void *kargs[] = {(void *)&pa};
+    hipError_t e = hipLaunchCooperativeKernel((const void *)k_pt_persist<T, BY, BZ>, dim3((unsigned)blocks), dim3(BX, BY, BZ), kargs, 0, s);
+    if (e != hipSuccess) return e;
+    static const bool check = std::getenv("NS3D_COOP_CHECK") && *std::getenv("NS3D_COOP_CHECK") == '1';
+    if (check) {
+        unsigned err = 0;
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+        if ((e = hipMemcpy(&err, ps->err, sizeof err, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+        if (err) { (void)hipMemset(ps->err, 0, sizeof err); return hipErrorLaunchTimeOut; }
+    }
+    return hipSuccess;
+}
+
+template <class T>
+hipError_t pt_persist(hipStream_t s, const T *Pin, T *Pout, T *D, const T *RHS, const ns3d_pt_params &p, int n_iters)
+{
+    if (n_iters < 1 || n_iters > 60000 || p.z_lo_is_halo || p.z_hi_is_halo) return hipErrorInvalidValue;
+    SweepArgs<T> a;
+    a.Pin = Pin; a.Pout = Pout; a.D = D; a.Din = D; a.RHS = RHS;
+    a.g = make_geo<T>(p.dx, p.dy, p.dz);
+    a.rho_dt = (T)p.rho / (T)p.dt; a.dtau = (T)p.dtau; a.one_m_damp = (T)1.0 - (T)p.damp;
+    a.outlet_val = (T)p.outlet_val; a.rho_g = (T)p.rho * (T)p.g;
+    a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
+    a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = 0; a.zhi_halo = 0;
+    a.k0 = 1; a.k1 = p.nz - 1; a.kz = 1;
+    // the iteration is arithmetic on the CUs the grid occupies plus one hand-over: the smallest workgroup the chip still holds
+    // all at once spreads the cells over the most CUs.  NS3D_PERSIST_SHAPE=22|42|44 pins a shape (A/B).
+    static const int pin = std::getenv("NS3D_PERSIST_SHAPE") ? std::atoi(std::getenv("NS3D_PERSIST_SHAPE")) : 0;
+    const bool probe = Pin == nullptr;                  // no arrays: only say whether the form applies to this grid
+    if (pin == 22) return pt_persist_shape<T, 2, 2>(s, a, n_iters, probe);
+    if (pin == 42) return pt_persist_shape<T, 4, 2>(s, a, n_iters, probe);
+    if (pin == 44) return pt_persist_shape<T, 4, 4>(s, a, n_iters, probe);
+    if (pt_persist_shape<T, 2, 2>(s, a, n_iters, true) == hipSuccess) return pt_persist_shape<T, 2, 2>(s, a, n_iters, probe);
+    if (pt_persist_shape<T, 4, 2>(s, a, n_iters, true) == hipSuccess) return pt_persist_shape<T, 4, 2>(s, a, n_iters, probe);
+    return pt_persist_shape<T, 4, 4>(s, a, n_iters, probe);
+}
+
 template <class T>
 hipError_t pt_sweep(hipStream_t s, int variant, const T *Pin, T *Pout, T *D, const T *RHS, const ns3d_pt_params &p,
                     int k0, int k1)
@@ -2496,6 +2735,7 @@ hipError_t divtest(hipStream_t s, double d, long n, unsigned long long seed, uns
                                   const T *, double, double, double, double, int, int, int, int, int, int);  \
     template hipError_t pt_sweep<T>(hipStream_t, int, const T *, T *, T *, const T *, const ns3d_pt_params &,\
                                     int, int);                                                               \
+    template hipError_t pt_persist<T>(hipStream_t, const T *, T *, T *, const T *, const ns3d_pt_params &, int); \
     template hipError_t pt_sweep2<T>(hipStream_t, int, const T *, T *, const T *, T *, const T *,            \
                                      const ns3d_pt_params &, int, int);                                      \
     template hipError_t pt_sweepn<T>(hipStream_t, int, int, const T *, T *, const T *, T *, const T *,       \

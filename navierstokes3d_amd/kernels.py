@@ -105,6 +105,11 @@ class Context:
         """HIP-graph replay of residual-check blocks in pt_solve: -1 auto (launch-bound grids), 0 off, 1 on."""
         L.check(self.lib.ns3d_set_graph_mode(self.handle, int(mode)))
 
+    def set_persist_mode(self, mode):
+        """pt_iterate / pt_solve on launch-bound grids: a whole block of iterations in one cooperative launch (k_pt_persist);
+        -1 automatic (small grids), 0 never, 1 wherever it applies.  Same results."""
+        L.check(self.lib.ns3d_set_persist_mode(self.handle, int(mode)))
+
     def set_autotune(self, on):
         """Time the tile shapes of the two-iteration sweep on the first launch per grid (default on; same results)."""
         L.check(self.lib.ns3d_set_autotune(self.handle, int(bool(on))))

@@ -8,6 +8,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+os.environ.setdefault("NS3D_COOP_CHECK", "1")     # k_pt_persist: a bounded wait that expires is an error, not a silent pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -830,3 +830,47 @@ def test_graph_cache_ignores_struct_padding(hip, oracle):
         assert n == base, (call, n, base)
     ctx.close()
 
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("grid", [(24, 15, 15), (70, 6, 7), (63, 38, 38), (131, 21, 35), (66, 7, 6), (5, 4, 3), (3, 3, 3), (200, 66, 30)])
+def test_pt_persist_equals_single_sweeps(hip, oracle, grid, dtype):
+    """k_pt_persist (a whole block of PT iterations in one cooperative launch, the grid resident on the chip, faces handed
+    between workgroups after every iteration): forced on (ns3d_set_persist_mode 1) against forced off, pt_iterate for several
+    counts and pt_solve with residual checks and early exits — identical fields, counts and residual histories; both boundary
+    sets; grids of one workgroup, of several in x, y and z, with ragged edges; the 63×38×38 case also against the oracle's loop."""
+    import torch
+    nx, ny, nz = grid
+    g = geometry(*grid)
+    npdt = np.float64 if dtype == "f64" else np.float32
+    Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 97, npdt)
+    rhs *= npdt(1e-3)
+    drhs = hip.from_numpy(rhs)
+    on, off = hip.Context(0, "strict"), hip.Context(0, "strict")
+    on.set_persist_mode(1); off.set_persist_mode(0); off.set_graph_mode(0)
+    for bc in ((0, True, 0.25), (0, False, 0.0), (1, False, 0.0)):
+        for n in (1, 2, 3, 8, 37):
+            res = []
+            for ctx in (on, off):
+                dP, dD = hip.from_numpy(Pr0), hip.from_numpy(d0)
+                hip.pt_iterate(dP, dD, drhs, _params(hip, dP, g, *bc), n, ctx=ctx)
+                torch.cuda.synchronize()
+                res.append((hip.to_numpy(dP), hip.to_numpy(dD)))
+            assert np.array_equal(res[0][0], res[1][0], equal_nan=True) and np.array_equal(res[0][1], res[1][1], equal_nan=True), (grid, bc, n)
+        for eps, niter, nchk in ((-1.0, 57, 14), (1e-30, 45, 7), (5e4, 400, 13)):
+            res = []
+            for ctx in (on, off):
+                dP, dD = hip.from_numpy(Pr0), hip.from_numpy(d0)
+                it, errs = hip.pt_solve(dP, dD, drhs, _params(hip, dP, g, *bc), eps, niter, nchk, 0.36, 1000.0, ctx=ctx)
+                torch.cuda.synchronize()
+                res.append((it, errs, hip.to_numpy(dP), hip.to_numpy(dD)))
+            assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1], equal_nan=True), (grid, bc, eps)
+            assert np.array_equal(res[0][2], res[1][2], equal_nan=True) and np.array_equal(res[0][3], res[1][3], equal_nan=True)
+    if grid == (63, 38, 38) and dtype == "f64":
+        Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
+        _oracle_iters(oracle, Pr, d, rhs, g, 8, 0, True, 0.25)
+        dP, dD = hip.from_numpy(Pr0), hip.from_numpy(d0)
+        hip.pt_iterate(dP, dD, drhs, _params(hip, dP, g, 0, True, 0.25), 8, ctx=on)
+        torch.cuda.synchronize()
+        assert np.array_equal(hip.to_numpy(dP), Pr) and np.array_equal(hip.to_numpy(dD), d)
+    on.close(); off.close()

@@ -10,12 +10,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--nx", type=int, default=63); ap.add_argument("--ny", type=int, default=38); ap.add_argument("--nz", type=int, default=38)
 ap.add_argument("--niter", type=int, default=1480); ap.add_argument("--nchk", type=int, default=37)
 ap.add_argument("--cases", default="1:0,2:0,2:716,3:600,4:600")
+ap.add_argument("--persist", type=int, default=0, help="ns3d_set_persist_mode for every case (1: k_pt_persist, a whole check block per launch)")
 a = ap.parse_args()
 nx, ny, nz = a.nx, a.ny, a.nz
 d = 1.0 / nx
 for case in a.cases.split(","):
     depth, var = (int(q) for q in case.split(":"))
     ctx = K.Context(0, "strict", async_=True)
+    ctx.set_persist_mode(a.persist)
     if depth == 1:
         ctx.set_pt_depth(1)
     else:
@@ -35,6 +37,7 @@ for case in a.cases.split(","):
         it, errs = K.pt_solve(Pr, D, rhs, pt, -1.0, a.niter, a.nchk, 1.0, 1.0, ctx=ctx)
         ctx.sync(); torch.cuda.synchronize()
         best = min(best, time.perf_counter() - t0)
+    print("persist %d " % a.persist, end="")
     print("depth %d variant %5d: %.2f us per iteration (last depth %d, ptn %d, pt2 %d) err %.6e" % (
         depth, var, best / a.niter * 1e6, ctx.last_pt_depth(), ctx.last_ptn_variant(), ctx.last_pt2_variant(), errs[-1]), flush=True)
     ctx.close()
