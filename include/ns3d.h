@@ -139,6 +139,14 @@ typedef struct ns3d_pt_params {
     int ns3d_predict_V_##S(ns3d_ctx *, T *Vx, T *Vy, T *Vz, const T *txx, const T *tyy, const T *tzz,        \
                            const T *txy, const T *txz, const T *tyz, double rho, double g, double dt,         \
                            double dx, double dy, double dz, int nx, int ny, int nz);                         \
+    /* {update_τ!; predict_V!} (multi.jl:449,451 / gpu.jl:121-122) in one pass for a driver that does not look at the stress \
+     * arrays: reads Vx, Vy, Vz, writes COMPLETE predicted fields into Vx_new, Vy_new, Vz_new (buffers of their own: the     \
+     * entries predict_V! leaves alone are written through) — the caller swaps the names.  Bit for bit what the two calls    \
+     * leave in Vx, Vy, Vz.  The stresses are not stored.  Not for ranks that exchange τ halos between the two calls with     \
+     * velocities that differ across ranks (multi.jl:450). */                                                \
+    int ns3d_predict_fused_##S(ns3d_ctx *, T *Vx_new, T *Vy_new, T *Vz_new, const T *Vx, const T *Vy, const T *Vz,          \
+                               double mu, double rho, double g, double dt, double dx, double dy, double dz, int nx, int ny,  \
+                               int nz);                                                                      \
     /* set_cylinder!(C,Vx,Vy,Vz,a2,b2,ox,oy,sinβ,cosβ,xco_g,yco_g,zco_g,lx,ly,lz,dx,dy,dz) multi.jl:249-281 */\
     int ns3d_set_cylinder_##S(ns3d_ctx *, T *C, T *Vx, T *Vy, T *Vz, double a2, double b2, double ox,        \
                               double oy, double sinb, double cosb, double xco_g, double yco_g, double zco_g, \

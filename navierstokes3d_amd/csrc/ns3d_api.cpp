@@ -801,6 +801,16 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
         return finish(c, DISPATCHG(c, dx, dy, dz, predict_V<T>(c->stream, Vx, Vy, Vz, txx, tyy, tzz, txy, txz, tyz, rho,  \
                                                   g, dt, dx, dy, dz, nx, ny, nz)), "predict_V");             \
     }                                                                                                        \
+    extern "C" int ns3d_predict_fused_##S(ns3d_ctx *c, T *Vx_new, T *Vy_new, T *Vz_new, const T *Vx, const T *Vy, \
+                                          const T *Vz, double mu, double rho, double g, double dt, double dx, \
+                                          double dy, double dz, int nx, int ny, int nz)                      \
+    {                                                                                                        \
+        CHECK_CTX(c); CHECK_PTRS(Vx_new, Vy_new, Vz_new, Vx, Vy, Vz); CHECK_GRID(nx, ny, nz, 2);             \
+        if (Vx_new == Vx || Vy_new == Vy || Vz_new == Vz)                                                    \
+            return fail(NS3D_ERR_ARG, "ns3d_predict_fused: the predicted velocities need buffers of their own"); \
+        return finish(c, DISPATCHG(c, dx, dy, dz, predict_fused<T>(c->stream, Vx_new, Vy_new, Vz_new, Vx, Vy, Vz, mu, rho, \
+                                                  g, dt, dx, dy, dz, nx, ny, nz)), "predict_fused");         \
+    }                                                                                                        \
     extern "C" int ns3d_set_cylinder_##S(ns3d_ctx *c, T *C, T *Vx, T *Vy, T *Vz, double a2, double b2,       \
                                          double ox, double oy, double sinb, double cosb, double xco_g,       \
                                          double yco_g, double zco_g, double lx, double ly, double lz,        \

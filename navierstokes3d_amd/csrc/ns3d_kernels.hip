@@ -112,7 +112,7 @@ __device__ __forceinline__ float div_by_known(float x, float d, float r)
 #define DIV_XX(v) ((v)*g.rdx2)
 #define DIV_YY(v) ((v)*g.rdy2)
 #define DIV_ZZ(v) ((v)*g.rdz2)
-#define DIV_3(v) ((v) / (T)3.0)
+#define DIV_3(v) div_by_known((v), (T)3, (T)1 / (T)3)     /* RN(v/3): 3 is an admissible divisor (test_divide_by_three_is_exact) */
 #elif defined(NS3D_EXACT_RECIP)
 #define DIV_X(v) div_by_known((v), g.dx, g.rdx)
 #define DIV_Y(v) div_by_known((v), g.dy, g.rdy)
@@ -120,7 +120,7 @@ __device__ __forceinline__ float div_by_known(float x, float d, float r)
 #define DIV_XX(v) div_by_known(div_by_known((v), g.dx, g.rdx), g.dx, g.rdx)
 #define DIV_YY(v) div_by_known(div_by_known((v), g.dy, g.rdy), g.dy, g.rdy)
 #define DIV_ZZ(v) div_by_known(div_by_known((v), g.dz, g.rdz), g.dz, g.rdz)
-#define DIV_3(v) ((v) / (T)3.0)
+#define DIV_3(v) div_by_known((v), (T)3, (T)1 / (T)3)
 #else
 #define DIV_X(v) ((v) / g.dx)
 #define DIV_Y(v) ((v) / g.dy)
@@ -228,6 +228,174 @@ hipError_t predict_V(hipStream_t s, T *Vx, T *Vy, T *Vz, const T *txx, const T *
     const T dt_rho = (T)dt / (T)rho, rho_g = (T)rho * (T)gg;
     hipLaunchKernelGGL(k_predict_V<T>, grid3(nx - 1, ny - 1, nz - 1, BLK3), BLK3, 0, s, Vx, Vy, Vz, txx, tyy, tzz,
                        txy, txz, tyz, dt_rho, rho_g, make_geo<T>(dx, dy, dz), nx, ny, nz);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// update_τ! + predict_V! in one pass (round 3): k_predict_fused.  The six stress arrays are temporaries of the
+// predictor (multi.jl:449-451: written by update_τ!, read by predict_V!, nothing else), 72 + 96 B per cell in two kernels
+// (3.0 + 3.1 ms at 512³).  Here a 1024-thread workgroup marches 64×16 columns in z with a ring of three xy-planes (+ the one
+// being fetched) of Vx, Vy, Vz in LDS, evaluates the stresses a cell's three faces need from the window — the same expressions
+// on the same operands as k_update_tau — and writes the predicted velocities into buffers of their own (the stencil on V now
+// has radius two: not in place; entries predict_V! leaves alone are written through, so the outputs are complete and the
+// caller swaps names).  What sits at the same (x, y) one plane lower — τzz, two τxz, two τyz — is carried in registers from the
+// previous step.  Per cell and step: 3 divergences, 5 normal and 7 shear stresses instead of 1 + 3 + 3 (the stresses are
+// recomputed where faces share them), 24 + 24 B of HBM traffic instead of 168.  ix, iy, iz are the reference's 1-based indices.
+// τ is not stored: a caller that wants the stress arrays runs update_τ!.
+// ---------------------------------------------------------------------------------------------------------
+template <class T>
+struct PredWin {
+    static constexpr int TX = 64, TY = 16, WX = TX + 2, WY = TY + 2, NSLOT = 4, PLANE = WX * WY;
+    typedef const T __attribute__((address_space(3))) *lds_ptr;
+    lds_ptr L;           // [3 arrays][NSLOT][PLANE]
+    int x0, y0;          // 1-based first column/row of the tile; the window starts one below
+    __device__ __forceinline__ T get(int a, int i, int j, int k) const    // plane k lives in slot k mod 4
+    {
+        return L[(a * NSLOT + (k & (NSLOT - 1))) * PLANE + (j - (y0 - 1)) * WX + (i - (x0 - 1))];
+    }
+};
+template <class T>
+__global__ __launch_bounds__(1024) void k_predict_fused(T *__restrict__ Vxn, T *__restrict__ Vyn, T *__restrict__ Vzn,
+                                                        const T *__restrict__ Vx, const T *__restrict__ Vy,
+                                                        const T *__restrict__ Vz, T mu, T dt_rho, T rho_g, Geo<T> g, int nx,
+                                                        int ny, int nz, int kz)
+{
+    typedef PredWin<T> W;
+    extern __shared__ __align__(16) unsigned char predict_lds_raw[];
+    T *L = reinterpret_cast<T *>(predict_lds_raw);
+    const int tid = threadIdx.y * W::TX + threadIdx.x;
+    const int x0 = blockIdx.x * W::TX + 1, y0 = blockIdx.y * W::TY + 1;
+    const int zb = blockIdx.z * kz + 1, ze = min(zb + kz, nz + 1);          // planes iz ∈ [zb, ze), iz ≤ nz
+    const int ix = x0 + threadIdx.x, iy = y0 + threadIdx.y;
+    const T *const src[3] = {Vx, Vy, Vz};
+    const int sxs[3] = {nx + 1, nx, nx}, sys[3] = {ny, ny + 1, ny}, szs[3] = {nz, nz, nz + 1};
+    // window positions this thread fills (two per array and plane: 1 188 positions, 1 024 threads); indices outside an array
+    // are clamped into it — such values only reach results that are not stored
+    unsigned fbase[3][2];
+    idx_t fplane[3];
+    int q[2];
+    bool has[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        q[h] = tid + h * 1024;
+        has[h] = q[h] < W::PLANE;
+        const int qq = has[h] ? q[h] : 0;
+        const int gi = x0 - 1 + qq % W::WX, gj = y0 - 1 + qq / W::WX;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int ci = min(max(gi, 1), sxs[a]), cj = min(max(gj, 1), sys[a]);
+            fbase[a][h] = (unsigned)(ci - 1) + (unsigned)sxs[a] * (unsigned)(cj - 1);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) fplane[a] = (idx_t)sxs[a] * sys[a];
+    auto fetch = [&](int plane, T (&v)[3][2]) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const T *__restrict__ pl = src[a] + fplane[a] * (min(max(plane, 1), szs[a]) - 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) v[a][h] = has[h] ? pl[fbase[a][h]] : (T)0;
+        }
+    };
+    auto publish = [&](int plane, const T (&v)[3][2]) {
+        const int slot = plane & (W::NSLOT - 1);            // plane ≥ 0
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (has[h]) L[(a * W::NSLOT + slot) * W::PLANE + q[h]] = v[a][h];
+    };
+    {
+        T v[3][2];
+        for (int pl = zb - 1; pl <= zb + 1; ++pl) { fetch(pl, v); publish(pl, v); }
+    }
+    __syncthreads();
+    const W w{(typename W::lds_ptr)L, x0, y0};
+#define VX(i_, j_, k_) w.get(0, (i_), (j_), (k_))
+#define VY(i_, j_, k_) w.get(1, (i_), (j_), (k_))
+#define VZ(i_, j_, k_) w.get(2, (i_), (j_), (k_))
+    const T two_mu = (T)2 * mu;
+    // the stresses of multi.jl:37-43 at 1-based entry (p, q, r) of their arrays
+    struct Normal { T xx, yy, zz; };
+    auto normal_at = [&](int p, int q_, int r) {
+        const T dVx = VX(p + 1, q_, r) - VX(p, q_, r), dVy = VY(p, q_ + 1, r) - VY(p, q_, r), dVz = VZ(p, q_, r + 1) - VZ(p, q_, r);
+        const T div = (DIV_X(dVx) + DIV_Y(dVy)) + DIV_Z(dVz); // @∇V()  multi.jl:15
+        Normal n;
+        n.xx = two_mu * (DIV_X(dVx) - DIV_3(div));
+        n.yy = two_mu * (DIV_Y(dVy) - DIV_3(div));
+        n.zz = two_mu * (DIV_Z(dVz) - DIV_3(div));
+        return n;
+    };
+    auto txy_at = [&](int p, int q_, int r) {
+        return mu * (DIV_Y(VX(p + 1, q_ + 1, r + 1) - VX(p + 1, q_, r + 1)) + DIV_X(VY(p + 1, q_ + 1, r + 1) - VY(p, q_ + 1, r + 1)));
+    };
+    auto txz_at = [&](int p, int q_, int r) {
+        return mu * (DIV_Z(VX(p + 1, q_ + 1, r + 1) - VX(p + 1, q_ + 1, r)) + DIV_X(VZ(p + 1, q_ + 1, r + 1) - VZ(p, q_ + 1, r + 1)));
+    };
+    auto tyz_at = [&](int p, int q_, int r) {
+        return mu * (DIV_Z(VY(p + 1, q_ + 1, r + 1) - VY(p + 1, q_ + 1, r)) + DIV_Y(VZ(p + 1, q_ + 1, r + 1) - VZ(p + 1, q_, r + 1)));
+    };
+    const bool in = ix <= nx && iy <= ny;
+    const int cix = min(ix, nx), ciy = min(iy, ny);
+    const unsigned oVx = (unsigned)(cix - 1) + (unsigned)(nx + 1) * (unsigned)(ciy - 1), oVy = (unsigned)(cix - 1) + (unsigned)nx * (unsigned)(ciy - 1);
+    const unsigned oVz = oVy;
+    const idx_t pVx = (idx_t)(nx + 1) * ny, pVy = (idx_t)nx * (ny + 1), pVz = (idx_t)nx * ny;
+    // what the first plane of this chunk needs from the plane below it (planes zb−1 and zb are in the window)
+    T tzz_lo = normal_at(ix, iy, zb - 1).zz;
+    T txz_a_lo = txz_at(ix - 1, iy - 1, zb - 1), txz_b_lo = txz_at(ix, iy - 1, zb - 1);
+    T tyz_a_lo = tyz_at(ix - 1, iy - 1, zb - 1), tyz_b_lo = tyz_at(ix - 1, iy, zb - 1);
+    for (int iz = zb; iz < ze; ++iz) {
+        T nxt[3][2];
+        fetch(iz + 2, nxt);                                 // in flight behind this plane's arithmetic
+        if (in) {
+            const Normal n0 = normal_at(ix, iy, iz);
+            const T txx_w = normal_at(ix - 1, iy, iz).xx, tyy_s = normal_at(ix, iy - 1, iz).yy;
+            const T txy_a = txy_at(ix - 1, iy, iz - 1), txy_b = txy_at(ix - 1, iy - 1, iz - 1), txy_c = txy_at(ix, iy - 1, iz - 1);
+            const T txz_a = txz_at(ix - 1, iy - 1, iz), txz_b = txz_at(ix, iy - 1, iz);
+            const T tyz_a = tyz_at(ix - 1, iy - 1, iz), tyz_b = tyz_at(ix - 1, iy, iz);
+            T *__restrict__ const Vxp = Vxn + pVx * (iz - 1), *__restrict__ const Vyp = Vyn + pVy * (iz - 1), *__restrict__ const Vzp = Vzn + pVz * (iz - 1);
+            const T vx = VX(ix, iy, iz), vy = VY(ix, iy, iz), vz = VZ(ix, iy, iz);
+            T ox = vx, oy = vy, oz = vz;
+            if (ix >= 2 && iy >= 2 && iy <= ny - 1 && iz >= 2 && iz <= nz - 1) {         // @inn(Vx)  multi.jl:51
+                const T a = DIV_X(n0.xx - txx_w), b = DIV_Y(txy_a - txy_b), c = DIV_Z(txz_a - txz_a_lo);
+                ox = vx + dt_rho * ((a + b) + c);
+            }
+            if (ix >= 2 && ix <= nx - 1 && iy >= 2 && iz >= 2 && iz <= nz - 1) {         // @inn(Vy)  multi.jl:52
+                const T a = DIV_Y(n0.yy - tyy_s), b = DIV_X(txy_c - txy_b), c = DIV_Z(tyz_a - tyz_a_lo);
+                oy = vy + dt_rho * ((a + b) + c);
+            }
+            if (ix >= 2 && ix <= nx - 1 && iy >= 2 && iy <= ny - 1 && iz >= 2) {         // @inn(Vz)  multi.jl:53 (iz ≤ nz here)
+                const T a = DIV_Z(n0.zz - tzz_lo), b = DIV_X(txz_b_lo - txz_a_lo), c = DIV_Y(tyz_b_lo - tyz_a_lo);
+                oz = vz + dt_rho * (((a + b) + c) - rho_g);
+            }
+            Vxp[oVx] = ox; Vyp[oVy] = oy; Vzp[oVz] = oz;
+            // the far faces of the staggered arrays: never predicted, written through
+            if (ix == nx) Vxp[oVx + 1] = VX(ix + 1, iy, iz);
+            if (iy == ny) Vyp[oVy + nx] = VY(ix, iy + 1, iz);
+            if (iz == nz) (Vzp + pVz)[oVz] = VZ(ix, iy, iz + 1);
+            tzz_lo = n0.zz; txz_a_lo = txz_a; txz_b_lo = txz_b; tyz_a_lo = tyz_a; tyz_b_lo = tyz_b;
+        }
+        publish(iz + 2, nxt);
+        __syncthreads();
+    }
+#undef VX
+#undef VY
+#undef VZ
+}
+template <class T>
+hipError_t predict_fused(hipStream_t s, T *Vxn, T *Vyn, T *Vzn, const T *Vx, const T *Vy, const T *Vz, double mu, double rho,
+                         double gg, double dt, double dx, double dy, double dz, int nx, int ny, int nz)
+{
+    typedef PredWin<T> W;
+    const size_t lds = (size_t)3 * W::NSLOT * W::PLANE * sizeof(T);
+    hipError_t ea = hipFuncSetAttribute((const void *)k_predict_fused<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ea != hipSuccess) return ea;
+    const T dt_rho = (T)dt / (T)rho, rho_g = (T)rho * (T)gg;
+    const int kz = nz >= 128 ? 64 : 32;
+    const dim3 blk(W::TX, W::TY, 1);
+    const dim3 grd((unsigned)((nx + W::TX - 1) / W::TX), (unsigned)((ny + W::TY - 1) / W::TY), (unsigned)((nz + kz - 1) / kz));
+    hipLaunchKernelGGL(k_predict_fused<T>, grd, blk, lds, s, Vxn, Vyn, Vzn, Vx, Vy, Vz, (T)mu, dt_rho, rho_g, make_geo<T>(dx, dy, dz), nx,
+                       ny, nz, kz);
     return hipGetLastError();
 }
 
@@ -764,14 +932,6 @@ __global__ __launch_bounds__(256) void k_advect(T *__restrict__ Vx, const T *__r
 #undef VYO
 #undef VZO
 }
-// ---- advect!, LDS-windowed ------------------------------------------------------------------------------------
-// k_advect reads 68 values per cell through L1/L2 (8-point gathers of four arrays plus the staggered velocity averages):
-// at 512³ that is ≈70 GB of cache traffic for 7.5 GB of algorithmic bytes.  Here a workgroup owns 64×8 columns and marches in
-// z; a ring of six xy-planes of the four OLD fields (window 67×11: one column/row below, two above — what |δ| < 1 can reach,
-// multi.jl:190-195) lives in LDS, the plane three steps ahead is fetched into registers while the current one is computed, and
-// every gather and every velocity average reads LDS.  A lane whose departure point leaves the window (|δ| ≥ 1 in some
-// direction: CFL_adv = 1 allows it where |v| > vin) takes the global gather instead — same values, same arithmetic, same
-// stores in the same order, so the result is bit-identical to k_advect for every δ.
 // clamp(floor(·) as Int, 1, hi) of multi.jl:192-194 with the clamp applied BEFORE the conversion: the same integer for every
 // finite value (the conversion is exact inside [1, hi]), the saturating behaviour of the device's float→int64 conversion for
 // huge values (→ hi / 1), and 1 for NaN (fmax drops it) — what clampi((long long)floor(·)) gives on this device, without the
@@ -779,119 +939,160 @@ __global__ __launch_bounds__(256) void k_advect(T *__restrict__ Vx, const T *__r
 __device__ __forceinline__ int clampf_i(double t, int hi) { return (int)__builtin_fmin(__builtin_fmax(t, 1.0), (double)hi); }
 __device__ __forceinline__ int clampf_i(float t, int hi) { return (int)__builtin_fminf(__builtin_fmaxf(t, 1.0f), (float)hi); }
 
+// ---- advect!, LDS-windowed --------------------------------------------------------------------------------------
+// k_advect reads 68 values per cell through L1/L2 (8-point gathers of four arrays plus the staggered velocity averages): at 512³
+// that is ≈70 GB of cache traffic for 7.5 GB of algorithmic bytes.  Here a workgroup marches a tile of columns in z with a ring
+// of xy-planes of the four OLD fields in LDS; the plane two steps ahead is fetched into registers while the current one is
+// computed, and every gather and every velocity average reads LDS.  The round-2 form (64×8 columns, a four-plane window of
+// 141 KB for 512 threads) kept 2 waves per SIMD and spent 44 % of its wave cycles waiting (profiles/r3_advect_sq.log): 505 VALU
+// instructions per wave and plane behind four exec-masked branches that each wait for their own loads, 4.45 ms at 512³.  Now
+//  * the workgroup owns 64×16 columns (1024 threads, 4 waves per SIMD) and the window holds THREE planes (iz−1 … iz+1: what a
+//    departure point with |δz| < 1 and the staggered averages reach) plus the slot the next plane is fetched into: 68×18×4
+//    slots × 4 arrays = 153 KB;
+//  * the window reaches two columns below and one above in x (the stream runs in +x at CFL_adv = 1, multi.jl:342: departure
+//    points lie up to 1+ε cells upstream), one row either side in y;
+//  * a lane inside the array (ix, iy, iz > 1) runs the back-tracks as straight-line code with the staggered averages
+//    sharing their loads (one back-track at a time: holding the departure cells of all four to issue their 32 gathers
+//    together spilled 35-58 registers at 128 per lane);
+//  * a plane lives in ring slot k mod 4, computed, not looked up (the round-2 ring of six kept a table that a per-lane k
+//    turned into a scratch array: two scratch loads per back-track);
+//  * in the faithful form the second branch's store to Vy[ix,iy,iz] is overwritten by the third's from the same lane
+//    (multi.jl:234, App. B1): where the third branch runs, the second is a dead store and is not computed;
+//  * the grid covers (nx, ny, nz) and the lanes at ix = nx, iy = ny, iz = nz write the far faces through (the reference's
+//    (nx+1, ny+1, nz+1) range does nothing else there) — 8×32 tiles at 512³ instead of 9×65;
+//  * loads and stores use a 32-bit in-plane offset per lane on a workgroup-uniform plane base instead of 64-bit index
+//    arithmetic per access.
+// 4.45 → 3.33 ms at 512³ (faithful; 4.56 → 3.8 fixed), 5.26 → 3.27 ms with the cylinder case's stream (departure points 0.7-1.3
+// cells upstream, which the round-2 window did not hold); 417 VALU instructions per wave and plane, SIMDs 68 % busy.
+// A lane whose departure point leaves the window takes the global gather for that back-track; same values, same expression
+// trees, same final stores: bit-identical to k_advect for every δ.
 template <class T>
-struct AdvWin {
-    static constexpr int TX = 64, TY = 8, WX = TX + 4, WY = TY + 3, NSLOT = 6, PLANE = WX * WY;   // 67 columns used; pitch 68
-    // explicitly an LDS pointer: through a generic one the gathers below become flat_load (the compiler merges the LDS and the
-    // global branch of backtrack_win into one generic access), which is what the first version of this kernel measured
+struct AdvWin2 {
+    static constexpr int TX = 64, TY = 16, XLO = 2, YLO = 1, WX = TX + 4 /* 67 used */, WY = TY + 2, NSLOT = 4, PLANE = WX * WY;
     typedef const T __attribute__((address_space(3))) *lds_ptr;
     lds_ptr L;           // [4 arrays][NSLOT][PLANE]
     int x0, y0, iz;      // 1-based first column/row of the tile, current plane
-    int so[4];           // ring offsets (slot·PLANE) of the planes iz-1 … iz+2 (workgroup-uniform, set once per step)
-    __device__ __forceinline__ void set_plane(int iz_)
-    {
-        iz = iz_;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) so[d] = ((iz_ - 1 + d) % NSLOT) * PLANE;     // iz_ ≥ 1: never negative
-    }
+    __device__ __forceinline__ void set_plane(int iz_) { iz = iz_; }
+    // plane k lives in slot k mod 4 (no table: a per-lane k would turn one into a scratch array)
+    __device__ __forceinline__ int slot_off(int k) const { return (k & (NSLOT - 1)) * PLANE; }
     __device__ __forceinline__ T get(int a, int i, int j, int k) const
     {
-        const int d = k - (iz - 1);                         // 0 … 3 for every plane the window holds
-        const int off = d == 0 ? so[0] : d == 1 ? so[1] : d == 2 ? so[2] : so[3];
-        return L[a * (NSLOT * PLANE) + off + (j - (y0 - 1)) * WX + (i - (x0 - 1))];
-    }
-    __device__ __forceinline__ int slot_off(int k) const
-    {
-        const int d = k - (iz - 1);
-        return d == 0 ? so[0] : d == 1 ? so[1] : d == 2 ? so[2] : so[3];
-    }
-    __device__ __forceinline__ bool holds(int i1, int i2, int j1, int j2, int k1, int k2) const
-    {
-        return (i1 >= x0 - 1) & (i2 <= x0 + TX + 1) & (j1 >= y0 - 1) & (j2 <= y0 + TY + 1) & (k1 >= iz - 1) & (k2 <= iz + 2);   // 67 × 11 × 4
+        return L[a * (NSLOT * PLANE) + slot_off(k) + (j - (y0 - YLO)) * WX + (i - (x0 - XLO))];
     }
 };
+// the departure cell of one back-track (multi.jl:190-197): the index arithmetic of backtrack() with the clamp on the float side
+template <class T> struct AdvDep { int i1, i2, j1, j2, k1, k2; T wx, wy, wz; };
 template <class T>
-__device__ __forceinline__ void backtrack_win(T *__restrict__ A, const T *__restrict__ A_o, const AdvWin<T> &w, int a, T vxc, T vyc,
-                                              T vzc, T dt, const Geo<T> &g, int ix, int iy, int iz, int sx, int sy, int sz, int koff = 0,
-                                              int szg = 0)
+__device__ __forceinline__ AdvDep<T> adv_departure(T vxc, T vyc, T vzc, T dt, const Geo<T> &g, int ix, int iy, int iz, int sx, int sy,
+                                                   int sz, int koff, int szg)
 {
-    if (szg <= 0) szg = sz;                                  // see backtrack(): window of a global array
+    if (szg <= 0) szg = sz;
 #if NS3D_FASTMATH
     const T ddx = dt * vxc * g.rdx, ddy = dt * vyc * g.rdy, ddz = dt * vzc * g.rdz;
 #else
     const T ddx = DIV_X(dt * vxc), ddy = DIV_Y(dt * vyc), ddz = DIV_Z(dt * vzc);
 #endif
-    const int ix1 = clampf_i(floor_((T)ix - ddx), sx);
-    const int iy1 = clampf_i(floor_((T)iy - ddy), sy);
-    const int iz1g = clampf_i(floor_((T)(iz + koff) - ddz), szg);
-    const int iz1 = min(max(iz1g - koff, 1), sz), iz2 = min(max(min(iz1g + 1, szg) - koff, 1), sz);
-    const int ix2 = min(ix1 + 1, sx), iy2 = min(iy1 + 1, sy);
-    const T wx = (ddx > (T)0 ? (T)1 : (T)0) - fmod1(ddx);
-    const T wy = (ddy > (T)0 ? (T)1 : (T)0) - fmod1(ddy);
-    const T wz = (ddz > (T)0 ? (T)1 : (T)0) - fmod1(ddz);
-    T v111, v211, v112, v212, v121, v221, v122, v222;      // A_o[ix·, iy·, iz·]
-    if (w.holds(ix1, ix2, iy1, iy2, iz1, iz2)) {
-        // one base address and three deltas instead of eight full index computations (two ring-slot look-ups instead of eight)
-        const int o1 = w.slot_off(iz1), o2 = w.slot_off(iz2);
-        const int base = a * (AdvWin<T>::NSLOT * AdvWin<T>::PLANE) + (iy1 - (w.y0 - 1)) * AdvWin<T>::WX + (ix1 - (w.x0 - 1));
-        const int ex = ix2 - ix1, ey = (iy2 - iy1) * AdvWin<T>::WX;          // 0 where the clamp at the array end bites
-        typename AdvWin<T>::lds_ptr q1 = w.L + base + o1, q2 = w.L + base + o2;
-        v111 = q1[0]; v211 = q1[ex]; v121 = q1[ey]; v221 = q1[ey + ex];
-        v112 = q2[0]; v212 = q2[ex]; v122 = q2[ey]; v222 = q2[ey + ex];
-    } else {
+    AdvDep<T> d;
+    d.i1 = clampf_i(floor_((T)ix - ddx), sx);
+    d.j1 = clampf_i(floor_((T)iy - ddy), sy);
+    const int k1g = clampf_i(floor_((T)(iz + koff) - ddz), szg);
+    d.k1 = min(max(k1g - koff, 1), sz);
+    d.k2 = min(max(min(k1g + 1, szg) - koff, 1), sz);
+    d.i2 = min(d.i1 + 1, sx);
+    d.j2 = min(d.j1 + 1, sy);
+    d.wx = (ddx > (T)0 ? (T)1 : (T)0) - fmod1(ddx);
+    d.wy = (ddy > (T)0 ? (T)1 : (T)0) - fmod1(ddy);
+    d.wz = (ddz > (T)0 ? (T)1 : (T)0) - fmod1(ddz);
+    return d;
+}
+template <class T>
+__device__ __forceinline__ int adv_holds(const AdvWin2<T> &w, const AdvDep<T> &d)
+{
+    typedef AdvWin2<T> W;
+    return (int)(d.i1 >= w.x0 - W::XLO) & (int)(d.i2 <= w.x0 + W::TX) & (int)(d.j1 >= w.y0 - W::YLO) & (int)(d.j2 <= w.y0 + W::TY) &
+           (int)(d.k1 >= w.iz - 1) & (int)(d.k2 <= w.iz + 1);
+}
+template <class T>
+__device__ __forceinline__ T adv_lerp8(T v111, T v211, T v121, T v221, T v112, T v212, T v122, T v222, const AdvDep<T> &d)
+{
+    const T fy1z1 = lerp_<T>(v111, v211, d.wx);
+    const T fy1z2 = lerp_<T>(v112, v212, d.wx);
+    const T fy2z1 = lerp_<T>(v121, v221, d.wx);
+    const T fy2z2 = lerp_<T>(v122, v222, d.wx);
+    const T fz1 = lerp_<T>(fy1z1, fy2z1, d.wy);
+    const T fz2 = lerp_<T>(fy1z2, fy2z2, d.wy);
+    return lerp_<T>(fz1, fz2, d.wz);
+}
+template <class T>
+__device__ __forceinline__ T adv_from_window(const AdvWin2<T> &w, int a, const AdvDep<T> &d)
+{
+    typedef AdvWin2<T> W;
+    const int base = a * (W::NSLOT * W::PLANE) + (d.j1 - (w.y0 - W::YLO)) * W::WX + (d.i1 - (w.x0 - W::XLO));
+    const int ex = d.i2 - d.i1, ey = (d.j2 - d.j1) * W::WX;                 // 0 where the clamp at the array end bites
+    typename W::lds_ptr q1 = w.L + base + w.slot_off(d.k1), q2 = w.L + base + w.slot_off(d.k2);
+    return adv_lerp8<T>(q1[0], q1[ex], q1[ey], q1[ey + ex], q2[0], q2[ex], q2[ey], q2[ey + ex], d);
+}
+template <class T>
+__device__ __forceinline__ T adv_from_global(const T *__restrict__ A_o, const AdvDep<T> &d, int sx, int sy)
+{
 #define AO(i_, j_, k_) A_o[IX3((i_)-1, (j_)-1, (k_)-1, sx, sy)]
-        v111 = AO(ix1, iy1, iz1); v211 = AO(ix2, iy1, iz1); v112 = AO(ix1, iy1, iz2); v212 = AO(ix2, iy1, iz2);
-        v121 = AO(ix1, iy2, iz1); v221 = AO(ix2, iy2, iz1); v122 = AO(ix1, iy2, iz2); v222 = AO(ix2, iy2, iz2);
+    return adv_lerp8<T>(AO(d.i1, d.j1, d.k1), AO(d.i2, d.j1, d.k1), AO(d.i1, d.j2, d.k1), AO(d.i2, d.j2, d.k1), AO(d.i1, d.j1, d.k2),
+                        AO(d.i2, d.j1, d.k2), AO(d.i1, d.j2, d.k2), AO(d.i2, d.j2, d.k2), d);
 #undef AO
-    }
-    const T fy1z1 = lerp_<T>(v111, v211, wx);
-    const T fy1z2 = lerp_<T>(v112, v212, wx);
-    const T fy2z1 = lerp_<T>(v121, v221, wx);
-    const T fy2z2 = lerp_<T>(v122, v222, wx);
-    const T fz1 = lerp_<T>(fy1z1, fy2z1, wy);
-    const T fz2 = lerp_<T>(fy1z2, fy2z2, wy);
-    A[IX3(ix - 1, iy - 1, iz - 1, sx, sy)] = lerp_<T>(fz1, fz2, wz);
+}
+template <class T>
+__device__ __forceinline__ T adv_value(const AdvWin2<T> &w, int a, const T *__restrict__ A_o, const AdvDep<T> &d, int sx, int sy)
+{
+    return adv_holds<T>(w, d) ? adv_from_window<T>(w, a, d) : adv_from_global<T>(A_o, d, sx, sy);
 }
 
-template <class T>
-__global__ __launch_bounds__(512) void k_advect_win(T *__restrict__ Vx, const T *__restrict__ Vx_o, T *__restrict__ Vy,
-                                                    const T *__restrict__ Vy_o, T *__restrict__ Vz, const T *__restrict__ Vz_o,
-                                                    T *__restrict__ C, const T *__restrict__ C_o, T dt, Geo<T> g, int nx, int ny,
-                                                    int nz, int flags, int kz, int koff, int nzg)
+template <class T, bool faithful>
+__global__ __launch_bounds__(1024) void k_advect_win2(T *__restrict__ Vx, const T *__restrict__ Vx_o, T *__restrict__ Vy,
+                                                      const T *__restrict__ Vy_o, T *__restrict__ Vz, const T *__restrict__ Vz_o,
+                                                      T *__restrict__ C, const T *__restrict__ C_o, T dt, Geo<T> g, int nx, int ny,
+                                                      int nz, int flags, int kz, int koff, int nzg)
 {
-    typedef AdvWin<T> W;
-    const int faithful = flags & 1, through = flags & 2;
+    typedef AdvWin2<T> W;
+    const bool through = flags & 2;
     const int gz0 = nzg > 0 ? nzg : 0, gz1 = nzg > 0 ? nzg + 1 : 0;
     extern __shared__ __align__(16) unsigned char advect_lds_raw[];
     T *L = reinterpret_cast<T *>(advect_lds_raw);
     const int tid = threadIdx.y * W::TX + threadIdx.x;
     const int x0 = blockIdx.x * W::TX + 1, y0 = blockIdx.y * W::TY + 1;
-    const int zb = blockIdx.z * kz + 1, ze = min(zb + kz, nz + 2);          // planes iz ∈ [zb, ze) of the (nz+1)-plane range
+    const int zb = blockIdx.z * kz + 1, ze = min(zb + kz, nz + 1);          // planes iz ∈ [zb, ze), iz ≤ nz
     const int ix = x0 + threadIdx.x, iy = y0 + threadIdx.y;
     const T *const src[4] = {Vx_o, Vy_o, Vz_o, C_o};
     const int sxs[4] = {nx + 1, nx, nx, nx}, sys[4] = {ny, ny + 1, ny, ny}, szs[4] = {nz, nz, nz + 1, nz};
-    // window positions this thread fills (two per array and plane: 737 positions, 512 threads)
-    int q[2], gi[2], gj[2];
+    // window positions this thread fills (two per array and plane: 1 224 positions, 1 024 threads), clamped like the gathers;
+    // in-plane offsets fit 32 bits, the plane's base is workgroup-uniform
+    unsigned fbase[4][2];
+    idx_t fplane[4];
+    int q[2];
     bool has[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        q[h] = tid + h * 512;
+        q[h] = tid + h * 1024;
         has[h] = q[h] < W::PLANE;
         const int qq = has[h] ? q[h] : 0;
-        gi[h] = x0 - 1 + qq % W::WX;                        // (the 68th column of the pitch is loaded too: never looked up)
-        gj[h] = y0 - 1 + qq / W::WX;
+        const int gi = x0 - W::XLO + qq % W::WX, gj = y0 - W::YLO + qq / W::WX;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int ci = min(max(gi, 1), sxs[a]), cj = min(max(gj, 1), sys[a]);
+            fbase[a][h] = (unsigned)(ci - 1) + (unsigned)sxs[a] * (unsigned)(cj - 1);
+        }
     }
-    auto fetch = [&](int plane, T (&v)[4][2]) {            // plane: 1-based, may lie outside the arrays (clamped like the gathers)
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a) fplane[a] = (idx_t)sxs[a] * sys[a];
+    auto fetch = [&](int plane, T (&v)[4][2]) {            // plane: 1-based, may lie outside the arrays
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int ci = min(max(gi[h], 1), sxs[a]), cj = min(max(gj[h], 1), sys[a]), ck = min(max(plane, 1), szs[a]);
-                v[a][h] = has[h] ? src[a][IX3(ci - 1, cj - 1, ck - 1, sxs[a], sys[a])] : (T)0;
-            }
+        for (int a = 0; a < 4; ++a) {
+            const T *__restrict__ pl = src[a] + fplane[a] * (min(max(plane, 1), szs[a]) - 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) v[a][h] = has[h] ? pl[fbase[a][h]] : (T)0;
+        }
     };
     auto publish = [&](int plane, const T (&v)[4][2]) {
-        const int slot = ((plane % W::NSLOT) + W::NSLOT) % W::NSLOT;
+        const int slot = plane & (W::NSLOT - 1);            // plane ≥ 0
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -900,55 +1101,100 @@ __global__ __launch_bounds__(512) void k_advect_win(T *__restrict__ Vx, const T 
     };
     {
         T v[4][2];
-        for (int pl = zb - 1; pl <= zb + 2; ++pl) { fetch(pl, v); publish(pl, v); }
+        for (int pl = zb - 1; pl <= zb + 1; ++pl) { fetch(pl, v); publish(pl, v); }
     }
     __syncthreads();
-    W w{(typename W::lds_ptr)L, x0, y0, zb, {0, 0, 0, 0}};
+    W w{(typename W::lds_ptr)L, x0, y0, zb};
+    const bool in = ix <= nx && iy <= ny;
+    const int cix = min(ix, nx), ciy = min(iy, ny);
+    // stores: the in-plane offset of (ix, iy) per thread (32 bits), the plane's base workgroup-uniform
+    const unsigned oVx = (unsigned)(cix - 1) + (unsigned)(nx + 1) * (unsigned)(ciy - 1), oVy = (unsigned)(cix - 1) + (unsigned)nx * (unsigned)(ciy - 1);
+    const unsigned oC = oVy;                                // C and Vz: rows of nx like Vy's
+    const idx_t pVx = (idx_t)(nx + 1) * ny, pVy = (idx_t)nx * (ny + 1), pC = (idx_t)nx * ny;
+    const bool vz_distinct = Vz != Vz_o;
 #define VXO(i_, j_, k_) w.get(0, (i_), (j_), (k_))
 #define VYO(i_, j_, k_) w.get(1, (i_), (j_), (k_))
 #define VZO(i_, j_, k_) w.get(2, (i_), (j_), (k_))
     for (int iz = zb; iz < ze; ++iz) {
         T nxt[4][2];
-        fetch(iz + 3, nxt);                                 // in flight behind this plane's arithmetic
+        fetch(iz + 2, nxt);                                 // in flight behind this plane's arithmetic
         w.set_plane(iz);
-        if (ix <= nx + 1 && iy <= ny + 1) {
-            T vxc, vyc, vzc;
+        T *__restrict__ const Vxp = Vx + pVx * (iz - 1), *__restrict__ const Vyp = Vy + pVy * (iz - 1), *__restrict__ const Vzp = Vz + pC * (iz - 1),
+                              *__restrict__ const Cp = C + pC * (iz - 1);
+        if (in) {
+            const T vx000 = VXO(ix, iy, iz), vx100 = VXO(ix + 1, iy, iz), vy000 = VYO(ix, iy, iz), vy010 = VYO(ix, iy + 1, iz);
+            const T vz000 = VZO(ix, iy, iz), vz001 = VZO(ix, iy, iz + 1);
             bool wx_ = false, wy_ = false, wz_ = false;
-            if (ix > 1 && ix < nx + 1 && iy <= ny && iz <= nz) { // multi.jl:218-223
-                wx_ = true;
-                vxc = VXO(ix, iy, iz);
-                vyc = (T)0.25 * (((VYO(ix - 1, iy, iz) + VYO(ix - 1, iy + 1, iz)) + VYO(ix, iy, iz)) + VYO(ix, iy + 1, iz));
-                vzc = (T)0.25 * (((VZO(ix - 1, iy, iz) + VZO(ix - 1, iy, iz + 1)) + VZO(ix, iy, iz)) + VZO(ix, iy, iz + 1));
-                backtrack_win<T>(Vx, Vx_o, w, 0, vxc, vyc, vzc, dt, g, ix, iy, iz, nx + 1, ny, nz, koff, gz0);
+            if (ix > 1 && iy > 1 && iz > 1) {
+                // all four branches of multi.jl:218-241 apply
+                const T ax = vx000;                                                                                        // :219
+                const T ay = (T)0.25 * (((VYO(ix - 1, iy, iz) + VYO(ix - 1, iy + 1, iz)) + vy000) + vy010);                // :220
+                const T az = (T)0.25 * (((VZO(ix - 1, iy, iz) + VZO(ix - 1, iy, iz + 1)) + vz000) + vz001);                // :221
+                const T cx = (T)0.25 * (((VXO(ix, iy, iz - 1) + VXO(ix + 1, iy, iz - 1)) + vx000) + vx100);                // :231
+                const T cy = (T)0.25 * (((VYO(ix, iy, iz - 1) + VYO(ix, iy + 1, iz - 1)) + vy000) + vy010);                // :232
+                const T cz = vz000;                                                                                        // :233
+                const T ex = (T)0.5 * (vx000 + vx100), ey = (T)0.5 * (vy000 + vy010), ez = (T)0.5 * (vz000 + vz001);      // :237-239
+                wx_ = true; wy_ = true;
+                Vxp[oVx] = adv_value<T>(w, 0, Vx_o, adv_departure<T>(ax, ay, az, dt, g, ix, iy, iz, nx + 1, ny, nz, koff, gz0), nx + 1, ny);
+                if (faithful) {
+                    // the third branch back-tracks Vy (sic) and its store lands on the second's: only the third is computed
+                    Vyp[oVy] = adv_value<T>(w, 1, Vy_o, adv_departure<T>(cx, cy, cz, dt, g, ix, iy, iz, nx, ny + 1, nz, koff, gz0), nx, ny + 1);
+                } else {
+                    const T bx = (T)0.25 * (((VXO(ix, iy - 1, iz) + VXO(ix + 1, iy - 1, iz)) + vx000) + vx100);            // :225
+                    const T by = vy000;                                                                                    // :226
+                    const T bz = (T)0.25 * (((VZO(ix, iy - 1, iz) + VZO(ix, iy - 1, iz + 1)) + vz000) + vz001);            // :227
+                    wz_ = true;
+                    Vyp[oVy] = adv_value<T>(w, 1, Vy_o, adv_departure<T>(bx, by, bz, dt, g, ix, iy, iz, nx, ny + 1, nz, koff, gz0), nx, ny + 1);
+                    Vzp[oC] = adv_value<T>(w, 2, Vz_o, adv_departure<T>(cx, cy, cz, dt, g, ix, iy, iz, nx, ny, nz + 1, koff, gz1), nx, ny);
+                }
+                Cp[oC] = adv_value<T>(w, 3, C_o, adv_departure<T>(ex, ey, ez, dt, g, ix, iy, iz, nx, ny, nz, koff, gz0), nx, ny);
+            } else {
+                // cells on the low faces: the branches one by one, as the reference guards them
+                T vxc, vyc, vzc;
+                if (ix > 1) { // multi.jl:218-223
+                    wx_ = true;
+                    vxc = vx000;
+                    vyc = (T)0.25 * (((VYO(ix - 1, iy, iz) + VYO(ix - 1, iy + 1, iz)) + vy000) + vy010);
+                    vzc = (T)0.25 * (((VZO(ix - 1, iy, iz) + VZO(ix - 1, iy, iz + 1)) + vz000) + vz001);
+                    Vxp[oVx] = adv_value<T>(w, 0, Vx_o, adv_departure<T>(vxc, vyc, vzc, dt, g, ix, iy, iz, nx + 1, ny, nz, koff, gz0), nx + 1, ny);
+                }
+                if (iy > 1) { // multi.jl:224-229
+                    wy_ = true;
+                    vxc = (T)0.25 * (((VXO(ix, iy - 1, iz) + VXO(ix + 1, iy - 1, iz)) + vx000) + vx100);
+                    vyc = vy000;
+                    vzc = (T)0.25 * (((VZO(ix, iy - 1, iz) + VZO(ix, iy - 1, iz + 1)) + vz000) + vz001);
+                    Vyp[oVy] = adv_value<T>(w, 1, Vy_o, adv_departure<T>(vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny + 1, nz, koff, gz0), nx, ny + 1);
+                }
+                if (iz > 1) { // multi.jl:230-235 (sic: back-tracks Vy again in the reference; this store comes second and wins)
+                    vxc = (T)0.25 * (((VXO(ix, iy, iz - 1) + VXO(ix + 1, iy, iz - 1)) + vx000) + vx100);
+                    vyc = (T)0.25 * (((VYO(ix, iy, iz - 1) + VYO(ix, iy + 1, iz - 1)) + vy000) + vy010);
+                    vzc = vz000;
+                    if (faithful) {
+                        wy_ = true;
+                        Vyp[oVy] = adv_value<T>(w, 1, Vy_o, adv_departure<T>(vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny + 1, nz, koff, gz0), nx, ny + 1);
+                    } else {
+                        wz_ = true;
+                        Vzp[oC] = adv_value<T>(w, 2, Vz_o, adv_departure<T>(vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny, nz + 1, koff, gz1), nx, ny);
+                    }
+                }
+                { // multi.jl:236-241
+                    vxc = (T)0.5 * (vx000 + vx100);
+                    vyc = (T)0.5 * (vy000 + vy010);
+                    vzc = (T)0.5 * (vz000 + vz001);
+                    Cp[oC] = adv_value<T>(w, 3, C_o, adv_departure<T>(vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny, nz, koff, gz0), nx, ny);
+                }
             }
-            if (iy > 1 && iy < ny + 1 && ix <= nx && iz <= nz) { // multi.jl:224-229
-                wy_ = true;
-                vxc = (T)0.25 * (((VXO(ix, iy - 1, iz) + VXO(ix + 1, iy - 1, iz)) + VXO(ix, iy, iz)) + VXO(ix + 1, iy, iz));
-                vyc = VYO(ix, iy, iz);
-                vzc = (T)0.25 * (((VZO(ix, iy - 1, iz) + VZO(ix, iy - 1, iz + 1)) + VZO(ix, iy, iz)) + VZO(ix, iy, iz + 1));
-                backtrack_win<T>(Vy, Vy_o, w, 1, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny + 1, nz, koff, gz0);
-            }
-            if (iz > 1 && iz < nz + 1 && ix <= nx && iy <= ny) { // multi.jl:230-235 (sic: back-tracks Vy again in the reference)
-                if (faithful) wy_ = true; else wz_ = true;
-                vxc = (T)0.25 * (((VXO(ix, iy, iz - 1) + VXO(ix + 1, iy, iz - 1)) + VXO(ix, iy, iz)) + VXO(ix + 1, iy, iz));
-                vyc = (T)0.25 * (((VYO(ix, iy, iz - 1) + VYO(ix, iy + 1, iz - 1)) + VYO(ix, iy, iz)) + VYO(ix, iy + 1, iz));
-                vzc = VZO(ix, iy, iz);
-                if (faithful) backtrack_win<T>(Vy, Vy_o, w, 1, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny + 1, nz, koff, gz0);
-                else backtrack_win<T>(Vz, Vz_o, w, 2, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny, nz + 1, koff, gz1);
-            }
-            if (ix <= nx && iy <= ny && iz <= nz) { // multi.jl:236-241
-                vxc = (T)0.5 * (VXO(ix, iy, iz) + VXO(ix + 1, iy, iz));
-                vyc = (T)0.5 * (VYO(ix, iy, iz) + VYO(ix, iy + 1, iz));
-                vzc = (T)0.5 * (VZO(ix, iy, iz) + VZO(ix, iy, iz + 1));
-                backtrack_win<T>(C, C_o, w, 3, vxc, vyc, vzc, dt, g, ix, iy, iz, nx, ny, nz, koff, gz0);
-            }
-            if (through) {      // entries no branch stores: old value written through (complete outputs, see advect())
-                if (!wx_ && iy <= ny && iz <= nz) Vx[IX3(ix - 1, iy - 1, iz - 1, nx + 1, ny)] = VXO(ix, iy, iz);
-                if (!wy_ && ix <= nx && iz <= nz) Vy[IX3(ix - 1, iy - 1, iz - 1, nx, ny + 1)] = VYO(ix, iy, iz);
-                if (!wz_ && Vz != Vz_o && ix <= nx && iy <= ny) Vz[IX3(ix - 1, iy - 1, iz - 1, nx, ny)] = VZO(ix, iy, iz);
+            if (through) {      // entries no branch stores: the old value written through (complete outputs, see advect())
+                if (!wx_) Vxp[oVx] = vx000;
+                if (!wy_) Vyp[oVy] = vy000;
+                if (!wz_ && vz_distinct) Vzp[oC] = vz000;
+                // the far faces of the staggered arrays (the reference's range reaches them and does nothing there)
+                if (ix == nx) Vxp[oVx + 1] = vx100;
+                if (iy == ny) Vyp[oVy + nx] = vy010;
+                if (iz == nz && vz_distinct) (Vzp + pC)[oC] = vz001;
             }
         }
-        publish(iz + 3, nxt);
+        publish(iz + 2, nxt);
         __syncthreads();
     }
 #undef VXO
@@ -971,16 +1217,21 @@ hipError_t advect(hipStream_t s, T *Vx, const T *Vx_o, T *Vy, const T *Vy_o, T *
                            C_o, (T)dt, make_geo<T>(dx, dy, dz), nx, ny, nz, faithful, koff, nzg);
         return hipGetLastError();
     }
-    typedef AdvWin<T> W;
+    typedef AdvWin2<T> W;
     const size_t lds = (size_t)4 * W::NSLOT * W::PLANE * sizeof(T);
-    // > 64 KB of dynamic LDS needs the opt-in (per device: a process may drive several)
-    hipError_t ea = hipFuncSetAttribute((const void *)k_advect_win<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t ea = hipFuncSetAttribute((faithful & 1) ? (const void *)k_advect_win2<T, true> : (const void *)k_advect_win2<T, false>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (ea != hipSuccess) return ea;
-    const int kz = 32;
+    static const int kz_env = std::getenv("NS3D_ADVECT_KZ") ? std::atoi(std::getenv("NS3D_ADVECT_KZ")) : 0;
+    const int kz = kz_env > 0 ? kz_env : (nz >= 128 ? 64 : 32);    // planes per workgroup (three of them are the window's lead-in)
     const dim3 blk(W::TX, W::TY, 1);
-    const dim3 grd((unsigned)((nx + 1 + W::TX - 1) / W::TX), (unsigned)((ny + 1 + W::TY - 1) / W::TY), (unsigned)((nz + 1 + kz - 1) / kz));
-    hipLaunchKernelGGL(k_advect_win<T>, grd, blk, lds, s, Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, C, C_o, (T)dt, make_geo<T>(dx, dy, dz), nx,
-                       ny, nz, faithful, kz, koff, nzg);
+    const dim3 grd((unsigned)((nx + W::TX - 1) / W::TX), (unsigned)((ny + W::TY - 1) / W::TY), (unsigned)((nz + kz - 1) / kz));
+    if (faithful & 1)
+        hipLaunchKernelGGL((k_advect_win2<T, true>), grd, blk, lds, s, Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, C, C_o, (T)dt, make_geo<T>(dx, dy, dz),
+                           nx, ny, nz, faithful, kz, koff, nzg);
+    else
+        hipLaunchKernelGGL((k_advect_win2<T, false>), grd, blk, lds, s, Vx, Vx_o, Vy, Vy_o, Vz, Vz_o, C, C_o, (T)dt, make_geo<T>(dx, dy, dz),
+                           nx, ny, nz, faithful, kz, koff, nzg);
     return hipGetLastError();
 }
 
@@ -2717,6 +2968,8 @@ hipError_t divtest(hipStream_t s, double d, long n, unsigned long long seed, uns
     template hipError_t predict_V<T>(hipStream_t, T *, T *, T *, const T *, const T *, const T *, const T *, \
                                      const T *, const T *, double, double, double, double, double, double,   \
                                      int, int, int);                                                         \
+    template hipError_t predict_fused<T>(hipStream_t, T *, T *, T *, const T *, const T *, const T *, double, \
+                                         double, double, double, double, double, double, int, int, int);      \
     template hipError_t set_cylinder<T>(hipStream_t, T *, T *, T *, T *, double, double, double, double,     \
                                         double, double, int, double, double, double, double, double, double, \
                                         int, int, int);                                                      \

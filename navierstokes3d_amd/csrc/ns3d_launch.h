@@ -42,6 +42,9 @@
     hipError_t pt_sweep(hipStream_t, int variant, const T *, T *, T *, const T *, const ns3d_pt_params &,    \
                         int k0, int k1);                                                                     \
     template <class T>                                                                                       \
+    hipError_t predict_fused(hipStream_t, T *, T *, T *, const T *, const T *, const T *, double mu, double rho, \
+                             double g, double dt, double dx, double dy, double dz, int, int, int);           \
+    template <class T>                                                                                       \
     hipError_t pt_persist(hipStream_t, const T *, T *, T *, const T *, const ns3d_pt_params &, int n_iters);  \
     template <class T>                                                                                       \
     hipError_t pt_sweep2(hipStream_t, int variant, const T *, T *, const T *, T *, const T *,                \

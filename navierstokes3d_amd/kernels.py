@@ -219,6 +219,15 @@ def predict_V(Vx, Vy, Vz, txx, tyy, tzz, txy, txz, tyz, rho, g, dt, dx, dy, dz, 
                         *_d(rho, g, dt, dx, dy, dz), nx, ny, nz)
 
 
+
+def predict_fused(Vx_new, Vy_new, Vz_new, Vx, Vy, Vz, mu, rho, g, dt, dx, dy, dz, ctx=None):
+    """{update_τ!; predict_V!} (multi.jl:449,451) in one pass: complete predicted fields into buffers of their own, the stress
+    arrays neither read nor written; the caller swaps the names."""
+    nx, ny, nz = Vx.shape[0] - 1, Vx.shape[1], Vx.shape[2]
+    _ctx(ctx, Vx).call("predict_fused", Vx, _chk(Vx_new, (nx + 1, ny, nz), "Vx_new"), _chk(Vy_new, (nx, ny + 1, nz), "Vy_new"),
+                       _chk(Vz_new, (nx, ny, nz + 1), "Vz_new"), _chk(Vx, (nx + 1, ny, nz), "Vx"), _chk(Vy, (nx, ny + 1, nz), "Vy"),
+                       _chk(Vz, (nx, ny, nz + 1), "Vz"), *_d(mu, rho, g, dt, dx, dy, dz), nx, ny, nz)
+
 def set_cylinder(Cf, Vx, Vy, Vz, a2, b2, ox, oy, sinb, cosb, *rest, ctx=None):
     """set_cylinder!  multi.jl:249-281 (19 arguments: …,xco_g,yco_g,zco_g,lx,ly,lz,dx,dy,dz) or
     gpu.jl:336-368 (16 arguments: …,lx,ly,lz,dx,dy,dz) — dispatched on the argument count like the two

@@ -35,6 +35,7 @@ _P, _D, _I, _L = C.c_void_p, C.c_double, C.c_int, C.c_long
 SIGNATURES = {
     "update_tau": [_P] * 9 + [_D] * 4 + [_I] * 3,
     "predict_V": [_P] * 9 + [_D] * 6 + [_I] * 3,
+    "predict_fused": [_P] * 6 + [_D] * 7 + [_I] * 3,
     "set_cylinder": [_P] * 4 + [_D] * 15 + [_I] * 3,
     "set_cylinder_local": [_P] * 4 + [_D] * 12 + [_I] * 3,
     "update_divV": [_P] * 4 + [_D] * 3 + [_I] * 3,

@@ -57,6 +57,86 @@ def test_predict_V(hip, oracle, grid, mode):
 
 
 @pytest.mark.parametrize("mode", ["strict", "fast"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("grid", GRIDS + [(131, 37, 70), (64, 16, 32), (65, 17, 33), (129, 3, 3), (3, 3, 3)])
+def test_predict_fused_equals_update_tau_then_predict_V(hip, oracle, grid, dtype, mode):
+    """ns3d_predict_fused (k_predict_fused: the stresses evaluated from an LDS window of the velocities, never stored) against
+    the oracle's update_τ! followed by predict_V! (multi.jl:449,451): complete predicted fields, bit for bit in STRICT mode
+    (non-power-of-two spacings: the exact-division build, DIV_3 through the known-divisor sequence), 1e-12 / 1e-5 in FAST;
+    one tile, several tiles and z-chunks with ragged edges, tiles of exactly 64×16×32 cells and one cell more; the inputs
+    untouched."""
+    import torch
+    nx, ny, nz = grid
+    g = geometry(*grid)
+    host = [np.asfortranarray(a.astype(dtype)) for a in fields(nx, ny, nz, ["vx", "vy", "vz", "c", "c", "c", "s", "s", "s"], 5)]
+    Vx, Vy, Vz, txx, tyy, tzz, txy, txz, tyz = [a.copy(order="F") for a in host]
+    oracle.update_tau(txx, tyy, tzz, txy, txz, tyz, Vx, Vy, Vz, g["mu"], g["dx"], g["dy"], g["dz"])
+    oracle.predict_V(Vx, Vy, Vz, txx, tyy, tzz, txy, txz, tyz, g["rho"], g["g"], g["dt"], g["dx"], g["dy"], g["dz"])
+    ctx = hip.Context(0, mode)
+    dV = [hip.from_numpy(a) for a in host[:3]]
+    out = [hip.from_numpy(np.full_like(a, 777.0)) for a in host[:3]]
+    hip.predict_fused(*out, *dV, g["mu"], g["rho"], g["g"], g["dt"], g["dx"], g["dy"], g["dz"], ctx=ctx)
+    torch.cuda.synchronize()
+    for name, got, ref, src in zip("xyz", out, (Vx, Vy, Vz), host[:3]):
+        got = hip.to_numpy(got)
+        if mode == "strict":
+            assert np.array_equal(got, ref), "V%s not bit-identical on %r (max |Δ| %g)" % (name, grid, np.abs(got - ref).max())
+        else:
+            assert rel_l2(got, ref) < (1e-12 if dtype == np.float64 else 1e-5), (name, rel_l2(got, ref))
+    for d, a in zip(dV, host[:3]):
+        assert np.array_equal(hip.to_numpy(d), a)
+    with pytest.raises(Exception):
+        hip.predict_fused(dV[0], out[1], out[2], *dV, g["mu"], g["rho"], g["g"], g["dt"], g["dx"], g["dy"], g["dz"], ctx=ctx)
+    ctx.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_predict_fused_power_of_two_spacings_and_a_larger_grid(hip, oracle, dtype):
+    """The power-of-two build (x/d = x·(1/d), v/3 through the known-divisor sequence with its guard) on values that over- and
+    underflow when scaled, against the oracle; and a 260×150×131 grid (5×10×3 workgroups) against the two unfused HIP kernels."""
+    import torch
+    grid = (70, 9, 7)
+    nx, ny, nz = grid
+    big = 1e300 if dtype == np.float64 else 1e36
+    tiny = 1e-305 if dtype == np.float64 else 1e-42
+    ctx = hip.Context(0, "strict")
+    for sp in POW2:
+        g = dict(geometry(*grid)); g.update(sp)
+        for scale in (1.0, big, tiny):
+            host = [np.asfortranarray((a * scale).astype(dtype)) for a in fields(nx, ny, nz, ["vx", "vy", "vz", "c", "c", "c", "s", "s", "s"], 11)]
+            Vx, Vy, Vz, txx, tyy, tzz, txy, txz, tyz = [a.copy(order="F") for a in host]
+            with np.errstate(all="ignore"):
+                oracle.update_tau(txx, tyy, tzz, txy, txz, tyz, Vx, Vy, Vz, g["mu"], g["dx"], g["dy"], g["dz"])
+                oracle.predict_V(Vx, Vy, Vz, txx, tyy, tzz, txy, txz, tyz, g["rho"], g["g"], g["dt"], g["dx"], g["dy"], g["dz"])
+            dV = [hip.from_numpy(a) for a in host[:3]]
+            out = [hip.from_numpy(np.zeros_like(a)) for a in host[:3]]
+            hip.predict_fused(*out, *dV, g["mu"], g["rho"], g["g"], g["dt"], g["dx"], g["dy"], g["dz"], ctx=ctx)
+            torch.cuda.synchronize()
+            for got, ref in zip(out, (Vx, Vy, Vz)):
+                assert np.array_equal(hip.to_numpy(got), ref, equal_nan=True), (sp, scale)
+    nx, ny, nz = 260, 150, 131
+    g = geometry(nx, ny, nz)
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+
+    def rnd_dev(*shape):
+        t = hip.zeros(shape, dtype=tdt)
+        t.permute(2, 1, 0).copy_(torch.rand(shape[::-1], generator=gen, device="cuda", dtype=tdt) - 0.5)
+        return t
+    Vx, Vy, Vz = rnd_dev(nx + 1, ny, nz), rnd_dev(nx, ny + 1, nz), rnd_dev(nx, ny, nz + 1)
+    out = [hip.zeros(tuple(V.shape), dtype=tdt) for V in (Vx, Vy, Vz)]
+    hip.predict_fused(*out, Vx, Vy, Vz, g["mu"], g["rho"], g["g"], g["dt"], g["dx"], g["dy"], g["dz"], ctx=ctx)
+    c, s_ = (nx, ny, nz), (nx - 1, ny - 1, nz - 1)
+    tau = [hip.zeros(c, dtype=tdt) for _ in range(3)] + [hip.zeros(s_, dtype=tdt) for _ in range(3)]
+    hip.update_tau(*tau, Vx, Vy, Vz, g["mu"], g["dx"], g["dy"], g["dz"], ctx=ctx)
+    hip.predict_V(Vx, Vy, Vz, *tau, g["rho"], g["g"], g["dt"], g["dx"], g["dy"], g["dz"], ctx=ctx)
+    torch.cuda.synchronize()
+    for got, ref in zip(out, (Vx, Vy, Vz)):
+        assert torch.equal(got, ref)
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["strict", "fast"])
 @pytest.mark.parametrize("grid", GRIDS)
 def test_update_divV(hip, oracle, grid, mode):
     g = geometry(*grid)

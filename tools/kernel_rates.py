@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--nz", type=int, default=None)
     ap.add_argument("--mode", default="strict")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default="", help="comma-separated kernel names (default: all)")
     a = ap.parse_args()
     p = cavity_params(a.n, a.nz)
     nx, ny, nz = p.nx, p.ny, p.nz
@@ -47,6 +48,7 @@ def main():
     cases = [
         ("update_tau", 72, lambda: K.update_tau(txx, tyy, tzz, txy, txz, tyz, Vx, Vy, Vz, p.mu, p.dx, p.dy, p.dz, ctx=ctx)),
         ("predict_V", 96, lambda: K.predict_V(Vx, Vy, Vz, txx, tyy, tzz, txy, txz, tyz, p.rho, 0.0, p.dt, p.dx, p.dy, p.dz, ctx=ctx)),
+        ("predict_fused", 48, lambda: K.predict_fused(Vxo, Vyo, Vzo, Vx, Vy, Vz, p.mu, p.rho, 0.0, p.dt, p.dx, p.dy, p.dz, ctx=ctx)),
         ("update_divV", 32, lambda: K.update_divV(dV, Vx, Vy, Vz, p.dx, p.dy, p.dz, ctx=ctx)),
         ("update_dPrdtau", 32, lambda: K.update_dPrdtau(Pr, D, dV, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, ctx=ctx)),
         ("update_Pr", 24, lambda: K.update_Pr(Pr, D, 1e-9, ctx=ctx)),
@@ -58,8 +60,21 @@ def main():
         ("set_bc_Vel", 0, lambda: K.set_bc_Vel_multi(Vx, Vy, Vz, True, 1.0, ctx=ctx)),
         ("copy", 16, lambda: K.copy(Co, C, ctx=ctx)),
         ("advect", 56, lambda: K.advect(Vx, Vxo, Vy, Vyo, Vz, Vzo, C, Co, p.dt, p.dx, p.dy, p.dz, ctx=ctx)),
+        ("advect_fixed", 64, lambda: K.advect(Vx, Vxo, Vy, Vyo, Vz, Vzo, C, Co, p.dt, p.dx, p.dy, p.dz, faithful=False, ctx=ctx)),
+        ("copy_advect", 56, lambda: K.copy_advect(Vxo, Vx, Vyo, Vy, Vzo, Vz, Co, C, p.dt, p.dx, p.dy, p.dz, ctx=ctx)),
     ]
+    only = [q for q in a.only.split(",") if q]
+    if not only or "advect_stream" in only:
+        # the stream of the cylinder case at CFL_adv = 1 (multi.jl:342): departure points 0.7-1.3 cells upstream in x, within
+        # 0.3 cells in y and z
+        Sx, Sy, Sz = rnd(nx + 1, ny, nz), rnd(nx, ny + 1, nz), rnd(nx, ny, nz + 1)
+        Sx.mul_(0.3).add_(1.0).mul_(p.dx / p.dt)
+        Sy.mul_(0.3 * p.dy / p.dt)
+        Sz.mul_(0.3 * p.dz / p.dt)
+        cases.append(("advect_stream", 56, lambda: K.advect(Vx, Sx, Vy, Sy, Vz, Sz, C, Co, p.dt, p.dx, p.dy, p.dz, ctx=ctx)))
     for name, bpc, fn in cases:
+        if only and name not in only:
+            continue
         fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
