@@ -40,7 +40,7 @@ export @init_parallel_stencil, @parallel, @parallel_indices, @zeros, Data
 export update_τ!, predict_V!, set_cylinder!, update_∇V!, update_dPrdτ!, update_Pr!, compute_res!, correct_V!, advect!
 export bc_x!, bc_y!, bc_z!, bc_zV!, bc_xhydstatic!, bc_x_Vx!, bc_x_Pr!, bc_xVx!, bc_xVyz!
 export init_global_grid, finalize_global_grid, nx_g, ny_g, nz_g, x_g, y_g, z_g, update_halo!, gather!
-export pt_solve!, pt_solve_slab!, maxabs
+export pt_solve!, pt_solve_slab!, maxabs, copy_advect!, predict_fused!, poisson_direct!
 
 const libns3d = get(ENV, "NS3D_LIB", joinpath(@__DIR__, "..", "navierstokes3d_amd", "libns3d.so"))
 const NS3D_STRICT, NS3D_FAST, NS3D_ASYNC = Cint(0), Cint(1), Cint(2)
@@ -216,6 +216,22 @@ function copy_advect!(Vx_new, Vx, Vy_new, Vy, Vz_new, Vz, C_new, C, dt, dx, dy, 
                 (Ptr{Cvoid}, PF, PF, PF, PF, PF, PF, PF, PF, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint, Cint, Cint),
                 _ctx(), ptr(Vx_new), ptr(Vx), ptr(Vy_new), ptr(Vy), ptr(Vz_new), ptr(Vz), ptr(C_new), ptr(C),
                 dt, dx, dy, dz, nx, ny, nz, faithful ? 1 : 0))
+end
+
+"""
+    predict_fused!(Vx_new, Vy_new, Vz_new, Vx, Vy, Vz, μ, ρ, g, dt, dx, dy, dz)
+
+Optional, same results as `update_τ!(τ…, Vx, Vy, Vz, μ, …); predict_V!(Vx, Vy, Vz, τ…, ρ, g, dt, …)` (multi.jl:449,451 /
+gpu.jl:121-122) for a driver that does not look at the stress arrays: reads the velocities, writes COMPLETE predicted fields into
+buffers of their own (e.g. `Vx_o, Vy_o, Vz_o`, idle at that point of the time step); the caller swaps the names afterwards.  The
+stresses are evaluated on the fly and not stored; multi.jl:450's `update_halo!(τxx,τyy,τzz)` goes with them (every rank computes
+those values itself from velocities that are consistent after multi.jl:477).
+"""
+function predict_fused!(Vx_new, Vy_new, Vz_new, Vx, Vy, Vz, μ, ρ, g, dt, dx, dy, dz)
+    nx, ny, nz = size(Vx, 1) - 1, size(Vx, 2), size(Vx, 3); _sync()
+    check(ccall((:ns3d_predict_fused_f64, libns3d), Cint,
+                (Ptr{Cvoid}, PF, PF, PF, PF, PF, PF, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint, Cint),
+                _ctx(), ptr(Vx_new), ptr(Vy_new), ptr(Vz_new), ptr(Vx), ptr(Vy), ptr(Vz), μ, ρ, g, dt, dx, dy, dz, nx, ny, nz))
 end
 
 # boundary-plane kernels: the array's own extents are passed (they act on Pr, Vx, Vy and Vz alike)
