@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--nt", type=int, default=3)
     ap.add_argument("--mode", default="strict")
     ap.add_argument("--compare-fast", action="store_true")
+    ap.add_argument("--marginal", type=int, default=0, metavar="N",
+                    help="also run nt+N steps and report (wall(nt+N) - wall(nt)) / N: the cost of one more time step without set-up, "
+                         "initial conditions and the final copy to the host")
     ap.add_argument("--compare-direct", action="store_true",
                     help="also run with pressure=\"direct\" (outside parity): seconds per step, and how far its fields are from the PT run's")
     a = ap.parse_args()
@@ -53,6 +56,10 @@ def main():
            "last_err_per_step": [e[-1] if e else None for e in info.errs], "wall_s": wall, "s_per_step": wall / a.nt,
            "Mcells_iter_per_s_whole_run": cells * its / wall / 1e6,
            "finite": bool(all(np.isfinite(v).all() for v in fields.values()))}
+    if a.marginal > 0:
+        wall_m, info_m, _ = run(a.script, a.nx, a.nt + a.marginal, a.mode)
+        res["marginal"] = {"extra_steps": a.marginal, "s_per_step": (wall_m - wall) / a.marginal,
+                           "pt_iters_of_the_extra_steps": info_m.iters[a.nt:]}
     if a.compare_fast:
         wall_f, info_f, fields_f = run(a.script, a.nx, a.nt, "fast")
         vn = np.sqrt(sum(np.sum(fields[n].astype(np.float64) ** 2) for n in ("Vx", "Vy", "Vz")))
@@ -73,6 +80,10 @@ def main():
         res["direct"] = {"wall_s": wall_d, "s_per_step": wall_d / a.nt, "speedup_per_step": wall / wall_d,
                          "err_per_step": [e[-1] for e in info_d.errs], "rel_l2_vs_pt_run": rel,
                          "finite": bool(all(np.isfinite(v).all() for v in fields_d.values()))}
+        if a.marginal > 0:
+            wall_dm, _, _ = run(a.script, a.nx, a.nt + a.marginal, a.mode, pressure="direct")
+            res["direct"]["marginal_s_per_step"] = (wall_dm - wall_d) / a.marginal
+            res["direct"]["marginal_speedup_per_step"] = res["marginal"]["s_per_step"] / res["direct"]["marginal_s_per_step"]
     print(json.dumps(res))
 
 
