@@ -58,6 +58,8 @@ def main():
         ("correct_V", 56, lambda: K.correct_V(Vx, Vy, Vz, Pr, p.dt, p.rho, p.dx, p.dy, p.dz, ctx=ctx)),
         ("set_bc_Pr", 0, lambda: K.set_bc_Pr_multi(Pr, True, 0.0, ctx=ctx)),
         ("set_bc_Vel", 0, lambda: K.set_bc_Vel_multi(Vx, Vy, Vz, True, 1.0, ctx=ctx)),
+        ("set_cylinder", 0, lambda: K.set_cylinder(C, Vx, Vy, Vz, 0.0025, 0.0025, -0.2, 0.0, 0.0, 1.0, -0.5, -0.5, -0.5, 1.0, 1.0, 1.0,
+                                                   p.dx, p.dy, p.dz, ctx=ctx)),
         ("copy", 16, lambda: K.copy(Co, C, ctx=ctx)),
         ("advect", 56, lambda: K.advect(Vx, Vxo, Vy, Vyo, Vz, Vzo, C, Co, p.dt, p.dx, p.dy, p.dz, ctx=ctx)),
         ("advect_fixed", 64, lambda: K.advect(Vx, Vxo, Vy, Vyo, Vz, Vzo, C, Co, p.dt, p.dx, p.dy, p.dz, faithful=False, ctx=ctx)),
