@@ -144,6 +144,7 @@ void ns3d_destroy(ns3d_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     c->clear_graphs();
+    if (c->persist.H) (void)hipFree(c->persist.H);
     if (c->direct_plan && c->direct_free) c->direct_free(c->direct_plan);
     if (c->fence) (void)hipEventDestroy(c->fence);
     for (int q = 0; q < 2; ++q)
@@ -627,7 +628,7 @@ static hipError_t enqueue_iters(ns3d_ctx *c, hipStream_t s, int n, bool two, T *
     hipError_t e = hipSuccess;
     // small grids: the whole block of n iterations in one cooperative launch (k_pt_persist), where it applies
     if (n >= 2 && use_persist<T>(c, p)) {
-        e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_persist<T>(s, src, dst, dsrc, divV, *p, n));
+        e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_persist<T>(s, src, dst, dsrc, divV, *p, n, &c->persist));
         if (e == hipSuccess) {
             T *t = src; src = dst; dst = t;
             return e;
@@ -709,7 +710,7 @@ static bool use_persist(const ns3d_ctx *c, const ns3d_pt_params *p)
         // where it was measured to win (profiles/r3_persist_ab.log): up to ≈170 000 cells, one workgroup across x
         if ((long long)p->nx * p->ny * p->nz > 170ll * 1000 || p->nx > 66) return false;
     }
-    const hipError_t e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_persist<T>(nullptr, nullptr, nullptr, nullptr, nullptr, *p, 2));
+    const hipError_t e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_persist<T>(nullptr, nullptr, nullptr, nullptr, nullptr, *p, 2, nullptr));
     if (e != hipSuccess) (void)hipGetLastError();
     return e == hipSuccess;                                         // the chip holds the whole grid at once
 }

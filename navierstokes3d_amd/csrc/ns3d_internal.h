@@ -42,6 +42,7 @@ struct ns3d_ctx {
         hipGraphExec_t exec;
     };
     std::vector<BlockGraph> graphs;
+    ns3d_persist_state persist;             // k_pt_persist's exchange area
     void *direct_plan = nullptr;            // ns3d_direct.hip: eigenvector matrices and scratch of the direct Poisson solve
     void (*direct_free)(void *) = nullptr;
     void clear_graphs()

@@ -2741,37 +2741,27 @@ __global__ __launch_bounds__(64 * BY * BZ) void k_pt_persist(PersistArgs<T> pa)
     }
 }
 
-struct PersistScratch { int device; hipStream_t stream; void *H; unsigned *err; size_t bytes; unsigned long long launches; };
-static PersistScratch *persist_scratch(hipStream_t s, size_t bytes)
+// the exchange area and the error word live with the caller's context (ns3d_persist_state, freed with it); a launch on another
+// stream than the previous one waits for that one first — two grids must not meet in the same slots
+static hipError_t persist_scratch(ns3d_persist_state *st, hipStream_t s, size_t bytes)
 {
-    static std::vector<PersistScratch> pool;
-    static std::mutex mtx;
-    std::lock_guard<std::mutex> lock(mtx);
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    PersistScratch *c = nullptr;
-    for (auto &q : pool)
-        if (q.device == dev && q.stream == s) c = &q;
-    if (!c) {
-        if (pool.capacity() < 64) pool.reserve(64);
-        if (pool.size() >= 64) return nullptr;
-        pool.push_back({dev, s, nullptr, nullptr, 0, 0ull});
-        c = &pool.back();
+    hipError_t e;
+    if (st->used && st->stream != s && (e = hipStreamSynchronize(st->stream)) != hipSuccess) return e;
+    st->stream = s; st->used = true;
+    if (st->bytes < bytes) {
+        if (st->H) { if ((e = hipStreamSynchronize(s)) != hipSuccess) return e; (void)hipFree(st->H); st->H = nullptr; st->bytes = 0; }
+        if ((e = hipMalloc(&st->H, bytes + 64)) != hipSuccess) return e;
+        if ((e = hipMemset(st->H, 0, bytes + 64)) != hipSuccess) return e;
+        st->err = (unsigned *)((char *)st->H + bytes);
+        st->bytes = bytes;
     }
-    if (c->bytes < bytes) {
-        if (c->H) { (void)hipStreamSynchronize(s); (void)hipFree(c->H); c->H = nullptr; c->bytes = 0; }
-        if (hipMalloc(&c->H, bytes + 64) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        if (hipMemset(c->H, 0, bytes + 64) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        c->err = (unsigned *)((char *)c->H + bytes);
-        c->bytes = bytes;
-    }
-    return c;
+    return hipSuccess;
 }
 
 // n fused PT iterations (Pin, D) → (Pout, D) in one cooperative launch; hipErrorInvalidValue where the form does not apply
 // (z-slab halo planes, more workgroups than the chip holds at once): the caller then takes the launch-per-iteration path
 template <class T, int BY, int BZ>
-static hipError_t pt_persist_shape(hipStream_t s, const SweepArgs<T> &a, int n_iters, bool probe_only)
+static hipError_t pt_persist_shape(hipStream_t s, const SweepArgs<T> &a, int n_iters, ns3d_persist_state *ps)
 {
     constexpr int BX = 64, R = 4, FACE = 2 * BX * BZ + 2 * BX * BY + 2 * BY * BZ;
     const int nbx = (a.nx - 2 + BX - 1) / BX, nby = (a.ny - 2 + BY - 1) / BY, nbz = (a.nz - 2 + BZ - 1) / BZ;
@@ -2783,9 +2773,9 @@ static hipError_t pt_persist_shape(hipStream_t s, const SweepArgs<T> &a, int n_i
         return max(1, min(2, min(n, workgroups_per_cu((const void *)k_pt_persist<T, BY, BZ>, 64 * BY * BZ))));
     }();
     if (blocks > (long)device_cus() * per_cu) return hipErrorInvalidValue;
-    if (probe_only) return hipSuccess;
-    PersistScratch *ps = persist_scratch(s, (size_t)blocks * R * FACE * 2 * sizeof(unsigned long long));
-    if (!ps) return hipErrorOutOfMemory;
+    if (!ps) return hipSuccess;                          // probe: the form applies
+    hipError_t e = persist_scratch(ps, s, (size_t)blocks * R * FACE * 2 * sizeof(unsigned long long));
+    if (e != hipSuccess) return e;
     // NS3D_PERSIST_XCDMAP=1: contiguous runs of blocks per XCD instead of round-robin — measured slower (profiles/r3_persist_ab.log)
     static const bool remap = std::getenv("NS3D_PERSIST_XCDMAP") && *std::getenv("NS3D_PERSIST_XCDMAP") == '1';
     PersistArgs<T> pa;
@@ -2793,7 +2783,7 @@ static hipError_t pt_persist_shape(hipStream_t s, const SweepArgs<T> &a, int n_i
     pa.epoch = (++ps->launches) << 16;
     pa.nbx = nbx; pa.nby = nby; pa.nbz = nbz; pa.n_iters = n_iters; pa.xcds = remap ? 8 : 1;
     void *kargs[] = {(void *)&pa};
-    hipError_t e = hipLaunchCooperativeKernel((const void *)k_pt_persist<T, BY, BZ>, dim3((unsigned)blocks), dim3(BX, BY, BZ), kargs, 0, s);
+    e = hipLaunchCooperativeKernel((const void *)k_pt_persist<T, BY, BZ>, dim3((unsigned)blocks), dim3(BX, BY, BZ), kargs, 0, s);
     if (e != hipSuccess) return e;
     static const bool check = std::getenv("NS3D_COOP_CHECK") && *std::getenv("NS3D_COOP_CHECK") == '1';
     if (check) {
@@ -2806,7 +2796,7 @@ static hipError_t pt_persist_shape(hipStream_t s, const SweepArgs<T> &a, int n_i
 }
 
 template <class T>
-hipError_t pt_persist(hipStream_t s, const T *Pin, T *Pout, T *D, const T *RHS, const ns3d_pt_params &p, int n_iters)
+hipError_t pt_persist(hipStream_t s, const T *Pin, T *Pout, T *D, const T *RHS, const ns3d_pt_params &p, int n_iters, ns3d_persist_state *st)
 {
     if (n_iters < 1 || n_iters > 60000 || p.z_lo_is_halo || p.z_hi_is_halo) return hipErrorInvalidValue;
     SweepArgs<T> a;
@@ -2820,13 +2810,13 @@ hipError_t pt_persist(hipStream_t s, const T *Pin, T *Pout, T *D, const T *RHS, 
     // the iteration is arithmetic on the CUs the grid occupies plus one hand-over: the smallest workgroup the chip still holds
     // all at once spreads the cells over the most CUs.  NS3D_PERSIST_SHAPE=22|42|44 pins a shape (A/B).
     static const int pin = std::getenv("NS3D_PERSIST_SHAPE") ? std::atoi(std::getenv("NS3D_PERSIST_SHAPE")) : 0;
-    const bool probe = Pin == nullptr;                  // no arrays: only say whether the form applies to this grid
-    if (pin == 22) return pt_persist_shape<T, 2, 2>(s, a, n_iters, probe);
-    if (pin == 42) return pt_persist_shape<T, 4, 2>(s, a, n_iters, probe);
-    if (pin == 44) return pt_persist_shape<T, 4, 4>(s, a, n_iters, probe);
-    if (pt_persist_shape<T, 2, 2>(s, a, n_iters, true) == hipSuccess) return pt_persist_shape<T, 2, 2>(s, a, n_iters, probe);
-    if (pt_persist_shape<T, 4, 2>(s, a, n_iters, true) == hipSuccess) return pt_persist_shape<T, 4, 2>(s, a, n_iters, probe);
-    return pt_persist_shape<T, 4, 4>(s, a, n_iters, probe);
+    if (Pin == nullptr) st = nullptr;                    // no arrays: only say whether the form applies to this grid
+    if (pin == 22) return pt_persist_shape<T, 2, 2>(s, a, n_iters, st);
+    if (pin == 42) return pt_persist_shape<T, 4, 2>(s, a, n_iters, st);
+    if (pin == 44) return pt_persist_shape<T, 4, 4>(s, a, n_iters, st);
+    if (pt_persist_shape<T, 2, 2>(s, a, n_iters, nullptr) == hipSuccess) return pt_persist_shape<T, 2, 2>(s, a, n_iters, st);
+    if (pt_persist_shape<T, 4, 2>(s, a, n_iters, nullptr) == hipSuccess) return pt_persist_shape<T, 4, 2>(s, a, n_iters, st);
+    return pt_persist_shape<T, 4, 4>(s, a, n_iters, st);
 }
 
 template <class T>
@@ -3001,7 +2991,7 @@ hipError_t divtest(hipStream_t s, double d, long n, unsigned long long seed, uns
                                   const T *, double, double, double, double, int, int, int, int, int, int);  \
     template hipError_t pt_sweep<T>(hipStream_t, int, const T *, T *, T *, const T *, const ns3d_pt_params &,\
                                     int, int);                                                               \
-    template hipError_t pt_persist<T>(hipStream_t, const T *, T *, T *, const T *, const ns3d_pt_params &, int); \
+    template hipError_t pt_persist<T>(hipStream_t, const T *, T *, T *, const T *, const ns3d_pt_params &, int, ns3d_persist_state *); \
     template hipError_t pt_sweep2<T>(hipStream_t, int, const T *, T *, const T *, T *, const T *,            \
                                      const ns3d_pt_params &, int, int);                                      \
     template hipError_t pt_sweepn<T>(hipStream_t, int, int, const T *, T *, const T *, T *, const T *,       \

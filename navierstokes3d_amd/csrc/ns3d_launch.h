@@ -5,6 +5,16 @@
 
 #include "../../include/ns3d.h"
 
+// k_pt_persist's exchange area (face values handed between workgroups) and error word: owned by a context, freed with it
+struct ns3d_persist_state {
+    void *H = nullptr;
+    unsigned *err = nullptr;
+    size_t bytes = 0;
+    unsigned long long launches = 0;    // key epoch: a launch never accepts a value an earlier one left in a slot
+    hipStream_t stream = nullptr;       // of the latest launch
+    bool used = false;
+};
+
 #define NS3D_LAUNCHER_DECLS(NS)                                                                              \
     namespace NS {                                                                                           \
     template <class T>                                                                                       \
@@ -45,7 +55,8 @@
     hipError_t predict_fused(hipStream_t, T *, T *, T *, const T *, const T *, const T *, double mu, double rho, \
                              double g, double dt, double dx, double dy, double dz, int, int, int);           \
     template <class T>                                                                                       \
-    hipError_t pt_persist(hipStream_t, const T *, T *, T *, const T *, const ns3d_pt_params &, int n_iters);  \
+    hipError_t pt_persist(hipStream_t, const T *, T *, T *, const T *, const ns3d_pt_params &, int n_iters,   \
+                          ns3d_persist_state *);                                                              \
     template <class T>                                                                                       \
     hipError_t pt_sweep2(hipStream_t, int variant, const T *, T *, const T *, T *, const T *,                \
                          const ns3d_pt_params &, int k0, int k1);                                            \

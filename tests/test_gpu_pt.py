@@ -874,3 +874,34 @@ def test_pt_persist_equals_single_sweeps(hip, oracle, grid, dtype):
         torch.cuda.synchronize()
         assert np.array_equal(hip.to_numpy(dP), Pr) and np.array_equal(hip.to_numpy(dD), d)
     on.close(); off.close()
+
+
+def test_pt_persist_scratch_lives_with_the_context(hip):
+    """k_pt_persist's exchange area belongs to the context that launched it: a hundred contexts created and closed in turn (each
+    with a stream of its own) all run it, and a context that changes stream between two blocks still gets the single sweeps' bits."""
+    import torch
+    grid = (40, 24, 24)
+    nx, ny, nz = grid
+    g = geometry(*grid)
+    Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 5)
+    rhs *= 1e-3
+    drhs = hip.from_numpy(rhs)
+    off = hip.Context(0, "strict"); off.set_persist_mode(0); off.set_graph_mode(0)
+    dP, dD = hip.from_numpy(Pr0), hip.from_numpy(d0)
+    hip.pt_iterate(dP, dD, drhs, _params(hip, dP, g, 0, True, 0.25), 12, ctx=off)
+    torch.cuda.synchronize()
+    ref = (hip.to_numpy(dP), hip.to_numpy(dD))
+    for q in range(100):
+        ctx = hip.Context(0, "strict", async_=True); ctx.set_persist_mode(1)
+        dP, dD = hip.from_numpy(Pr0), hip.from_numpy(d0)
+        p = _params(hip, dP, g, 0, True, 0.25)
+        hip.pt_iterate(dP, dD, drhs, p, 5, ctx=ctx)
+        if q % 10 == 0:
+            with torch.cuda.stream(torch.cuda.Stream()):      # the context follows the current stream
+                hip.pt_iterate(dP, dD, drhs, p, 7, ctx=ctx)
+        else:
+            hip.pt_iterate(dP, dD, drhs, p, 7, ctx=ctx)
+        ctx.sync(); torch.cuda.synchronize()
+        assert np.array_equal(hip.to_numpy(dP), ref[0]) and np.array_equal(hip.to_numpy(dD), ref[1]), q
+        ctx.close()
+    off.close()
