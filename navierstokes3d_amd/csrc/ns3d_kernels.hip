@@ -2134,7 +2134,16 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
     const int nb = gridDim.x, b = blockIdx.x;
     const int q = nb >> 3, rem = nb & 7, xcd = b & 7, loc = b >> 3;
     const int tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
+#if defined(NS3D_TILE_ORDER) && NS3D_TILE_ORDER == 1     // A/B: y-neighbouring tiles next to each other in an XCD's range
+    const int ty_t = tile % nty, tx_t = (tile / nty) % ntx, tz_t = tile / (ntx * nty);
+#elif defined(NS3D_TILE_ORDER) && NS3D_TILE_ORDER >= 2   // A/B: strips NS3D_TILE_ORDER tiles wide in x, y-fastest inside a strip
+    const int tz_t = tile / (ntx * nty), t2 = tile % (ntx * nty);
+    const int strip = t2 / (NS3D_TILE_ORDER * nty), ins = t2 % (NS3D_TILE_ORDER * nty);
+    const int sw = min(NS3D_TILE_ORDER, ntx - strip * NS3D_TILE_ORDER);
+    const int tx_t = strip * NS3D_TILE_ORDER + ins % sw, ty_t = ins / sw;
+#else
     const int tx_t = tile % ntx, ty_t = (tile / ntx) % nty, tz_t = tile / (ntx * nty);
+#endif
     const int ox = 1 + tx_t * (TX - OV), oy = 1 + ty_t * (TY - OV);
     const int kb = a.k0 + tz_t * a.kz;
     const int ke = min(kb + a.kz, a.k1);
