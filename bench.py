@@ -214,6 +214,9 @@ def main():
     ap.add_argument("--no-strong", action="store_true",
                     help="N>1: skip the second measurement (the same GLOBAL grid split in z) reported as `strong`")
     ap.add_argument("--cpu-iters", type=int, default=12)
+    ap.add_argument("--no-traffic", action="store_true", default=os.environ.get("NS3D_BENCH_NO_TRAFFIC") == "1",
+                    help="N=1: do not measure roofline.traffic live (two short rocprofv3 --pmc child runs of this command's kernel "
+                         "instance after the timed region); the figure then comes from profiles/pt_sweep_traffic.json")
     ap.add_argument("--transport", default=os.environ.get("NS3D_BENCH_TRANSPORT", "auto"), choices=["auto", "rccl", "host"],
                     help="N>1: rccl = libns3d's RCCL communicator (fails loudly if it cannot come up), host = host-staged "
                          "over gloo, auto = rccl with a collective fall-back to host")
@@ -505,6 +508,68 @@ def run_case(a, world, rank, device, ndev, shared_gpu, p, scaling):
     torch.cuda.empty_cache()
     return res
 
+def measure_traffic(a, r):
+    """HBM bytes per launch of the kernel instance that was just timed, measured on THIS box: two short child runs of this
+    script (same grid, element type, arithmetic mode, pass depth and tile variant; no self-check, no CPU baseline) under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` — separate passes, kernel trace only, the program itself
+    after `--`, as MI355X_MICROARCH.md's HBM section prescribes; FETCH_SIZE doubled (gfx950 tallies 128-B read requests at
+    64 B), both counters in KiB.  One launch = the sweep kernel + the boundary-cell launches that belong to a pass.  Returns
+    (bytes, source) or (None, reason); never raises: the figure is a report, not a reason to lose the bench line."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    if any("ROCPROF" in k or k.startswith("ROCP_") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "already under a profiler"
+    depth = r["depth"]
+    nx, ny, nz = r["local_grid"]
+    args = ["--gpus", "1", "--steps", str(6 * depth), "--warmup", str(depth), "--grid", str(nx), "--grid-nz", str(nz),
+            "--mode", a.mode, "--dtype", a.dtype, "--no-cpu-baseline", "--no-verify", "--no-traffic", "--no-strong"]
+    if depth >= 2:
+        args += ["--depth", str(depth)]
+        args += ["--variant2", str(r["pt2_variant"])] if depth == 2 else ["--variantn", str(r["ptn_variant"])]
+    else:
+        args += ["--no-temporal-blocking", "--variant", str(a.variant)]
+    per = {}
+    work = tempfile.mkdtemp(prefix="ns3d_pmc_")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-f", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__)] + args
+            subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT, timeout=240)
+            acc = {}                                    # kernel name -> {dispatch id: counter value summed over its rows}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") != counter:
+                        continue
+                    k = row["Kernel_Name"].split("(")[0]
+                    dd = acc.setdefault(k, {})
+                    did = row.get("Dispatch_Id", str(len(dd)))
+                    dd[did] = dd.get(did, 0.0) + float(row["Counter_Value"])
+            per[counter] = acc
+        sweeps = {k: v for k, v in per["FETCH_SIZE"].items() if "k_pt_sweep" in k}
+        if not sweeps:
+            return None, "no k_pt_sweep dispatch in the counter files"
+        main = max(sweeps, key=lambda k: len(sweeps[k]))          # the timed instance: by far the most dispatches
+        n = len(sweeps[main])
+        tot = {}
+        for counter in per:
+            t = sum(per[counter].get(main, {}).values())
+            t += sum(sum(v.values()) for k, v in per[counter].items() if "k_pt_faces" in k)
+            tot[counter] = t / n
+        return 2.0 * 1024.0 * tot["FETCH_SIZE"] + 1024.0 * tot["WRITE_SIZE"], \
+            "measured on this box: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE, separate kernel-trace passes, %d launches of %s" % (
+                n, main.replace("void ", ""))
+    except Exception as e:
+        return None, "live measurement failed: %r" % (e,)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
 
 def json_line(a, world, r):
     nx, ny, nz = r["local_grid"]
@@ -515,17 +580,22 @@ def json_line(a, world, r):
     must_move = algorithmic_bytes(nx, ny, nz, itemsize)          # bytes ONE pass has to move, per launch
     physical = must_move / (kern_ms * 1e-3) / 1e9
     effective = r["effective"]                       # 40 B per cell and iteration
-    traffic = None
+    traffic, traffic_source = None, "--no-traffic" if a.no_traffic else "N > 1"
+    if world == 1 and not a.no_traffic:
+        traffic, traffic_source = measure_traffic(a, r)
+        if traffic is None:
+            sys.stderr.write("bench.py: roofline.traffic not measured live (%s); falling back to profiles/\n" % traffic_source)
     tfile = os.path.join(ROOT, "profiles", "pt_sweep_traffic.json")
-    if world == 1 and os.path.exists(tfile):
+    if traffic is None and world == 1 and os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
             key = "%dx%dx%d_%s_%s_x%d" % (nx, ny, nz, a.dtype, a.mode, its_per_launch)
             if its_per_launch >= 2:                         # measured per tile shape (tools/collect_traffic.py)
                 key += "_v%d" % (r["pt2_variant"] if its_per_launch == 2 else r["ptn_variant"])
             traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            traffic_source = "profiles lookup (%s)" % traffic_source if traffic is not None else "none"
         except Exception:
-            traffic = None
+            traffic, traffic_source = None, "none"
     return {
         "metric": "Mcells*PT-iter/s, fused pseudo-transient Poisson iteration, %dx%dx%d per GPU" % (nx, ny, nz),
         "value": r["value"],
@@ -546,7 +616,7 @@ def json_line(a, world, r):
         "roofline": {"bound": "hbm", "achieved": physical, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": physical / HBM_PEAK_GBPS,
                      "definition": "bytes one launch must move (one pass: itemsize*(N+4*N_inner)) / launch time / peak",
-                     "traffic": traffic, "traffic_source": "profiles lookup" if traffic is not None else "none",
+                     "traffic": traffic, "traffic_source": traffic_source,
                      # what the memory system actually delivered: PMC bytes of a launch / launch time (the overlap rows of
                      # neighbouring tiles are read more than once, so this exceeds `achieved`)
                      "hbm_gbps_measured": (traffic / (kern_ms * 1e-3) / 1e9) if traffic is not None else None,

@@ -2,6 +2,7 @@
 # A/B of the pacing hint (k_pt_sweepN built with -DNS3D_PACE=<slack>, tools/ab/build_variant.sh) on ONE box:
 #   gpurun -- 'bash tools/ab/pace_ab.sh "--variantn 2891" "--variantn 2800"'
 # every tools/ab/libns3d_*.so, interleaved, twice per argument set; prints value, ms per pass, verified.
+export NS3D_BENCH_NO_TRAFFIC=1   # these runs are timed or profiled themselves: no nested rocprofv3 --pmc child runs (bench.py --no-traffic)
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out

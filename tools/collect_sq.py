@@ -33,7 +33,7 @@ def main():
         wd = "/tmp/ns3d_sq"
         shutil.rmtree(wd, ignore_errors=True)
         cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + COUNTERS + ["-f", "csv", "-d", wd, "-o", "p", "--", sys.executable,
-               os.path.join(ROOT, "bench.py"), "--steps", str(8 * int(depth)), "--warmup", depth, "--no-cpu-baseline", "--mode", mode,
+               os.path.join(ROOT, "bench.py"), "--steps", str(8 * int(depth)), "--warmup", depth, "--no-cpu-baseline", "--no-traffic", "--mode", mode,
                "--dtype", a.dtype, "--grid", a.grid, "--depth", depth, "--variant2" if depth == "2" else "--variantn", variant]
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
         acc = {}

@@ -48,7 +48,7 @@ def main():
     for mode in a.modes.split(","):
         for run in a.runs.split(","):
             depth, v = run.split(":")
-            args = ["--steps", str(6 * int(depth)), "--warmup", depth, "--no-cpu-baseline", "--grid", str(a.grid), "--mode", mode,
+            args = ["--steps", str(6 * int(depth)), "--warmup", depth, "--no-cpu-baseline", "--no-traffic", "--grid", str(a.grid), "--mode", mode,
                     "--dtype", a.dtype, "--depth", depth, "--variant2" if depth == "2" else "--variantn", v]
             per = {c: one_pass(c, args, "/tmp/ns3d_pmc_%s" % c) for c in ("FETCH_SIZE", "WRITE_SIZE")}
             fetch = write = 0.0
