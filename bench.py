@@ -535,8 +535,9 @@ def measure_traffic(a, r):
     else:
         args += ["--no-temporal-blocking", "--variant", str(a.variant)]
     per = {}
-    work = tempfile.mkdtemp(prefix="ns3d_pmc_")
+    work = None
     try:
+        work = tempfile.mkdtemp(prefix="ns3d_pmc_")
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(work, counter)
             cmd = [exe, "--kernel-trace", "--pmc", counter, "-f", "csv", "-d", d, "-o", "p", "--",
@@ -568,7 +569,8 @@ def measure_traffic(a, r):
     except Exception as e:
         return None, "live measurement failed: %r" % (e,)
     finally:
-        shutil.rmtree(work, ignore_errors=True)
+        if work is not None:
+            shutil.rmtree(work, ignore_errors=True)
 
 
 def json_line(a, world, r):
