@@ -597,7 +597,9 @@ def json_line(a, world, r):
             traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             traffic_source = "profiles lookup (%s)" % traffic_source if traffic is not None else "none"
         except Exception:
-            traffic, traffic_source = None, "none"
+            traffic = None
+    if traffic is None:
+        traffic_source = "none"
     return {
         "metric": "Mcells*PT-iter/s, fused pseudo-transient Poisson iteration, %dx%dx%d per GPU" % (nx, ny, nz),
         "value": r["value"],
