@@ -276,8 +276,11 @@ NS3D_DECL(float, f32)
  * are left untouched; the same rule per dimension for a Cartesian topology, dimensions in the order x, y, z so that edge and
  * corner values arrive in two / three hops.  Column-major xy-planes are contiguous, so a z message is one block as it lies;
  * x and y faces are packed / unpacked by a kernel on both ends.  ns3d_pt_solve_slab runs the loop multi.jl:458-471 on any
- * topology: on z-slabs with the deep-ghost state below (several iterations per pass over memory), on a grid decomposed in x
- * or y with one fused sweep and one halo update per iteration; ns3d_slab_load / _iterate / _store are z-slab only.
+ * topology with deep ghosts — several iterations per pass over memory, one round of exchanges per pass: on z-slabs with the state
+ * below (seam planes first, their exchange behind the interior sweep), on a grid decomposed in x or y with every rank's state in a
+ * box extended by depth−1 ghost cells in each decomposed direction, the ghost layers exchanged dimension by dimension (x / y
+ * layers packed by a kernel); with depth 1 (ns3d_mgpu_set_temporal) or NS3D_CART_DEEP=0 such a grid runs one fused sweep and one
+ * halo update per iteration instead.  ns3d_slab_load / _iterate / _store are z-slab only.
  *
  * An ns3d_mgpu holds `nlocal` of the P ranks: all P in the one-process form (ns3d_mgpu_create; planes move by
  * hipMemcpyPeerAsync over xGMI; a device may appear several times — virtual ranks), exactly one in the one-process-per-GPU

@@ -311,8 +311,9 @@ end
     pt_solve_slab!(Pr, dPrdτ, ∇V, ρ, dt, dτ, damp, dx, dy, dz; …) -> (iters, errs)
 
 The same loop on a rank of the global grid after `init_global_grid` (`ns3d_pt_solve_slab_f64`; `owns_outlet` = the GLOBAL
-x-hi face carries the outlet rule, the library applies it on the ranks that hold it).  On a topology decomposed in x or y: one
-fused sweep and one halo update per iteration.  On z-slabs (`init_global_grid(…; dimx=1, dimy=1)`): two ghost planes per seam, seam planes
+x-hi face carries the outlet rule, the library applies it on the ranks that hold it).  On a topology decomposed in x or y (the
+default of `init_global_grid`): deep ghosts in every decomposed direction, up to four iterations per pass, ghost layers exchanged
+x, y, z in turn.  On z-slabs (`init_global_grid(…; dimx=1, dimy=1)`): two ghost planes per seam, seam planes
 swept first, their RCCL exchange behind the interior sweep, global residual by ncclAllReduce.  Collective over the ranks.
 """
 function pt_solve_slab!(Pr, dPrdτ, ∇V, ρ, dt, dτ, damp, dx, dy, dz; owns_outlet = true, g = 0.0, εit = 1e-3, niter, nchk, ly, psc)

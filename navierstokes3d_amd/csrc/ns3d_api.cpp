@@ -560,6 +560,12 @@ hipError_t ns3d_enqueue_face_copy(ns3d_ctx *c, hipStream_t s, T *A, T *buf, int 
     return DISPATCH(c, face_copy<T>(s, A, buf, sx, sy, sz, dim, idx, unpack));
 }
 template <class T>
+hipError_t ns3d_enqueue_subbox_copy(ns3d_ctx *c, hipStream_t s, T *dst, long dpx, long dpl, const T *src, long spx, long spl, int cx,
+                                    int cy, int cz)
+{
+    return DISPATCH(c, subbox_copy<T>(s, dst, dpx, dpl, src, spx, spl, cx, cy, cz));
+}
+template <class T>
 hipError_t ns3d_enqueue_advect(ns3d_ctx *c, hipStream_t s, T *Vx, const T *Vx_o, T *Vy, const T *Vy_o, T *Vz, const T *Vz_o, T *C,
                                const T *C_o, double dt, double dx, double dy, double dz, int nx, int ny, int nz, int flags, int koff,
                                int nzg)
@@ -580,7 +586,8 @@ hipError_t ns3d_enqueue_advect(ns3d_ctx *c, hipStream_t s, T *Vx, const T *Vx_o,
     template hipError_t ns3d_enqueue_residual_key<T>(ns3d_ctx *, hipStream_t, const T *, const T *,                  \
                                                      const ns3d_pt_params *, unsigned long long *);                 \
     template hipError_t ns3d_enqueue_strip_inner<T>(ns3d_ctx *, hipStream_t, const T *, T *, int, int, int);         \
-    template hipError_t ns3d_enqueue_face_copy<T>(ns3d_ctx *, hipStream_t, T *, T *, int, int, int, int, int, int);
+    template hipError_t ns3d_enqueue_face_copy<T>(ns3d_ctx *, hipStream_t, T *, T *, int, int, int, int, int, int);  \
+    template hipError_t ns3d_enqueue_subbox_copy<T>(ns3d_ctx *, hipStream_t, T *, long, long, const T *, long, long, int, int, int);
 NS3D_INST_INTERNAL(double)
 NS3D_INST_INTERNAL(float)
 #undef NS3D_INST_INTERNAL

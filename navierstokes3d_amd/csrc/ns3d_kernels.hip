@@ -1294,6 +1294,26 @@ hipError_t face_copy(hipStream_t s, T *A, T *buf, int sx, int sy, int sz, int di
     return hipGetLastError();
 }
 
+// A cx·cy·cz block between two column-major arrays of different pitches (row pitch dpx / spx elements, plane pitch dpl / spl);
+// dst and src point at the block's first element.  The deep-ghost state of a Cartesian topology (ns3d_mgpu.cpp, solve_box)
+// moves through it: local array ↔ ghost-extended box, and the G+1 layers next to an x or y seam ↔ a packed message buffer.
+template <class T>
+__global__ __launch_bounds__(256) void k_subbox_copy(T *__restrict__ dst, long dpx, long dpl, const T *__restrict__ src, long spx,
+                                                     long spl, int cx, int cy, int cz)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
+    if (i < cx && j < cy && k < cz) dst[i + j * dpx + k * dpl] = src[i + j * spx + k * spl];
+}
+template <class T>
+hipError_t subbox_copy(hipStream_t s, T *dst, long dpx, long dpl, const T *src, long spx, long spl, int cx, int cy, int cz)
+{
+    if (cx <= 0 || cy <= 0 || cz <= 0) return hipSuccess;
+    if (cz > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_subbox_copy<T>, dim3((unsigned)((cx + 63) / 64), (unsigned)((cy + 3) / 4), (unsigned)cz), dim3(64, 4, 1), 0, s,
+                       dst, dpx, dpl, src, spx, spl, cx, cy, cz);
+    return hipGetLastError();
+}
+
 // =========================================================================================================
 // The fused pseudo-transient sweep  —  THE hot kernel (≥98 % of all bytes moved).
 //
@@ -3009,7 +3029,8 @@ hipError_t divtest(hipStream_t s, double d, long n, unsigned long long seed, uns
                                             unsigned long long *);                                           \
     template hipError_t divtest<T>(hipStream_t, double, long, unsigned long long, unsigned long long *);   \
     template hipError_t strip_inner<T>(hipStream_t, const T *, T *, int, int, int);                          \
-    template hipError_t face_copy<T>(hipStream_t, T *, T *, int, int, int, int, int, int);
+    template hipError_t face_copy<T>(hipStream_t, T *, T *, int, int, int, int, int, int);                  \
+    template hipError_t subbox_copy<T>(hipStream_t, T *, long, long, const T *, long, long, int, int, int);
 INST(double)
 INST(float)
 #undef INST

@@ -72,6 +72,9 @@ struct ns3d_persist_state {
     hipError_t strip_inner(hipStream_t, const T *A, T *out, int sx, int sy, int sz);                         \
     template <class T>                                                                                       \
     hipError_t face_copy(hipStream_t, T *A, T *buf, int sx, int sy, int sz, int dim, int idx, int unpack);   \
+    template <class T>                                                                                       \
+    hipError_t subbox_copy(hipStream_t, T *dst, long dpx, long dpl, const T *src, long spx, long spl, int cx,\
+                           int cy, int cz);                                                                  \
     }
 
 NS3D_LAUNCHER_DECLS(ns3d_strict)

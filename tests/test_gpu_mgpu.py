@@ -261,6 +261,63 @@ def test_pt_solve_on_a_cartesian_topology_equals_global_pt_solve(hip, dims, dtyp
     mg.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("dims,n,depth", [((2, 1, 1), (20, 14, 10), 4), ((1, 2, 1), (20, 14, 10), 3), ((2, 2, 1), (70, 30, 9), 4),
+                                          ((2, 2, 2), (20, 14, 10), 4), ((2, 2, 2), (20, 14, 10), 2), ((3, 1, 2), (12, 9, 7), 4),
+                                          ((2, 3, 1), (9, 6, 8), 4), ((1, 2, 2), (66, 12, 5), 4)])
+def test_deep_ghosts_on_a_cartesian_topology_equal_the_global_pt_solve(hip, dims, n, depth, dtype, monkeypatch):
+    """solve_box (ns3d_mgpu.cpp): the solve state of every rank in a box extended by depth−1 ghost cells in x, y and z, passes of
+    up to `depth` iterations on the whole box, ghost layers exchanged dimension by dimension (x/y layers packed by k_subbox_copy).
+    Same iteration count, error history and fields as ns3d_pt_solve on the global grid, bit for bit — with the planner's pass
+    depth and with every depth forced; a thin dimension (6 cells: four own layers) caps the ghost depth; NS3D_CART_DEEP=0 takes
+    the one-sweep-per-iteration path and gives the same bits."""
+    import torch
+    N = tuple(dims[d] * (n[d] - 2) + 2 for d in range(3))
+    g = geometry(*N)
+    g["dtau"] = 0.8 / np.sqrt(1.0 / g["dx"] ** 2 + 1.0 / g["dy"] ** 2 + 1.0 / g["dz"] ** 2)     # inside the iteration's stability limit
+    Pg, Dg, Rg = fields(*N, ["c", "i", "c"], 17, dtype)
+    Pg *= 1e-3; Dg *= 1e-3; Rg *= 1e-6
+    eps, niter, nchk, mul, div = -1.0, 47, 9, 0.36, 1000.0          # fixed iteration count: blocks of 9 = 4+4+1, 3+3+3, 2+2+2+2+1
+    ctx = hip.Context(0, "strict")
+    dP, dD = hip.from_numpy(Pg), hip.from_numpy(Dg)
+    pg = hip.pt_params(dP, g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, True, 0.25, 0.0)
+    it_ref, errs_ref = hip.pt_solve(dP, dD, hip.from_numpy(Rg), pg, eps, niter, nchk, mul, div, ctx=ctx)
+    torch.cuda.synchronize()
+    Pref, Dref = hip.to_numpy(dP), hip.to_numpy(dD)
+    ctx.close()
+    assert it_ref == niter and len(errs_ref) == niter // nchk and np.all(np.isfinite(errs_ref)) and np.all(np.isfinite(Pref))
+    from navierstokes3d_amd.mgpu import MultiGpu
+    from oracle.driver_ref import cart_coords
+    P = dims[0] * dims[1] * dims[2]
+
+    def cut(A, r, shrink):
+        c = cart_coords(r, dims)
+        return np.asfortranarray(A[tuple(slice(c[d] * (n[d] - 2), c[d] * (n[d] - 2) + n[d] - shrink) for d in range(3))])
+
+    for deep, force in (("1", 0), ("1", 2), ("1", 3), ("1", 4), ("0", 0)):
+        if force > depth:
+            continue
+        monkeypatch.setenv("NS3D_CART_DEEP", deep)
+        mg = MultiGpu.create([0] * P, *n, "strict", dims=dims, own_streams=OWN_STREAMS)
+        mg.set_temporal(depth)
+        for c in mg.contexts:
+            c.set_pt_depth(force)
+        Pr = [hip.from_numpy(cut(Pg, r, 0)) for r in range(P)]
+        D = [hip.from_numpy(cut(Dg, r, 2)) for r in range(P)]
+        R = [hip.from_numpy(cut(Rg, r, 0)) for r in range(P)]
+        p = hip.pt_params(Pr[0], g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, True, 0.25, 0.0)
+        it, errs = mg.pt_solve_slab(Pr, D, R, p, eps, niter, nchk, mul, div)
+        mg.sync()
+        assert it == it_ref and errs == errs_ref, (deep, force)
+        for r in range(P):
+            assert np.array_equal(hip.to_numpy(Pr[r]), cut(Pref, r, 0)), (deep, force, r)
+            assert np.array_equal(hip.to_numpy(D[r]), cut(Dref, r, 2)), (deep, force, r)
+        if deep == "1":
+            cap = min([depth] + [n[d] - 2 for d in range(3) if dims[d] > 1])
+            assert 1 <= mg.pass_depth() <= cap and (force == 0 or mg.pass_depth() == min(force, cap)), (mg.pass_depth(), force, cap)
+        mg.close()
+
+
 @pytest.mark.parametrize("P,fused,temporal", [(2, True, True), (3, True, True), (2, True, False), (2, False, False)])
 def test_driver_on_mgpu_grid_vs_oracle_virtual_ranks(hip, P, fused, temporal):
     """The product driver (multi.jl:287-536) on the C-ABI grid — update_halo!, max_g, gather!, and the inner loop as

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """PT loop of P virtual ranks on ONE GPU through the multi-GPU C ABI, by topology: z-slabs (deep-ghost passes), a Cartesian
-topology fused (one sweep + one halo update per iteration) and the same kernel by kernel (multi.jl:458-471 as written).
+topology with deep ghosts in x, y and z (solve_box: passes of up to four iterations on the extended box), the same topology with
+one sweep + one halo update per iteration (NS3D_CART_DEEP=0) and kernel by kernel (multi.jl:458-471 as written).
 
-    python tools/cart_rates.py [--local 130] [--iters 120]
+    python tools/cart_rates.py [--local 130] [--iters 120] [--dims "1,1,8;2,2,2"]
 
 The ranks share the device, so this prices the schedules (launches, pack/unpack kernels, events, copies), not xGMI.
 """
@@ -25,12 +26,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--local", type=int, default=130)
     ap.add_argument("--iters", type=int, default=120)
+    ap.add_argument("--dims", default="1,1,8;2,2,2")
+    ap.add_argument("--no-reference", action="store_true")
+    ap.add_argument("--depth", type=int, default=0, help="force the iterations per pass (0: the planner's choice)")
     a = ap.parse_args()
     n, its = a.local, a.iters
-    for dims in [(1, 1, 8), (2, 2, 2)]:
+    for dims in [tuple(int(x) for x in t.split(",")) for t in a.dims.split(";")]:
         P = dims[0] * dims[1] * dims[2]
         mg = MultiGpu.create([0] * P, n, n, n, "strict", dims=dims)
         grid = MgpuGrid(mg, n, n, n)
+        for c in mg.contexts:
+            c.set_pt_depth(a.depth)
         d = 1.0 / (dims[0] * (n - 2) + 2)
         fs = []
         for r in range(P):
@@ -44,18 +50,21 @@ def main():
                             eps=-1.0, owns_outlet=False)
         pt = K.pt_params(fs[0].Pr, q.rho, q.dt, q.dtau, q.damp, q.dx, q.dy, q.dz, L.NS3D_BC_MULTI, False, 0.0, 0.0)
         cells = P * n * n * n
-        modes = ["fused"] + (["reference"] if dims != (1, 1, 8) else [])
+        zslabs = dims[0] == 1 and dims[1] == 1
+        modes = ["fused"] if zslabs else ["deep ghosts", "fused"] + ([] if a.no_reference else ["reference"])
         for mode in modes:
+            os.environ["NS3D_CART_DEEP"] = "0" if mode == "fused" and not zslabs else "1"
             for rep in range(2):                                # first pass: plan / warm-up
                 torch.cuda.synchronize(); mg.sync()
                 t0 = time.perf_counter()
-                if mode == "fused":
+                if mode != "reference":
                     mg.pt_solve_slab(col("Pr"), col("dPrdtau"), col("divV"), pt, -1.0, its, 0, 1.0, 1.0)
                 else:
                     pt_loop_reference(mg.contexts, grid, fs, [q] * P, its)
                 mg.sync(); torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
             print(json.dumps({"dims": dims, "local": [n, n, n], "ranks_on_one_gpu": P, "loop": mode, "iters": its,
+                              "pass_depth": mg.pass_depth() if (zslabs or mode == "deep ghosts") else 1,
                               "ms_per_iteration": round(dt / its * 1e3, 4),
                               "Mcells_iter_per_s": round(cells * its / dt / 1e6)}), flush=True)
         mg.close()
