@@ -560,10 +560,9 @@ hipError_t ns3d_enqueue_face_copy(ns3d_ctx *c, hipStream_t s, T *A, T *buf, int 
     return DISPATCH(c, face_copy<T>(s, A, buf, sx, sy, sz, dim, idx, unpack));
 }
 template <class T>
-hipError_t ns3d_enqueue_subbox_copy(ns3d_ctx *c, hipStream_t s, T *dst, long dpx, long dpl, const T *src, long spx, long spl, int cx,
-                                    int cy, int cz)
+hipError_t ns3d_enqueue_subbox_copy(ns3d_ctx *c, hipStream_t s, const ns3d_subbox_batch<T> &batch)
 {
-    return DISPATCH(c, subbox_copy<T>(s, dst, dpx, dpl, src, spx, spl, cx, cy, cz));
+    return DISPATCH(c, subbox_copy<T>(s, batch));
 }
 template <class T>
 hipError_t ns3d_enqueue_advect(ns3d_ctx *c, hipStream_t s, T *Vx, const T *Vx_o, T *Vy, const T *Vy_o, T *Vz, const T *Vz_o, T *C,
@@ -587,7 +586,7 @@ hipError_t ns3d_enqueue_advect(ns3d_ctx *c, hipStream_t s, T *Vx, const T *Vx_o,
                                                      const ns3d_pt_params *, unsigned long long *);                 \
     template hipError_t ns3d_enqueue_strip_inner<T>(ns3d_ctx *, hipStream_t, const T *, T *, int, int, int);         \
     template hipError_t ns3d_enqueue_face_copy<T>(ns3d_ctx *, hipStream_t, T *, T *, int, int, int, int, int, int);  \
-    template hipError_t ns3d_enqueue_subbox_copy<T>(ns3d_ctx *, hipStream_t, T *, long, long, const T *, long, long, int, int, int);
+    template hipError_t ns3d_enqueue_subbox_copy<T>(ns3d_ctx *, hipStream_t, const ns3d_subbox_batch<T> &);
 NS3D_INST_INTERNAL(double)
 NS3D_INST_INTERNAL(float)
 #undef NS3D_INST_INTERNAL

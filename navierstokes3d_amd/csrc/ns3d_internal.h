@@ -134,7 +134,6 @@ hipError_t ns3d_enqueue_advect(ns3d_ctx *c, hipStream_t s, T *Vx, const T *Vx_o,
 // x (dim 0) or y (dim 1) face `idx` of A ↔ packed buffer (update_halo! of a 3-D topology)
 template <class T>
 hipError_t ns3d_enqueue_face_copy(ns3d_ctx *c, hipStream_t s, T *A, T *buf, int sx, int sy, int sz, int dim, int idx, int unpack);
-// a cx·cy·cz block between two column-major arrays (row / plane pitches in elements; dst, src at the block's first element)
+// up to NS3D_SUBBOX_MAX blocks between column-major arrays of different pitches in one launch (ns3d_launch.h: ns3d_subbox_batch)
 template <class T>
-hipError_t ns3d_enqueue_subbox_copy(ns3d_ctx *c, hipStream_t s, T *dst, long dpx, long dpl, const T *src, long spx, long spl, int cx,
-                                    int cy, int cz);
+hipError_t ns3d_enqueue_subbox_copy(ns3d_ctx *c, hipStream_t s, const ns3d_subbox_batch<T> &batch);

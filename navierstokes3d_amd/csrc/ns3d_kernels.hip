@@ -1294,23 +1294,43 @@ hipError_t face_copy(hipStream_t s, T *A, T *buf, int sx, int sy, int sz, int di
     return hipGetLastError();
 }
 
-// A cx·cy·cz block between two column-major arrays of different pitches (row pitch dpx / spx elements, plane pitch dpl / spl);
-// dst and src point at the block's first element.  The deep-ghost state of a Cartesian topology (ns3d_mgpu.cpp, solve_box)
-// moves through it: local array ↔ ghost-extended box, and the G+1 layers next to an x or y seam ↔ a packed message buffer.
+// Up to NS3D_SUBBOX_MAX cx·cy·cz blocks, each between two column-major arrays of different pitches (row pitch dpx / spx elements,
+// plane pitch dpl / spl; dst and src point at a block's first element), in ONE launch.  The deep-ghost state of a Cartesian
+// topology (ns3d_mgpu.cpp, solve_box) moves through it: local arrays ↔ ghost-extended box, and the layers next to an x or y seam
+// of every array and both sides ↔ packed message buffers.  A block's (i, j) plane is flattened over the threads, so that a block
+// four cells wide (x layers) still fills its waves.
 template <class T>
-__global__ __launch_bounds__(256) void k_subbox_copy(T *__restrict__ dst, long dpx, long dpl, const T *__restrict__ src, long spx,
-                                                     long spl, int cx, int cy, int cz)
+__global__ __launch_bounds__(256) void k_subbox_copy(ns3d_subbox_batch<T> b)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
-    if (i < cx && j < cy && k < cz) dst[i + j * dpx + k * dpl] = src[i + j * spx + k * spl];
+    int q = 0;
+    unsigned blk = blockIdx.x;
+#pragma unroll 1
+    while (q + 1 < b.n && blk >= b.p[q].blocks) { blk -= b.p[q].blocks; ++q; }
+    const ns3d_subbox<T> &s = b.p[q];
+    const unsigned per_plane = (unsigned)(((long)s.cx * s.cy + 255) / 256);
+    const int k = (int)(blk / per_plane);
+    const long t = (long)(blk % per_plane) * 256 + threadIdx.x;
+    if (k >= s.cz || t >= (long)s.cx * s.cy) return;
+    const int i = (int)(t % s.cx), j = (int)(t / s.cx);
+    s.dst[i + j * s.dpx + k * s.dpl] = s.src[i + j * s.spx + k * s.spl];
 }
 template <class T>
-hipError_t subbox_copy(hipStream_t s, T *dst, long dpx, long dpl, const T *src, long spx, long spl, int cx, int cy, int cz)
+hipError_t subbox_copy(hipStream_t st, const ns3d_subbox_batch<T> &batch)
 {
-    if (cx <= 0 || cy <= 0 || cz <= 0) return hipSuccess;
-    if (cz > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_subbox_copy<T>, dim3((unsigned)((cx + 63) / 64), (unsigned)((cy + 3) / 4), (unsigned)cz), dim3(64, 4, 1), 0, s,
-                       dst, dpx, dpl, src, spx, spl, cx, cy, cz);
+    ns3d_subbox_batch<T> b = batch;
+    unsigned long total = 0;
+    int m = 0;
+    for (int q = 0; q < b.n; ++q) {
+        ns3d_subbox<T> &s = b.p[q];
+        if (s.cx <= 0 || s.cy <= 0 || s.cz <= 0) continue;
+        s.blocks = (unsigned)((((long)s.cx * s.cy + 255) / 256) * s.cz);
+        total += s.blocks;
+        b.p[m++] = s;
+    }
+    b.n = m;
+    if (m == 0) return hipSuccess;
+    if (total > 0x7fffffffu) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_subbox_copy<T>, dim3((unsigned)total), dim3(256), 0, st, b);
     return hipGetLastError();
 }
 
@@ -3030,7 +3050,7 @@ hipError_t divtest(hipStream_t s, double d, long n, unsigned long long seed, uns
     template hipError_t divtest<T>(hipStream_t, double, long, unsigned long long, unsigned long long *);   \
     template hipError_t strip_inner<T>(hipStream_t, const T *, T *, int, int, int);                          \
     template hipError_t face_copy<T>(hipStream_t, T *, T *, int, int, int, int, int, int);                  \
-    template hipError_t subbox_copy<T>(hipStream_t, T *, long, long, const T *, long, long, int, int, int);
+    template hipError_t subbox_copy<T>(hipStream_t, const ns3d_subbox_batch<T> &);
 INST(double)
 INST(float)
 #undef INST

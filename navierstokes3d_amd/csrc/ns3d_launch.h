@@ -15,6 +15,28 @@ struct ns3d_persist_state {
     bool used = false;
 };
 
+// k_subbox_copy: one cx·cy·cz block between two column-major arrays (pitches in elements), and a batch of them for one launch
+#define NS3D_SUBBOX_MAX 8
+template <class T>
+struct ns3d_subbox {
+    T *dst;
+    const T *src;
+    long dpx, dpl, spx, spl;
+    int cx, cy, cz;
+    unsigned blocks;               // filled by the launcher
+};
+template <class T>
+struct ns3d_subbox_batch {
+    ns3d_subbox<T> p[NS3D_SUBBOX_MAX];
+    int n = 0;
+    bool add(T *dst, long dpx, long dpl, const T *src, long spx, long spl, int cx, int cy, int cz)
+    {
+        if (n >= NS3D_SUBBOX_MAX) return false;
+        p[n++] = {dst, src, dpx, dpl, spx, spl, cx, cy, cz, 0u};
+        return true;
+    }
+};
+
 #define NS3D_LAUNCHER_DECLS(NS)                                                                              \
     namespace NS {                                                                                           \
     template <class T>                                                                                       \
@@ -73,8 +95,7 @@ struct ns3d_persist_state {
     template <class T>                                                                                       \
     hipError_t face_copy(hipStream_t, T *A, T *buf, int sx, int sy, int sz, int dim, int idx, int unpack);   \
     template <class T>                                                                                       \
-    hipError_t subbox_copy(hipStream_t, T *dst, long dpx, long dpl, const T *src, long spx, long spl, int cx,\
-                           int cy, int cz);                                                                  \
+    hipError_t subbox_copy(hipStream_t, const ns3d_subbox_batch<T> &);                                       \
     }
 
 NS3D_LAUNCHER_DECLS(ns3d_strict)

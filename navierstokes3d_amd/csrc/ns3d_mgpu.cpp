@@ -915,6 +915,7 @@ int box_exchange(ns3d_mgpu *m, const std::vector<std::vector<BoxArr>> &arrs)
             const Box<T> b(m, r);
             ns3d_device_guard g(r.device);
             size_t off = 0;
+            ns3d_subbox_batch<T> pack;                  // every array's layers for both neighbours: one launch
             for (const BoxArr &a : arrs[l]) {
                 const int sh = a.dshape ? 2 : 0, L = a.layers;
                 const int s[3] = {b.e[0] - sh, b.e[1] - sh, b.e[2] - sh};
@@ -935,15 +936,16 @@ int box_exchange(ns3d_mgpu *m, const std::vector<std::vector<BoxArr>> &arrs)
                 off += 4 * face * sizeof(T);
                 blocks[l].push_back({b0, b0 + 2 * face, b0 + face, b0 + 3 * face, face * sizeof(T)});
                 pieces[l].push_back({A, px, pl, {c[0], c[1], c[2]}, recv_lo, recv_hi});
-                hipError_t e1 = hipSuccess, e2 = hipSuccess;
+                bool ok = true;
                 if (r.nbr[d][0] >= 0)
-                    e1 = ns3d_enqueue_subbox_copy<T>(r.ctx, compute(r), b0, c[0], (long)c[0] * c[1], A + pitch[d] * send_lo, (long)px,
-                                                     (long)pl, c[0], c[1], c[2]);
+                    ok = ok && pack.add(b0, c[0], (long)c[0] * c[1], A + pitch[d] * send_lo, (long)px, (long)pl, c[0], c[1], c[2]);
                 if (r.nbr[d][1] >= 0)
-                    e2 = ns3d_enqueue_subbox_copy<T>(r.ctx, compute(r), b0 + face, c[0], (long)c[0] * c[1], A + pitch[d] * send_hi,
-                                                     (long)px, (long)pl, c[0], c[1], c[2]);
-                if (e1 != hipSuccess || e2 != hipSuccess)
-                    return fail(NS3D_ERR_HIP, "ghost pack launch: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+                    ok = ok && pack.add(b0 + face, c[0], (long)c[0] * c[1], A + pitch[d] * send_hi, (long)px, (long)pl, c[0], c[1], c[2]);
+                if (!ok) return fail(NS3D_ERR_STATE, "box_exchange: more than %d pieces in one pack", NS3D_SUBBOX_MAX);
+            }
+            if (d < 2) {
+                hipError_t e = ns3d_enqueue_subbox_copy<T>(r.ctx, compute(r), pack);
+                if (e != hipSuccess) return fail(NS3D_ERR_HIP, "ghost pack launch: %s", hipGetErrorString(e));
             }
         }
         int rc = exchange_begin(m, blocks, d);
@@ -953,20 +955,22 @@ int box_exchange(ns3d_mgpu *m, const std::vector<std::vector<BoxArr>> &arrs)
         for (int l = 0; l < n; ++l) {
             MRank &r = m->loc[l];
             ns3d_device_guard g(r.device);
+            ns3d_subbox_batch<T> unpack;
+            bool ok = true;
             for (size_t q = 0; q < pieces[l].size(); ++q) {
                 const Piece &pc = pieces[l][q];
                 const Block &bk = blocks[l][q];
                 const size_t pitch = d == 0 ? 1 : pc.px;
-                hipError_t e1 = hipSuccess, e2 = hipSuccess;
                 if (r.nbr[d][0] >= 0)
-                    e1 = ns3d_enqueue_subbox_copy<T>(r.ctx, compute(r), pc.base + pitch * pc.recv_lo, (long)pc.px, (long)pc.pl,
-                                                     (const T *)bk.recv_lo, pc.c[0], (long)pc.c[0] * pc.c[1], pc.c[0], pc.c[1], pc.c[2]);
+                    ok = ok && unpack.add(pc.base + pitch * pc.recv_lo, (long)pc.px, (long)pc.pl, (const T *)bk.recv_lo, pc.c[0],
+                                          (long)pc.c[0] * pc.c[1], pc.c[0], pc.c[1], pc.c[2]);
                 if (r.nbr[d][1] >= 0)
-                    e2 = ns3d_enqueue_subbox_copy<T>(r.ctx, compute(r), pc.base + pitch * pc.recv_hi, (long)pc.px, (long)pc.pl,
-                                                     (const T *)bk.recv_hi, pc.c[0], (long)pc.c[0] * pc.c[1], pc.c[0], pc.c[1], pc.c[2]);
-                if (e1 != hipSuccess || e2 != hipSuccess)
-                    return fail(NS3D_ERR_HIP, "ghost unpack launch: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+                    ok = ok && unpack.add(pc.base + pitch * pc.recv_hi, (long)pc.px, (long)pc.pl, (const T *)bk.recv_hi, pc.c[0],
+                                          (long)pc.c[0] * pc.c[1], pc.c[0], pc.c[1], pc.c[2]);
             }
+            if (!ok) return fail(NS3D_ERR_STATE, "box_exchange: more than %d pieces in one unpack", NS3D_SUBBOX_MAX);
+            hipError_t e = ns3d_enqueue_subbox_copy<T>(r.ctx, compute(r), unpack);
+            if (e != hipSuccess) return fail(NS3D_ERR_HIP, "ghost unpack launch: %s", hipGetErrorString(e));
         }
     }
     return NS3D_OK;
@@ -1007,11 +1011,12 @@ int box_load(ns3d_mgpu *m, const T *const *Pr, const T *const *D, const T *const
         r.st.ip = r.st.id = 0;
         const size_t op = b.g[0][0] + b.px * b.g[1][0] + b.pl * b.g[2][0], od = b.g[0][0] + b.dpx * b.g[1][0] + b.dpl * b.g[2][0];
         const long nx = b.n[0], ny = b.n[1];
-        hipError_t e1 = ns3d_enqueue_subbox_copy<T>(r.ctx, s, (T *)r.st.P[0] + op, (long)b.px, (long)b.pl, Pr[l], nx, nx * ny, b.n[0], b.n[1], b.n[2]);
-        hipError_t e2 = ns3d_enqueue_subbox_copy<T>(r.ctx, s, (T *)r.st.R + op, (long)b.px, (long)b.pl, divV[l], nx, nx * ny, b.n[0], b.n[1], b.n[2]);
-        hipError_t e3 = ns3d_enqueue_subbox_copy<T>(r.ctx, s, (T *)r.st.D[0] + od, (long)b.dpx, (long)b.dpl, D[l], nx - 2, (nx - 2) * (ny - 2),
-                                                    b.n[0] - 2, b.n[1] - 2, b.n[2] - 2);
-        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(NS3D_ERR_HIP, "box load launch failed");
+        ns3d_subbox_batch<T> in;
+        in.add((T *)r.st.P[0] + op, (long)b.px, (long)b.pl, Pr[l], nx, nx * ny, b.n[0], b.n[1], b.n[2]);
+        in.add((T *)r.st.R + op, (long)b.px, (long)b.pl, divV[l], nx, nx * ny, b.n[0], b.n[1], b.n[2]);
+        in.add((T *)r.st.D[0] + od, (long)b.dpx, (long)b.dpl, D[l], nx - 2, (nx - 2) * (ny - 2), b.n[0] - 2, b.n[1] - 2, b.n[2] - 2);
+        hipError_t e = ns3d_enqueue_subbox_copy<T>(r.ctx, s, in);
+        if (e != hipSuccess) return fail(NS3D_ERR_HIP, "box load launch: %s", hipGetErrorString(e));
         arrs.push_back({{r.st.P[0], false, m->G + 1}, {r.st.D[0], true, m->G}, {r.st.R, false, m->G + 1}});
     }
     return box_exchange<T>(m, arrs);
@@ -1027,11 +1032,11 @@ int box_store(ns3d_mgpu *m, T *const *Pr, T *const *D)
         hipStream_t s = compute(r);
         const size_t op = b.g[0][0] + b.px * b.g[1][0] + b.pl * b.g[2][0], od = b.g[0][0] + b.dpx * b.g[1][0] + b.dpl * b.g[2][0];
         const long nx = b.n[0], ny = b.n[1];
-        hipError_t e1 = ns3d_enqueue_subbox_copy<T>(r.ctx, s, Pr[l], nx, nx * ny, (const T *)r.st.P[r.st.ip] + op, (long)b.px, (long)b.pl,
-                                                    b.n[0], b.n[1], b.n[2]);
-        hipError_t e2 = ns3d_enqueue_subbox_copy<T>(r.ctx, s, D[l], nx - 2, (nx - 2) * (ny - 2), (const T *)r.st.D[r.st.id] + od, (long)b.dpx,
-                                                    (long)b.dpl, b.n[0] - 2, b.n[1] - 2, b.n[2] - 2);
-        if (e1 != hipSuccess || e2 != hipSuccess) return fail(NS3D_ERR_HIP, "box store launch failed");
+        ns3d_subbox_batch<T> out;
+        out.add(Pr[l], nx, nx * ny, (const T *)r.st.P[r.st.ip] + op, (long)b.px, (long)b.pl, b.n[0], b.n[1], b.n[2]);
+        out.add(D[l], nx - 2, (nx - 2) * (ny - 2), (const T *)r.st.D[r.st.id] + od, (long)b.dpx, (long)b.dpl, b.n[0] - 2, b.n[1] - 2, b.n[2] - 2);
+        hipError_t e = ns3d_enqueue_subbox_copy<T>(r.ctx, s, out);
+        if (e != hipSuccess) return fail(NS3D_ERR_HIP, "box store launch: %s", hipGetErrorString(e));
     }
     return NS3D_OK;
 }
