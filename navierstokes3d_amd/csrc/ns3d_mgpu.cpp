@@ -569,15 +569,23 @@ int slab_plan(ns3d_mgpu *m)
             const Ext<T> e(m, r);
             const int np = m->G + 1;
             const int a = has_lower(m, r) ? std::min(e.k0 + np, e.k1) : e.k0, b = has_upper(m, r) ? std::max(e.k1 - np, a) : e.k1;
-            if (b - a < 2) {        // nothing to measure on: two iterations per pass unless the context asks for more
-                depth = std::min(depth, r.ctx->pt_depth >= 2 ? r.ctx->pt_depth : 2);
+            // Between ranks a pass costs its sweeps PLUS an exchange, and the deepest pass the ghosts allow wins on every slab
+            // measured (tools/cart_rates.py, virtual ranks: 8 × 130³ 0.46 / 0.38 / 0.28 ms per iteration with two / three / four per
+            // pass, 2 × 258³ 0.25 / 0.22 / 0.20; 512² planes: DESIGN §6) although the sweep alone prefers two or three on small
+            // planes: with neighbours the tile shapes are measured FOR that depth unless the caller pinned one (ns3d_set_pt_depth).
+            const int pinned = r.ctx->pt_depth;
+            const int want = (pinned <= 0 && m->P > 1) ? m->G + 1 : pinned;
+            if (b - a < 2) {        // nothing to measure on
+                depth = std::min(depth, want >= 2 ? want : 2);
                 continue;
             }
             const ns3d_pt_params pe = ext_params(m, r);
             ns3d_device_guard g(r.device);
             // outputs go to the buffers the next pass overwrites anyway
+            r.ctx->pt_depth = want;
             const int d = ns3d_plan_pt_internal<T>(r.ctx, (const T *)r.st.P[r.st.ip], (T *)r.st.P[r.st.ip ^ 1],
                                                    (const T *)r.st.D[r.st.id], (T *)r.st.D[r.st.id ^ 1], (const T *)r.st.R, &pe, a, b);
+            r.ctx->pt_depth = pinned;
             depth = std::min(depth, std::max(2, d));
         }
     }

@@ -145,8 +145,8 @@ def test_slab_state_equals_global_solve(hip, P, depth, shape, n_iters, dtype):
                                                        (4, (24, 15, 6), 0, 8)])
 def test_ghost_depth_follows_the_planned_pass_depth(hip, P, shape, pass_depth, n_iters):
     """ADVICE r2: the state is loaded with ghosts for the deepest pass allowed (set_temporal(4): three ghost planes per seam);
-    when the ranks then settle for fewer iterations per pass (forced here through the contexts; 0 = whatever the planner says on
-    a grid this small: two) ns3d_slab_plan drops the outer ghost planes — thinner seam sweeps, pass_depth + pass_depth − 1 planes
+    when the ranks then settle for fewer iterations per pass (forced here through the contexts; 0 = the planner: between ranks
+    the deepest pass the ghosts allow) ns3d_slab_plan drops the outer ghost planes — thinner seam sweeps, pass_depth + pass_depth − 1 planes
     per exchange — and the iterates stay those of the single-device solve of the global grid, bit for bit."""
     nx, ny, nz = shape
     nz_g = P * (nz - 2) + 2
@@ -165,7 +165,7 @@ def test_ghost_depth_follows_the_planned_pass_depth(hip, P, shape, pass_depth, n
     mg.slab_load(Pr, D, R, p)
     assert mg.ghost_depth() == min(4, nz - 2) - 1
     planned = mg.slab_plan()
-    assert planned == (pass_depth if pass_depth else 2) and mg.ghost_depth() == planned - 1
+    assert planned == (pass_depth if pass_depth else min(4, nz - 2)) and mg.ghost_depth() == planned - 1
     mg.slab_iterate(n_iters)
     assert mg.slab_plan() == planned and mg.ghost_depth() == planned - 1          # planning again changes nothing
     mg.slab_iterate(1)
