@@ -264,7 +264,8 @@ def test_pt_solve_on_a_cartesian_topology_equals_global_pt_solve(hip, dims, dtyp
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("dims,n,depth", [((2, 1, 1), (20, 14, 10), 4), ((1, 2, 1), (20, 14, 10), 3), ((2, 2, 1), (70, 30, 9), 4),
                                           ((2, 2, 2), (20, 14, 10), 4), ((2, 2, 2), (20, 14, 10), 2), ((3, 1, 2), (12, 9, 7), 4),
-                                          ((2, 3, 1), (9, 6, 8), 4), ((1, 2, 2), (66, 12, 5), 4)])
+                                          ((2, 3, 1), (9, 6, 8), 4), ((1, 2, 2), (66, 12, 5), 4),
+                                          ((2, 2, 1), (130, 70, 34), 4), ((1, 2, 2), (200, 40, 30), 3)])   # several tiles per box
 def test_deep_ghosts_on_a_cartesian_topology_equal_the_global_pt_solve(hip, dims, n, depth, dtype, monkeypatch):
     """solve_box (ns3d_mgpu.cpp): the solve state of every rank in a box extended by depth−1 ghost cells in x, y and z, passes of
     up to `depth` iterations on the whole box, ghost layers exchanged dimension by dimension (x/y layers packed by k_subbox_copy).
