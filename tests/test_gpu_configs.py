@@ -57,6 +57,54 @@ def test_config_D_slabs_equal_global_poisson_solve(hip, P, nz_loc):
     mg.close()
 
 
+@pytest.mark.parametrize("dims,n", [((2, 1, 1), (514, 512, 512)), ((2, 2, 1), (258, 258, 512))])
+def test_default_topologies_of_init_global_grid_at_full_size(hip, dims, n):
+    """What `init_global_grid(nx, ny, nz)` itself picks for 2 and 4 ranks — (2,1,1) and (2,2,1), never z-slabs — at configs[3]'s
+    scale: two ranks of 514×512×512 (global 1026×512×512, 269 M cells) and four of 258×258×512.  ns3d_pt_solve_slab takes the
+    deep-ghost box path there (solve_box: three ghost cells per decomposed direction, four iterations per pass); after 9
+    iterations (4+4+1) with a residual check every 4 the counts, the error history and every local array — halo cells
+    included — equal ns3d_pt_solve on the global grid, compared on the device."""
+    import torch
+    from navierstokes3d_amd.mgpu import MultiGpu
+    from util import geometry
+    N = tuple(dims[d] * (n[d] - 2) + 2 for d in range(3))
+    g = geometry(*N)
+    g["dtau"] = 0.8 / np.sqrt(1.0 / g["dx"] ** 2 + 1.0 / g["dy"] ** 2 + 1.0 / g["dz"] ** 2)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(4242)
+
+    def rnd_dev(*shape):
+        t = hip.zeros(shape, torch.float64)
+        t.permute(2, 1, 0).uniform_(-1.0, 1.0, generator=gen)
+        return t
+
+    Pg, Dg, Rg = rnd_dev(*N), rnd_dev(N[0] - 2, N[1] - 2, N[2] - 2), rnd_dev(*N)
+    P = dims[0] * dims[1] * dims[2]
+
+    def cut(A, r, shrink):
+        c = (r // (dims[1] * dims[2]), (r // dims[2]) % dims[1], r % dims[2])
+        return hip.clone(A[tuple(slice(c[d] * (n[d] - 2), c[d] * (n[d] - 2) + n[d] - shrink) for d in range(3))])
+
+    Pr = [cut(Pg, r, 0) for r in range(P)]
+    D = [cut(Dg, r, 2) for r in range(P)]
+    R = [cut(Rg, r, 0) for r in range(P)]
+    ctx = hip.Context(0, "strict")
+    pg = hip.pt_params(Pg, g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, True, 0.25, 0.0)
+    it_ref, errs_ref = hip.pt_solve(Pg, Dg, Rg, pg, -1.0, 9, 4, 0.36, 1000.0, ctx=ctx)
+    ctx.sync()
+    mg = MultiGpu.create([0] * P, *n, "strict", dims=dims)
+    p = hip.pt_params(Pr[0], g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, True, 0.25, 0.0)
+    it, errs = mg.pt_solve_slab(Pr, D, R, p, -1.0, 9, 4, 0.36, 1000.0)
+    mg.sync()
+    assert mg.pass_depth() == 4 and it == it_ref == 9 and errs == errs_ref and len(errs) == 2
+    for r in range(P):
+        c = (r // (dims[1] * dims[2]), (r // dims[2]) % dims[1], r % dims[2])
+        sl = lambda shrink: tuple(slice(c[d] * (n[d] - 2), c[d] * (n[d] - 2) + n[d] - shrink) for d in range(3))
+        assert torch.equal(Pr[r].view(torch.int64), Pg[sl(0)].view(torch.int64)), "Pr of rank %d" % r
+        assert torch.equal(D[r].view(torch.int64), Dg[sl(2)].view(torch.int64)), "dPrdτ of rank %d" % r
+    ctx.close()
+    mg.close()
+
+
 def test_config_D_cylinder_chorin_steps_on_two_slabs(hip):
     """configs[3] as what it says — flow around the cylinder, full Chorin steps, 512×512×1024 global on two z-slabs — through
     the explicit-shape entry of the driver (shape=…: multi.jl hard-codes ny = nz = ceil(0.6 nx)).  Two time steps (the first
