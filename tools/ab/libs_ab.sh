@@ -1,7 +1,8 @@
 #!/bin/bash
-# A/B of the pacing hint (k_pt_sweepN built with -DNS3D_PACE=<slack>, tools/ab/build_variant.sh) on ONE box:
-#   gpurun -- 'bash tools/ab/pace_ab.sh "--variantn 2891" "--variantn 2800"'
+# A/B of library builds (tools/ab/build_variant.sh NAME "-D…") on ONE box, several bench argument sets per call:
+#   gpurun -- 'bash tools/ab/libs_ab.sh "--depth 4 --variantn 2891" "--depth 4 --variantn 2800" "--dtype f32"'
 # every tools/ab/libns3d_*.so, interleaved, twice per argument set; prints value, ms per pass, verified.
+# (profiles/r3_pace_order_ab.log: pacing hint, tile order, halo-ring duties, compiler scheduling strategies)
 export NS3D_BENCH_NO_TRAFFIC=1   # these runs are timed or profiled themselves: no nested rocprofv3 --pmc child runs (bench.py --no-traffic)
 set -e
 cd $GRAFT_REPO_ROOT
