@@ -204,7 +204,7 @@ def main():
     ap.add_argument("--variant2", type=int, default=None, help="tile shape of the two-iteration sweep")
     ap.add_argument("--no-temporal-blocking", action="store_true")
     ap.add_argument("--depth", type=int, default=int(os.environ.get("NS3D_BENCH_DEPTH", "0")),
-                    help="PT iterations per pass over memory: 0 = what the plan phase measures as fastest (2, 3 or 4), 2…4 forced")
+                    help="PT iterations per pass over memory: 0 = what the plan phase measures as fastest (2, 3 or 4; 5 with --dtype f32), 2…5 forced")
     ap.add_argument("--variantn", type=int, default=None, help="tile shape of the N-iteration sweep")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: n x n x nz per GPU (the reference's model); strong: n x n x nz is the GLOBAL grid, split in z")

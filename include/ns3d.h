@@ -95,7 +95,8 @@ int ns3d_set_pt2_variant(ns3d_ctx *ctx, int variant);
  * before level 1 / between the levels); 24: fp32 only, 64×32 with 1024 threads.  kz as above (0: chosen per launch).  0 = built-in.
  * A shape that cannot hold `nlev` levels (tile too small, LDS) or does not exist for the element type makes the call fail. */
 int ns3d_set_ptn_variant(ns3d_ctx *ctx, int variant);
-/* PT iterations per pass over memory in ns3d_pt_iterate / ns3d_pt_solve: 0 = automatic, 1…4 forced (same results). */
+/* PT iterations per pass over memory in ns3d_pt_iterate / ns3d_pt_solve: 0 = automatic, 1…4 forced (same results); 5 is
+ * available with float32 fields only (k_pt_sweepN has registers for a fifth level there and nowhere else). */
 int ns3d_set_pt_depth(ns3d_ctx *ctx, int depth);
 int ns3d_set_autotune(ns3d_ctx *ctx, int on);
 int ns3d_last_pt2_variant(const ns3d_ctx *ctx);
@@ -232,7 +233,7 @@ typedef struct ns3d_pt_params {
      * z-slab ranks run it on buffers extended by a second ghost plane per seam. */              \
     int ns3d_pt_sweep2_##S(ns3d_ctx *, const T *Pr_in, T *Pr_out, const T *dPrdtau_in, T *dPrdtau_out,       \
                            const T *divV, const ns3d_pt_params *p, int k0, int k1);                          \
-    /* nlev (2…4) fused PT iterations in one pass over memory, otherwise as ns3d_pt_sweep2: results identical to nlev   \
+    /* nlev (2…4; 5 in the _f32 form) fused PT iterations in one pass over memory, otherwise as ns3d_pt_sweep2: results identical to nlev   \
      * ns3d_pt_sweep calls, output planes k0 ≤ k < k1 (reads planes k0-nlev … k1+nlev-1 of Pr_in, clamped to the grid). */ \
     int ns3d_pt_sweepn_##S(ns3d_ctx *, int nlev, const T *Pr_in, T *Pr_out, const T *dPrdtau_in, T *dPrdtau_out,  \
                            const T *divV, const ns3d_pt_params *p, int k0, int k1);                          \

@@ -226,7 +226,7 @@ int ns3d_set_ptn_variant(ns3d_ctx *c, int v)
 int ns3d_set_pt_depth(ns3d_ctx *c, int depth)
 {
     if (!c) return fail(NS3D_ERR_ARG, "ns3d_set_pt_depth: null context");
-    if (depth < 0 || depth > 4) return fail(NS3D_ERR_ARG, "ns3d_set_pt_depth: depth %d (0 = automatic, 1…4)", depth);
+    if (depth < 0 || depth > 5) return fail(NS3D_ERR_ARG, "ns3d_set_pt_depth: depth %d (0 = automatic, 1…4; 5: float32 fields only)", depth);
     c->pt_depth = depth;
     return NS3D_OK;
 }
@@ -330,6 +330,7 @@ template <class T>
 static Plan lookup_plan(const ns3d_ctx *c, int mode, const ns3d_pt_params *p, int k0, int k1)
 {
     Plan pl{c->pt_depth > 0 ? c->pt_depth : 2, c->pt2_variant > 0 ? c->pt2_variant : 0, c->ptn_variant, true};
+    if (sizeof(T) == 8 && pl.depth > 4) pl.depth = 4;       // the fifth level exists for float32 fields only
     const int nk = k1 - k0;
     const long long cells = (long long)p->nx * p->ny * nk;
     if (!c->autotune || cells < NS3D_TWO_MIN_CELLS) return pl;
@@ -463,9 +464,21 @@ static Plan tune_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
                     pl.vn = best4v;
                 }
             }
+            // a fifth level: fp32 only, on the 1024-thread shape (registers to spare there and nowhere else): +6 % at 512³, +9.5 % at
+            // 1024³ per iteration
+            if (sizeof(T) == 4 && pl.depth == 4 && nk >= 24 && (c->ptn_variant <= 0 || c->ptn_variant / 100 == 24)) {
+                const int v5 = c->ptn_variant > 0 ? c->ptn_variant : 2400;
+                float a4 = 0.f, b5 = 0.f;
+                if (time_launch(5, v5, ms) && ms / 5.f < 0.99f * best4 / 4.f && time_launch(4, pl.vn, a4, 6) && time_launch(5, v5, b5, 6) &&
+                    b5 / 5.f < 0.98f * a4 / 4.f) {
+                    pl.depth = 5;
+                    pl.vn = v5;
+                }
+            }
         }
     } else if (c->pt_depth >= 3 && c->ptn_variant <= 0 && cells >= NS3D_TWO_MIN_CELLS) {
-        static const int cand[] = {1100, 2300, 2391, 2800, 2891, 100, 1600, 600, 2200, 1132};
+        // (24xx: float32 only, 28xx / 23xx with 768 threads: both element types; a shape that cannot run the depth is skipped)
+        static const int cand[] = {1100, 2400, 2491, 2300, 2391, 2800, 2891, 100, 1600, 600, 2200, 1132};
         float bestd = 0.f, ms = 0.f;
         for (int v : cand) {
             if (!time_launch(c->pt_depth, v, ms)) continue;
@@ -486,7 +499,7 @@ static Plan pick_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
     if (!pl.known && may_tune) pl = tune_plan<T>(c, s, mode, src, dst, dsrc, ddst, divV, p, k0, k1);
     return pl;
 }
-// one pass of `depth` (2…4) PT iterations
+// one pass of `depth` (2…4, fp32: 5) PT iterations
 template <class T>
 static hipError_t launch_pass(ns3d_ctx *c, hipStream_t s, int depth, const Plan &pl, const T *src, T *dst, const T *dsrc, T *ddst,
                               const T *divV, const ns3d_pt_params *p, int k0, int k1)
@@ -505,7 +518,7 @@ static int next_depth(const Plan &pl, bool blocked, int rem)
 {
     if (!blocked || rem < 2) return 1;
     if (rem >= pl.depth) return (rem == pl.depth + 1 && pl.depth >= 3) ? pl.depth - 1 : pl.depth;   // 4 = 2+2, not 3+1
-    return rem >= 3 ? 3 : 2;
+    return rem;                                             // 2 … depth−1 left: one pass of exactly that many
 }
 template <class T>
 static hipError_t launch_pt2(ns3d_ctx *c, hipStream_t s, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV,
@@ -1010,7 +1023,8 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
         CHECK_CTX(c); CHECK_PTRS(Pr_in, Pr_out, dPrdtau, dPrdtau_out, divV);                                 \
         int rc = ns3d_check_pt_params(p, "ns3d_pt_sweepn");                                                  \
         if (rc) return rc;                                                                                   \
-        if (nlev < 2 || nlev > 4) return fail(NS3D_ERR_ARG, "ns3d_pt_sweepn: %d levels (2…4)", nlev);        \
+        if (nlev < 2 || nlev > (sizeof(T) == 4 ? 5 : 4))                                                     \
+            return fail(NS3D_ERR_ARG, "ns3d_pt_sweepn: %d levels (2…4; 5 with float32 fields)", nlev);       \
         if (Pr_in == Pr_out || dPrdtau == dPrdtau_out)                                                       \
             return fail(NS3D_ERR_ARG, "ns3d_pt_sweepn: input and output buffers must differ");               \
         if (p->z_lo_is_halo || p->z_hi_is_halo)                                                              \

@@ -2139,7 +2139,7 @@ static hipError_t launch_sweep2(hipStream_t s, SweepArgs<T> &a, int kz)
 }
 
 // =========================================================================================================
-// NL PT iterations per pass over memory  —  k_pt_sweepN  (NL = 3, 4; NL = 2 is kept for cross-checks against k_pt_sweep2)
+// NL PT iterations per pass over memory  —  k_pt_sweepN  (NL = 3, 4, in fp32 also 5; NL = 2 is kept for cross-checks against k_pt_sweep2)
 //
 // A two-iteration pass already sits at the HBM ceiling of its 3-read/2-write traffic mix: the only way
 // up is fewer bytes per ITERATION.  NL chained Jacobi sweeps
@@ -2159,7 +2159,7 @@ static hipError_t launch_sweep2(hipStream_t s, SweepArgs<T> &a, int kz)
 template <class T, int NL, int WX, int WY, int CPT, int PF, int MINW = 1>
 __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a, int ntx, int nty)
 {
-    static_assert(NL >= 2 && NL <= 4, "levels");
+    static_assert(NL >= 2 && NL <= 5, "levels");
     static_assert(PF == 0 || PF == 1, "PF");
     constexpr bool EARLY = PF == 1;
     constexpr int TX = 64 * WX, TY = CPT * WY, PX = TX + 2, OV = 2 * (NL - 1);
@@ -2563,7 +2563,7 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
     // built-in: 64×32 columns, next step's loads issued before level 1 (measured best at 512³ for three levels); four levels
     // want three or four waves per SIMD: 64×24 columns with 768 threads in fp64 (loads between the levels: measured best once the
     // steps were written out), 64×32 with 1024 threads in fp32
-    if (variant == 0) { shape = nlev == 4 ? (sizeof(T) == 8 ? 28 : 24) : 11; kz = 0; }
+    if (variant == 0) { shape = nlev >= 4 ? (sizeof(T) == 8 ? 28 : 24) : 11; kz = 0; }
 #define NS3D_SWN(NLV, WXV, WYV, CPTV, PFV) return launch_sweepN<T, NLV, WXV, WYV, CPTV, PFV>(s, a, kz)
 #define NS3D_SWN_SHAPES(NLV)                                                                                \
     switch (shape) {                                                                                        \
@@ -2583,6 +2583,13 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
     case 2: NS3D_SWN_SHAPES(2)
     case 3: NS3D_SWN_SHAPES(3)
     case 4: NS3D_SWN_SHAPES(4)
+    case 5:     // a fifth level only where registers are left: fp32 on 1024-thread workgroups (128 registers, four waves per SIMD).
+                // 512³ fp32: 0.918 ms per pass against 0.778 for four = +6 % per iteration, 1024³ +9.5 %; fp64 spills (57 registers:
+                // 3.2–3.7 ms per pass against 1.39), six levels in fp32 too (44: 1.89 ms) — profiles/r3_pace_order_ab.log
+        if constexpr (sizeof(T) == 4) {
+            if (shape == 24) NS3D_SWN(5, 1, 16, 2, true);
+        }
+        return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
     }
 #undef NS3D_SWN_SHAPES

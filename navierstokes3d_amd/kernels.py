@@ -138,7 +138,7 @@ class Context:
         L.check(self.lib.ns3d_set_ptn_variant(self.handle, int(v)))
 
     def set_pt_depth(self, depth):
-        """PT iterations per pass over memory in pt_iterate / pt_solve: 0 automatic, 1…4 forced."""
+        """PT iterations per pass over memory in pt_iterate / pt_solve: 0 automatic, 1…4 forced (5: float32 fields only)."""
         L.check(self.lib.ns3d_set_pt_depth(self.handle, int(depth)))
 
     def selftest_exact_div(self, d, n=1 << 24, seed=1, dtype=torch.float64):
@@ -426,7 +426,7 @@ def pt_sweep2(Pr_in, Pr_out, dPrdtau_in, dPrdtau_out, divV, p, k0=None, k1=None,
 
 
 def pt_sweepn(nlev, Pr_in, Pr_out, dPrdtau_in, dPrdtau_out, divV, p, k0=None, k1=None, ctx=None):
-    """nlev (2…4) fused PT iterations (Pr_in, dPrdtau_in) → (Pr_out, dPrdtau_out) in one pass over memory (same result as
+    """nlev (2…4; float32 also 5) fused PT iterations (Pr_in, dPrdtau_in) → (Pr_out, dPrdtau_out) in one pass over memory (same result as
     nlev pt_sweep calls); all four buffers distinct."""
     nx, ny, nz = Pr_in.shape
     _ctx(ctx, Pr_in).call("pt_sweepn", Pr_in, int(nlev), _chk(Pr_in, None, "Pr_in"), _chk(Pr_out, (nx, ny, nz), "Pr_out"),

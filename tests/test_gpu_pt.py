@@ -468,6 +468,95 @@ def test_pt_sweepn_tile_edge_sizes(hip, oracle, grid, nlev):
     ctx.close()
 
 
+@pytest.mark.parametrize("bc", [(0, True, 0.0), (0, False, 0.0), (0, True, 0.75), (1, False, 0.0)])
+@pytest.mark.parametrize("grid", [(24, 15, 15), (70, 6, 13), (63, 38, 38), (260, 19, 12), (131, 40, 11), (66, 70, 12), (57, 25, 9), (58, 26, 10)])
+def test_pt_sweepn_five_levels_f32(hip, oracle, grid, bc):
+    """A FIFTH level exists where k_pt_sweepN has registers left: float32 on the 1024-thread 64×32 shape (variants 24xx; tiles
+    overlap by 8 columns / rows / planes).  One launch == five reference iterations bit for bit — whole grids and plane
+    sub-ranges, grids straddling the tile strides (56 columns, 24 rows), both boundary sets, STRICT; FAST within tolerance;
+    float64 fields and shapes without room refuse."""
+    import torch
+    from navierstokes3d_amd import lib as L
+    nx, ny, nz = grid
+    bc_kind, owns, val = bc
+    g = geometry(nx, ny, nz)
+    P0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 1234, np.float32)
+    Pr, d = P0.copy(order="F"), d0.copy(order="F")
+    _oracle_iters(oracle, Pr, d, rhs, g, 5, bc_kind, owns, val)
+    for mode, cmp in (("strict", np.array_equal), ("fast", lambda a, b: rel_l2(a, b) < 1e-5)):
+        ctx = hip.Context(0, mode)
+        p = _params(hip, hip.from_numpy(P0), g, bc_kind, owns, val)
+        for v in (0, 2400, 2405, 2491):
+            ctx.set_ptn_variant(v)
+            for k0, k1 in ((None, None), (1, 4), (nz - 5, nz - 1), (3, nz - 3)):
+                if k0 is not None and k1 <= k0:
+                    continue
+                dP, dout, dd = hip.from_numpy(P0), hip.from_numpy(np.full_like(P0, 555.0)), hip.from_numpy(d0)
+                ddout = hip.from_numpy(np.full_like(d0, 444.0))
+                hip.pt_sweepn(5, dP, dout, dd, ddout, hip.from_numpy(rhs), p, k0, k1, ctx=ctx)
+                torch.cuda.synchronize()
+                gP, gd = hip.to_numpy(dout), hip.to_numpy(ddout)
+                a, b = (1, nz - 1) if k0 is None else (k0, k1)
+                assert cmp(gd[:, :, a - 1:b - 1], d[:, :, a - 1:b - 1]) and cmp(gP[:, :, a:b], Pr[:, :, a:b]), (mode, v, k0, k1)
+                if k0 is None:
+                    assert cmp(gP, Pr)
+                else:
+                    assert (gP[:, :, b + 1:] == 555.0).all() and (gd[:, :, b:] == 444.0).all()
+        if mode == "strict":
+            ctx.set_ptn_variant(2800)                                  # a shape without room for five levels
+            with pytest.raises(L.Ns3dError, match="cannot run"):
+                hip.pt_sweepn(5, hip.from_numpy(P0), hip.from_numpy(P0), hip.from_numpy(d0), hip.from_numpy(d0), hip.from_numpy(rhs), p, ctx=ctx)
+            P64 = P0.astype(np.float64)
+            with pytest.raises(L.Ns3dError, match="levels"):
+                q = _params(hip, hip.from_numpy(P64), g, bc_kind, owns, val)
+                hip.pt_sweepn(5, hip.from_numpy(P64), hip.from_numpy(P64.copy(order="F")), hip.from_numpy(d0.astype(np.float64)),
+                              hip.from_numpy(d0.astype(np.float64)), hip.from_numpy(rhs.astype(np.float64)), q, ctx=ctx)
+        ctx.close()
+
+
+@pytest.mark.parametrize("grid,n_iters", [((70, 21, 23), 13), ((63, 38, 38), 16), ((131, 40, 30), 11)])
+def test_pt_iterate_and_solve_with_five_per_pass_f32(hip, oracle, grid, n_iters):
+    """ns3d_set_pt_depth(5) on float32 fields: pt_iterate / pt_solve schedule passes of five (13 = 5+5+3, 16 = 5+5+4+2, 11 = 5+4+2)
+    and give the oracle's iterates, counts and error history; a float64 context with the same setting runs four per pass."""
+    import torch
+    nx, ny, nz = grid
+    g = geometry(nx, ny, nz)
+    P0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 777, np.float32)
+    rhs *= np.float32(1e-3)
+    Pr, d = P0.copy(order="F"), d0.copy(order="F")
+    _oracle_iters(oracle, Pr, d, rhs, g, n_iters, 0, True, 0.25)
+    ctx = hip.Context(0, "strict")
+    ctx.set_pt_depth(5)
+    dP, dd = hip.from_numpy(P0), hip.from_numpy(d0)
+    p = _params(hip, dP, g, 0, True, 0.25)
+    hip.pt_iterate(dP, dd, hip.from_numpy(rhs), p, n_iters, ctx=ctx)
+    torch.cuda.synchronize()
+    assert ctx.last_pt_depth() in (2, 3, 4, 5)
+    assert np.array_equal(hip.to_numpy(dP), Pr) and np.array_equal(hip.to_numpy(dd), d)
+    Rp = np.zeros((nx - 2, ny - 2, nz - 2), dtype=np.float32, order="F")
+    Pr, d = P0.copy(order="F"), d0.copy(order="F")
+    it_ref, errs_ref = oracle.pt_solve(Pr, d, rhs, Rp, g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, True,
+                                       0.25, g["g"], -1.0, 3 * n_iters, n_iters, 0.36, 1000.0)
+    dP, dd = hip.from_numpy(P0), hip.from_numpy(d0)
+    it, errs = hip.pt_solve(dP, dd, hip.from_numpy(rhs), p, -1.0, 3 * n_iters, n_iters, 0.36, 1000.0, ctx=ctx)
+    torch.cuda.synchronize()
+    assert it == it_ref and errs == errs_ref
+    assert np.array_equal(hip.to_numpy(dP), Pr) and np.array_equal(hip.to_numpy(dd), d)
+    ctx.close()
+    # float64: the setting is accepted and clamps to four per pass
+    P64, d64, r64 = fields(nx, ny, nz, ["c", "i", "c"], 778)
+    Pr, d = P64.copy(order="F"), d64.copy(order="F")
+    _oracle_iters(oracle, Pr, d, r64, g, n_iters, 0, True, 0.25)
+    ctx = hip.Context(0, "strict")
+    ctx.set_pt_depth(5)
+    dP, dd = hip.from_numpy(P64), hip.from_numpy(d64)
+    hip.pt_iterate(dP, dd, hip.from_numpy(r64), _params(hip, dP, g, 0, True, 0.25), n_iters, ctx=ctx)
+    torch.cuda.synchronize()
+    assert ctx.last_pt_depth() <= 4
+    assert np.array_equal(hip.to_numpy(dP), Pr) and np.array_equal(hip.to_numpy(dd), d)
+    ctx.close()
+
+
 @pytest.mark.parametrize("nlev", [3, 4])
 def test_pt_sweepn_plane_ranges_f32_fast_and_extremes(hip, oracle, nlev):
     """(a) output plane sub-ranges [k0,k1) — what a z-slab rank's seam / interior launches use; (b) float32; (c) FAST mode
@@ -711,7 +800,7 @@ def test_planned_passes_on_odd_large_grids(hip, grid, dtype):
         hip.pt_sweep(Pb, Pc, Db, R, p, 1, nz - 1, ctx=ctx)
         Pb, Pc = Pc, Pb
     torch.cuda.synchronize()
-    assert depth in (2, 3, 4)
+    assert depth in ((2, 3, 4) if dtype == "f64" else (2, 3, 4, 5))
     assert torch.equal(Pa.view(bits), Pb.view(bits)) and torch.equal(Da.view(bits), Db.view(bits)), (grid, dtype, depth)
     ctx.close()
 
@@ -763,6 +852,23 @@ def _timed_instance_properties(hip, oracle, n, dtype):
         assert ctx.last_ptn_variant() == v
         assert torch.equal(Pa.view(bits), Pb.view(bits)), "Pr differs after a four-iteration pass, variant %d, %r" % (v, n)
         assert torch.equal(Da.view(bits), Db.view(bits)), "dPrdτ differs after a four-iteration pass, variant %d, %r" % (v, n)
+    if dtype == "f32":      # the fifth level (fp32 only, 1024-thread shape): what the planner times against four — and takes on large grids
+        Pc = zeros((nx, ny, nz))
+        ctx.set_pt_variant(100)
+        P5, D5 = hip.clone(Pb), hip.clone(Db)
+        hip.pt_sweep(P5, Pc, D5, R, p, 1, nz - 1, ctx=ctx)          # fifth single sweep: Pc, D5
+        ctx.set_pt_variant(0)
+        for v in sorted({planned if planned // 100 == 24 else 2400, 2400, 2491}):
+            ctx.set_ptn_variant(v)
+            Pa.zero_(); Da.zero_()
+            hip.pt_sweepn(5, P0, Pa, D0, Da, R, p, ctx=ctx)
+            torch.cuda.synchronize()
+            assert torch.equal(Pa.view(bits), Pc.view(bits)) and torch.equal(Da.view(bits), D5.view(bits)), "five-iteration pass, variant %d, %r" % (v, n)
+        del Pc, P5, D5
+        ctx.set_ptn_variant(planned if planned > 0 else 2400)
+        Pa.zero_(); Da.zero_()
+        hip.pt_sweepn(4, P0, Pa, D0, Da, R, p, ctx=ctx)
+        torch.cuda.synchronize()
     # (b) the oracle on planes [a, b): four iterations are exact on [a+4, b−4)
     mid = nz // 2
     a, b = mid - 16, mid + 14
