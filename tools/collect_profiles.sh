@@ -12,6 +12,7 @@ b() { name=$1; shift; python3 bench.py "$@" > $O/${TAG}_bench_$name.json 2> $O/$
 NS3D_BENCH_NO_TRAFFIC=0 b strict                       # the headline line measures roofline.traffic live
 NS3D_BENCH_NO_TRAFFIC=0 b fast --mode fast --no-cpu-baseline
 NS3D_BENCH_NO_TRAFFIC=0 b f32_strict --dtype f32 --no-cpu-baseline
+b f32_fast --dtype f32 --mode fast --no-cpu-baseline
 b strict_depth2 --depth 2 --no-cpu-baseline
 b strict_depth3 --depth 3 --no-cpu-baseline
 b 1024cubed_strict --grid 1024 --steps 60 --warmup 6 --no-cpu-baseline
@@ -31,7 +32,7 @@ rm -rf /tmp/ns3d_kt; rocprofv3 --kernel-trace --stats -f csv -d /tmp/ns3d_kt -o 
 f=$(find /tmp/ns3d_kt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/${TAG}_kernel_stats_f32_512.csv
 python3 tools/collect_sq.py --out $O/${TAG}_pmc_sq_512.json --runs 4:2891,4:2300,3:1100,2:1392 --modes strict,fast 2>&1 | tail -4
 python3 tools/collect_traffic.py --out $O/${TAG}_traffic_512.json --runs 4:2300,4:2391,4:2800,4:2891,3:1100,2:1392 --modes strict,fast 2>&1 | tail -4
-python3 tools/collect_traffic.py --out $O/${TAG}_traffic_512_f32.json --runs 4:2400,4:2200,3:100,2:1100 --modes strict --dtype f32 2>&1 | tail -3
+python3 tools/collect_traffic.py --out $O/${TAG}_traffic_512_f32.json --runs 5:2400,4:2400,4:2200,3:100,2:1100 --modes strict --dtype f32 2>&1 | tail -3
 python3 tools/kernel_rates.py > $O/${TAG}_kernel_rates_512.jsonl 2>/dev/null; grep -c kernel $O/${TAG}_kernel_rates_512.jsonl
 python3 tools/run_config.py --script multi --nx 63 --nt 20 > $O/${TAG}_config_a_63x38x38.json 2>/dev/null; tail -c 300 $O/${TAG}_config_a_63x38x38.json; echo
 python3 tools/run_config.py --script multi --nx 255 --nt 3 --marginal 5 --compare-fast --compare-direct > $O/${TAG}_config_b_multi_255x153x153.json 2>/dev/null; tail -c 300 $O/${TAG}_config_b_multi_255x153x153.json; echo
