@@ -41,6 +41,9 @@ typedef long long idx_t;
 #ifndef NS3D_STEP_UNROLL
 #define NS3D_STEP_UNROLL 0      // 0: chosen per tile shape (k_pt_sweepN); 1, 2, 4: forced, for A/B builds
 #endif
+#ifndef NS3D_SHAPE24_F64
+#define NS3D_SHAPE24_F64 0      // A/B: the 1024-thread 64×32 shape for fp64 as well (it spills: 128 registers per lane)
+#endif
 #define IX3(i, j, k, sx, sy) ((idx_t)(i) + (idx_t)(sx) * ((idx_t)(j) + (idx_t)(sy) * (idx_t)(k)))
 
 // Grid spacings.  STRICT divides (x/dx, x/dx/dx) exactly like the Julia expressions; FAST multiplies by
@@ -2573,7 +2576,7 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
     case 16: NS3D_SWN(NLV, 1, 4, 4, true);                                                                  \
     case 22: if constexpr (sizeof(T) == 4) { NS3D_SWN(NLV, 1, 12, 4, true); } else return hipErrorInvalidValue; /* fp32: 64×48, 768 threads = three waves per SIMD */ \
     case 23: NS3D_SWN(NLV, 1, 12, 2, true);  /* 64×24, 768 threads, two rows per thread: three waves per SIMD */ \
-    case 24: if constexpr (sizeof(T) == 4) { NS3D_SWN(NLV, 1, 16, 2, true); } else return hipErrorInvalidValue; /* fp32: 64×32, 1024 threads = four waves per SIMD (fp64 would spill) */ \
+    case 24: if constexpr (sizeof(T) == 4 || NS3D_SHAPE24_F64) { NS3D_SWN(NLV, 1, 16, 2, true); } else return hipErrorInvalidValue; /* fp32: 64×32, 1024 threads = four waves per SIMD (fp64 spills: A/B with -DNS3D_SHAPE24_F64=1) */ \
     case 28: NS3D_SWN(NLV, 1, 12, 2, false);                                                                     \
     case 11: NS3D_SWN(NLV, 1, 8, 4, true);                                                                  \
     case 12: NS3D_SWN(NLV, 2, 4, 4, true);                                                                  \
