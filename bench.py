@@ -214,6 +214,9 @@ def main():
     ap.add_argument("--no-strong", action="store_true",
                     help="N>1: skip the second measurement (the same GLOBAL grid split in z) reported as `strong`")
     ap.add_argument("--cpu-iters", type=int, default=12)
+    ap.add_argument("--no-config-b", action="store_true", default=os.environ.get("NS3D_BENCH_NO_TRAFFIC") == "1",
+                    help="N=1: skip the `config_b` object (the same Poisson-only measurement on the reference's own 255x153x153 "
+                         "grid and spacings, STRICT and FAST, a few seconds)")
     ap.add_argument("--no-traffic", action="store_true", default=os.environ.get("NS3D_BENCH_NO_TRAFFIC") == "1",
                     help="N=1: do not measure roofline.traffic live (two short rocprofv3 --pmc child runs of this command's kernel "
                          "instance after the timed region); the figure then comes from profiles/pt_sweep_traffic.json")
@@ -255,11 +258,16 @@ def main():
             strong = strong_object(head, world)
         else:
             strong = strong_object(run_case(a, world, rank, device, ndev, shared_gpu, strong_params(a.n, p.nz, world), "strong"), world)
+    config_b = None
+    if world == 1 and not a.no_config_b:
+        config_b = config_b_object(a, device, ndev, shared_gpu)
     ok = True
     if rank == 0:
         out = json_line(a, world, head)
         if strong is not None:
             out["strong"] = strong
+        if world == 1 and config_b is not None:
+            out["config_b"] = config_b
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(a.n, 128, a.cpu_iters, a.dtype)
@@ -275,6 +283,36 @@ def main():
     if not ok:
         sys.stderr.write("bench.py: the timed kernel / schedule did NOT reproduce the single-sweep reference (config.verified)\n")
         sys.exit(3)
+
+
+def config_b_object(a, device, ndev, shared_gpu):
+    """BASELINE's north_star asks for the 255×153×153 cylinder case next to the synthetic grids: the same Poisson-only measurement
+    (∇V synthetic, Pr = dPrdτ = 0, all-Neumann) on the reference's own grid and SPACINGS (multi.jl:322-341 for nx = 255: dx = 1/255 …
+    — not powers of two, so STRICT takes the exact-division build), in STRICT and in FAST mode (the product mode on such grids:
+    within 1e-6, identical iteration counts), each self-verified like the headline.  A report beside the headline, never a reason
+    to lose it."""
+    import argparse
+    out = {"workload": "Poisson-only PT iteration on the grid and spacings of the reference's cylinder case (BASELINE configs[1], "
+                       "multi.jl nx = 255)", "unit": "Mcells*iter/s"}
+    try:
+        from navierstokes3d_amd.params import multi_params
+        p = multi_params(255)
+        out["grid"] = [p.nx, p.ny, p.nz]
+        for mode in ("strict", "fast"):
+            b = argparse.Namespace(**vars(a))
+            b.mode, b.steps, b.warmup = mode, max(a.steps, 240), max(a.warmup, 24)
+            b.depth, b.variant, b.variant2, b.variantn, b.no_temporal_blocking = 0, 0, None, None, False
+            r = run_case(b, 1, 0, device, ndev, shared_gpu, p, "weak")
+            itemsize = 8 if a.dtype == "f64" else 4
+            kern_ms = r["dev_ms"] / r["launches"]
+            out[mode] = {"value": r["value"], "ms_per_step": r["ms_per_step"], "steps": b.steps, "pt_depth": r["depth"],
+                         "arith_build": r["arith_build"], "pt2_variant": r["pt2_variant"], "ptn_variant": r["ptn_variant"],
+                         "verified": r["verified"], "finite": r["finite"],
+                         "roofline_frac": algorithmic_bytes(p.nx, p.ny, p.nz, itemsize) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "hbm_gbps_algorithmic": r["effective"]}
+    except Exception as e:
+        out["error"] = repr(e)
+    return out
 
 
 def strong_params(n, nz_g, world):
@@ -528,7 +566,7 @@ def measure_traffic(a, r):
     depth = r["depth"]
     nx, ny, nz = r["local_grid"]
     args = ["--gpus", "1", "--steps", str(6 * depth), "--warmup", str(depth), "--grid", str(nx), "--grid-nz", str(nz),
-            "--mode", a.mode, "--dtype", a.dtype, "--no-cpu-baseline", "--no-verify", "--no-traffic", "--no-strong"]
+            "--mode", a.mode, "--dtype", a.dtype, "--no-cpu-baseline", "--no-verify", "--no-traffic", "--no-strong", "--no-config-b"]
     if depth >= 2:
         args += ["--depth", str(depth)]
         args += ["--variant2", str(r["pt2_variant"])] if depth == 2 else ["--variantn", str(r["ptn_variant"])]

@@ -45,6 +45,13 @@ def test_bench_prints_one_json_line(extra):
         assert r["traffic_source"].startswith("profiles lookup") or r["traffic_source"] == "none"
     assert r["frac"] * (1 - 1e-9) <= r["effective_frac"] <= r["pt_iterations_per_launch"] * r["frac"] * (1 + 1e-9)
     assert abs(d["hbm_gbps_algorithmic"] - r["effective_gbps"]) < 1e-6 * r["effective_gbps"]
+    # the reference's own grid beside the synthetic one (north_star: "throughput on the 255×153×153 cylinder case …"): STRICT takes the
+    # exact-division build there, FAST is the product mode; both self-verified
+    b = d["config_b"]
+    assert b["grid"] == [255, 153, 153] and "error" not in b
+    assert b["strict"]["arith_build"] == "strictx" and b["fast"]["arith_build"] == "fast"
+    for m in ("strict", "fast"):
+        assert b[m]["value"] > 0 and b[m]["verified"] is True and b[m]["finite"] is True and 0 < b[m]["roofline_frac"] <= 1.0
     if "--no-cpu-baseline" not in extra:
         c = d["cpu_baseline"]
         assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
