@@ -37,7 +37,7 @@ def main():
     rhs.permute(2, 1, 0).uniform_(-1e-3, 1e-3)
     abytes = isz * (nx * ny * nz + 4 * (nx - 2) * (ny - 2) * (nz - 2))
     ctxs = {m: K.Context(0, m, async_=True) for m in a.modes.split(",")}
-    variants = [int(v) for v in a.variants.split(",")]
+    variants = [int(v) for v in a.variants.split(",") if v != ""]
     res = {}
     pt = K.pt_params(Pr, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy, p.dz, L.NS3D_BC_MULTI, False, 0.0, 0.0)
     for rnd in range(a.rounds + 1):
