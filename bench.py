@@ -214,7 +214,10 @@ def main():
     ap.add_argument("--no-strong", action="store_true",
                     help="N>1: skip the second measurement (the same GLOBAL grid split in z) reported as `strong`")
     ap.add_argument("--cpu-iters", type=int, default=12)
-    ap.add_argument("--no-config-b", action="store_true", default=os.environ.get("NS3D_BENCH_NO_TRAFFIC") == "1",
+    ap.add_argument("--pass-chain", dest="no_pass_chain", action="store_false", default=os.environ.get("NS3D_PASS_CHAIN") != "1",
+                    help="A/B: two-iteration passes neither write nor read the boundary cells between them (include/ns3d.h NS3D_PASS_*; "
+                         "measured slower on the reference's grid, so off by default, as in ns3d_pt_iterate)")
+    ap.add_argument("--no-config-b", action="store_true", default=os.environ.get("NS3D_BENCH_NO_CONFIG_B") == "1",
                     help="N=1: skip the `config_b` object (the same Poisson-only measurement on the reference's own 255x153x153 "
                          "grid and spacings, STRICT and FAST, a few seconds)")
     ap.add_argument("--no-traffic", action="store_true", default=os.environ.get("NS3D_BENCH_NO_TRAFFIC") == "1",
@@ -276,6 +279,8 @@ def main():
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(out))
         ok = out["config"]["verified"] is not False and (strong is None or strong.get("verified") is not False)
+        if config_b is not None:        # the reference's own grid is part of the gate too: a failed self-check there exits 3 as well
+            ok = ok and all(v.get("verified") is not False for v in config_b.values() if isinstance(v, dict))
     if world > 1:
         ok = agree(ok)
         dist.barrier()
@@ -427,16 +432,29 @@ def run_case(a, world, rank, device, ndev, shared_gpu, p, scaling):
         if slab is not None:
             slab.iterate(n)
             return
-        for its in schedule(n):
+        sched = schedule(n)
+        prev_skipped = False
+        for i, its in enumerate(sched):
             if its == 1:
                 K.pt_sweep(st["Pr"], st["Pb"], st["D"], rhs, pt, 1, nz - 1, ctx=ctx)
                 st["Pr"], st["Pb"] = st["Pb"], st["Pr"]
+                prev_skipped = False
                 continue
+            # the boundary cells between two multi-iteration passes are neither written nor read (what ns3d_pt_iterate does
+            # inside a residual-check block, ns3d_api.cpp enqueue_iters; include/ns3d.h NS3D_PASS_*): the first pass of the
+            # run reads them as they are, the last one writes them
+            flags = 0
+            if not a.no_pass_chain and its == 2:        # two-iteration passes chain (k_pt_sweep2); deeper ones keep their boundary cells
+                nxt_deep = i + 1 < len(sched) and sched[i + 1] == 2
+                flags = (L.NS3D_PASS_INPUT_OBEYS_BC if prev_skipped else 0) | (L.NS3D_PASS_SKIP_FACES if nxt_deep else 0)
+                prev_skipped = nxt_deep
+            ctx.set_pt_pass_flags(flags)
             if its == 2:
                 K.pt_sweep2(st["Pr"], st["Pb"], st["D"], st["D2"], rhs, pt, ctx=ctx)
             else:
                 K.pt_sweepn(its, st["Pr"], st["Pb"], st["D"], st["D2"], rhs, pt, ctx=ctx)
             st["Pr"], st["Pb"], st["D"], st["D2"] = st["Pb"], st["Pr"], st["D2"], st["D"]
+        ctx.set_pt_pass_flags(0)
 
     # plan phase, untimed and outside the warmup count: ns3d_plan_pt times the tile shapes of k_pt_sweep2 / k_pt_sweepN on
     # these arguments, decides how many iterations a pass advances, and the process keeps the winner (same bits either way)
@@ -482,20 +500,35 @@ def run_case(a, world, rank, device, ndev, shared_gpu, p, scaling):
     verified = None
     if not a.no_verify:
         vd = max(passes) if passes else 0
+        nver = vd
         if vd >= 1:
             vctx = ctx
             if world == 1:
                 P0, D0 = st["Pr"], st["D"]
                 Pa, Da = st["Pb"], (st["D2"] if st["D2"] is not None else K.clone(D0))
+                def one_pass(Pi, Po, Di, Do, flags):
+                    ctx.set_pt_pass_flags(flags)
+                    if vd == 2:
+                        K.pt_sweep2(Pi, Po, Di, Do, rhs, pt, ctx=ctx)
+                    else:
+                        K.pt_sweepn(vd, Pi, Po, Di, Do, rhs, pt, ctx=ctx)
+                    ctx.set_pt_pass_flags(0)
                 if vd == 1:
                     Da = K.clone(D0)
                     K.pt_sweep(P0, Pa, Da, rhs, pt, 1, nz - 1, ctx=ctx)
-                elif vd == 2:
-                    K.pt_sweep2(P0, Pa, D0, Da, rhs, pt, ctx=ctx)
+                elif a.no_pass_chain or vd != 2:
+                    one_pass(P0, Pa, D0, Da, 0)
                 else:
-                    K.pt_sweepn(vd, P0, Pa, D0, Da, rhs, pt, ctx=ctx)
+                    # the timed passes are chained (boundary cells neither written nor read in between): check TWO of them, the
+                    # first without its boundary cells, the second forming them — against 2·depth single sweeps
+                    Pm, Dm = K.clone(P0), K.clone(D0)
+                    Pm.fill_(float("nan"))               # whatever the first pass leaves unwritten must not matter
+                    one_pass(P0, Pm, D0, Dm, L.NS3D_PASS_SKIP_FACES)
+                    one_pass(Pm, Pa, Dm, Da, L.NS3D_PASS_INPUT_OBEYS_BC)
+                    del Pm, Dm
+                    nver = 2 * vd
                 halo = lambda X: None
-                verify["against"] = "%d launches of the one-thread-per-cell sweep (k_pt_sweep_naive)" % vd
+                verify["against"] = "%d launches of the one-thread-per-cell sweep (k_pt_sweep_naive)" % nver
             else:
                 P0, D0 = K.zeros((nx, ny, nz), tdt, dev), K.zeros((nx - 2, ny - 2, nz - 2), tdt, dev)
                 Pa, Da = K.zeros((nx, ny, nz), tdt, dev), K.zeros((nx - 2, ny - 2, nz - 2), tdt, dev)
@@ -506,7 +539,7 @@ def run_case(a, world, rank, device, ndev, shared_gpu, p, scaling):
                 verify["against"] = "%d x {one-thread-per-cell sweep; update_halo!(Pr)} per rank" % vd
             vctx.set_pt_variant(100)
             Pq, Pw, Dq = K.clone(P0), K.clone(P0), K.clone(D0)
-            for _ in range(vd):
+            for _ in range(nver):
                 K.pt_sweep(Pq, Pw, Dq, rhs, pt, 1, nz - 1, ctx=vctx)
                 halo(Pw)
                 Pq, Pw = Pw, Pq
@@ -524,7 +557,7 @@ def run_case(a, world, rank, device, ndev, shared_gpu, p, scaling):
                 t = torch.tensor([1.0 if okv else 0.0, 1.0 if bitwise else 0.0, -rel], dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MIN)
                 okv, bitwise, rel = bool(t[0].item()), bool(t[1].item()), -t[2].item()
-            verify.update(iterations=vd, bitwise=bitwise, rel_l2=rel,
+            verify.update(iterations=nver, bitwise=bitwise, rel_l2=rel, chained_passes=bool(world == 1 and vd == 2 and not a.no_pass_chain),
                           criterion="bitwise" if a.mode == "strict" else "rel_l2 <= 1e-6 (BASELINE north_star tolerance)")
             verified = okv
             del Pq, Pw, Dq

@@ -112,6 +112,7 @@ ns3d_ctx *ns3d_create(int device, int flags)
     if (const char *ev = std::getenv("NS3D_PT2_VARIANT")) c->pt2_variant = std::atoi(ev);   // experiments without an API call
     c->ptn_variant = 0;
     if (const char *ev = std::getenv("NS3D_PTN_VARIANT")) c->ptn_variant = std::atoi(ev);
+    if (const char *ev = std::getenv("NS3D_PASS_CHAIN")) c->pass_chain = std::atoi(ev) ? 1 : 0;
     c->pt_depth = 0;
     if (const char *ev = std::getenv("NS3D_PT_DEPTH")) c->pt_depth = std::atoi(ev);
     c->autotune = 1;
@@ -223,6 +224,20 @@ int ns3d_set_ptn_variant(ns3d_ctx *c, int v)
     return NS3D_OK;
 }
 
+int ns3d_set_pt_pass_flags(ns3d_ctx *c, int flags)
+{
+    if (!c) return fail(NS3D_ERR_ARG, "ns3d_set_pt_pass_flags: null context");
+    if (flags & ~(NS3D_PASS_INPUT_OBEYS_BC | NS3D_PASS_SKIP_FACES)) return fail(NS3D_ERR_ARG, "ns3d_set_pt_pass_flags: unknown flags %d", flags);
+    c->pass_flags = flags;
+    return NS3D_OK;
+}
+int ns3d_set_pass_chain(ns3d_ctx *c, int on)
+{
+    if (!c) return fail(NS3D_ERR_ARG, "ns3d_set_pass_chain: null context");
+    if ((on != 0) != (c->pass_chain != 0)) c->clear_graphs();       // captured blocks hold the other form
+    c->pass_chain = on ? 1 : 0;
+    return NS3D_OK;
+}
 int ns3d_set_pt_depth(ns3d_ctx *c, int depth)
 {
     if (!c) return fail(NS3D_ERR_ARG, "ns3d_set_pt_depth: null context");
@@ -290,6 +305,9 @@ static int ensure_pingpong(ns3d_ctx *c, const ns3d_pt_params *p, T **buf)
         }
         HIPCHK(c, hipMalloc(&c->pingpong, need));
         c->pingpong_bytes = need;
+        // chained passes leave the y/z boundary cells of this buffer unwritten and never use what they read there; zeros keep the
+        // exact-division build's range guard (which tests values as they are loaded) from seeing arbitrary bit patterns
+        HIPCHK(c, hipMemsetAsync(c->pingpong, 0, need, c->stream));
     }
     *buf = (T *)c->pingpong;
     return NS3D_OK;
@@ -325,7 +343,11 @@ static int ensure_pingpong_d(ns3d_ctx *c, const ns3d_pt_params *p, T **buf)
 // How a pass over memory is made: PT iterations per pass (depth 2: k_pt_sweep2 with tile variant v2; 3, 4: k_pt_sweepN with
 // tile variant vn).  Explicit settings (ns3d_set_pt2_variant / _ptn_variant / _pt_depth) always win.
 struct Plan { int depth, v2, vn; bool known; };
-static const long long NS3D_DEEP_MIN_CELLS = 8ll * 1000 * 1000;     // below this a deeper pass never paid (192³: two per pass; 256×256×128: four, +10 %)
+// Below this the planner does not time deeper passes.  Round 4 lowered it from 8 M to 3 M cells: on the reference's own 255×153×153
+// grid (6.0 M cells) three iterations per pass run 34 % faster than two in FAST mode (2800: 17.8 against 23.8 µs per iteration;
+// profiles/r4_midsize.log) — the round-2 finding "stays at two" held for the exact-division STRICT build only, which is
+// VALU-bound there (29.8 against 28.4) and keeps two because the planner measures head to head.  127×77×77 (0.75 M): two.
+static const long long NS3D_DEEP_MIN_CELLS = 3ll * 1000 * 1000;
 template <class T>
 static Plan lookup_plan(const ns3d_ctx *c, int mode, const ns3d_pt_params *p, int k0, int k1)
 {
@@ -368,8 +390,10 @@ static Plan tune_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
         bool ok = true;
         for (int rep = 0; rep <= timed && ok; ++rep) {     // one untimed launch, then `timed` timed ones
             if (rep == 1) ok = hipEventRecord(c->tune_ev[0], s) == hipSuccess;
-            hipError_t e = depth == 2 ? DISPATCHM(mode, pt_sweep2<T>(s, v, src, dst, dsrc, ddst, divV, *p, k0, k1))
-                                      : DISPATCHM(mode, pt_sweepn<T>(s, depth, v, src, dst, dsrc, ddst, divV, *p, k0, k1));
+            // timed as the passes inside a block run: without the boundary-cell launch behind the sweep (interior results unchanged)
+            const int tf = (c->pass_chain && depth == 2) ? NS3D_PASS_SKIP_FACES : 0;
+            hipError_t e = depth == 2 ? DISPATCHM(mode, pt_sweep2<T>(s, v, src, dst, dsrc, ddst, divV, *p, k0, k1, tf))
+                                      : DISPATCHM(mode, pt_sweepn<T>(s, depth, v, src, dst, dsrc, ddst, divV, *p, k0, k1, tf));
             ok = ok && e == hipSuccess;
         }
         ok = ok && hipEventRecord(c->tune_ev[1], s) == hipSuccess && hipEventSynchronize(c->tune_ev[1]) == hipSuccess &&
@@ -424,7 +448,7 @@ static Plan tune_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
     // a clear per-ITERATION gain (≥ 2 %), head to head.
     const long long cells = (long long)p->nx * p->ny * nk;
     if (c->pt_depth <= 0 && cells >= NS3D_DEEP_MIN_CELLS && nk >= 12) {
-        static const int cand[] = {1100, 2800, 2300, 100, 1600, 600, 2200, 1132};   // the first one is the built-in shape: it wins near-ties
+        static const int cand[] = {1100, 2800, 2300, 100, 1600, 600, 2200, 1132, 3800};   // the first one is the built-in shape: it wins near-ties
         int bestn = c->ptn_variant;
         float best3 = 0.f, ms = 0.f;
         if (c->ptn_variant > 0) { if (!time_launch(3, bestn, best3)) best3 = 0.f; }
@@ -444,12 +468,14 @@ static Plan tune_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
         // (two rows per thread: 154 registers), in fp32 1024-thread workgroups of 64×32 columns (two rows per thread, ≤ 128
         // registers) or 768 threads on 64×48; 2391 / 2891 = ONE round of workgroups, each marching the whole z range
         if (nk >= 16) {
-            static const int cand4_f32[] = {2400, 2200, 1100, 0}, cand4_f64[] = {2800, 2891, 2300, 2391};
+            // 3800 (round 4): k_pt_sweepD, the planes of P⁰ through an LDS-DMA ring — what lets fp64 fit a 1024-thread 64×32 tile;
+            // ties 2800 at 512³ (180 tiles for 256 CUs), so it has to win its place by 2 % like every later candidate
+            static const int cand4_f32[] = {2400, 2200, 1100, 0, 0}, cand4_f64[] = {2800, 2891, 2300, 2391, 3800};
             const int *cand4 = sizeof(T) == 4 ? cand4_f32 : cand4_f64;
             const float cur_per_it = pl.depth == 3 ? best3 / 3.f : ms2 / 2.f;
             int best4v = 0;
             float best4 = 0.f;
-            for (int q4 = 0; q4 < 4; ++q4) {
+            for (int q4 = 0; q4 < 5; ++q4) {
                 const int v = cand4[q4];
                 if (v == 0) continue;
                 if (c->ptn_variant > 0 && v != c->ptn_variant) continue;
@@ -478,7 +504,7 @@ static Plan tune_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
         }
     } else if (c->pt_depth >= 3 && c->ptn_variant <= 0 && cells >= NS3D_TWO_MIN_CELLS) {
         // (24xx: float32 only, 28xx / 23xx with 768 threads: both element types; a shape that cannot run the depth is skipped)
-        static const int cand[] = {1100, 2400, 2491, 2300, 2391, 2800, 2891, 100, 1600, 600, 2200, 1132};
+        static const int cand[] = {1100, 2400, 2491, 2300, 2391, 2800, 2891, 100, 1600, 600, 2200, 1132, 3800};
         float bestd = 0.f, ms = 0.f;
         for (int v : cand) {
             if (!time_launch(c->pt_depth, v, ms)) continue;
@@ -506,12 +532,13 @@ static hipError_t launch_pass(ns3d_ctx *c, hipStream_t s, int depth, const Plan 
 {
     const int mode = mode_of(c, p->dx, p->dy, p->dz);
     c->last_depth = depth;
+    const int flags = c->pass_flags;
     if (depth == 2) {
         c->last_pt2 = pl.v2;
-        return DISPATCHM(mode, pt_sweep2<T>(s, pl.v2, src, dst, dsrc, ddst, divV, *p, k0, k1));
+        return DISPATCHM(mode, pt_sweep2<T>(s, pl.v2, src, dst, dsrc, ddst, divV, *p, k0, k1, flags));
     }
     c->last_ptn = pl.vn;
-    return DISPATCHM(mode, pt_sweepn<T>(s, depth, pl.vn, src, dst, dsrc, ddst, divV, *p, k0, k1));
+    return DISPATCHM(mode, pt_sweepn<T>(s, depth, pl.vn, src, dst, dsrc, ddst, divV, *p, k0, k1, flags));
 }
 // iterations of the next pass when `rem` remain until the next residual check / the end
 static int next_depth(const Plan &pl, bool blocked, int rem)
@@ -659,16 +686,31 @@ static hipError_t enqueue_iters(ns3d_ctx *c, hipStream_t s, int n, bool two, T *
     Plan pl{2, 0, 0, true};
     if (two && n >= 2)
         pl = pick_plan<T>(c, s, mode_of(c, p->dx, p->dy, p->dz), src, dst, dsrc, ddst, divV, p, 1, p->nz - 1, may_tune);
+    // Between two deep passes of a block nobody reads the boundary cells of the iterate: the pass in front does not write its
+    // y/z faces (NS3D_PASS_SKIP_FACES: no k_pt_faces launch — 5.6 µs beside a 52 µs pass at 255×153×153) and the pass behind
+    // forms them from the boundary rule (NS3D_PASS_INPUT_OBEYS_BC).  The first pass of a block reads the caller's cells as they
+    // are; the last one — and any pass in front of a single sweep, which reads them — writes them.  Same bits.
+    const int user_flags = c->pass_flags;
+    bool prev_skipped = false;
     for (int it = 0; it < n && e == hipSuccess;) {
         const int d = next_depth(pl, two, n - it);
         if (d >= 2) {
+            // chained: two-iteration passes only (k_pt_sweep2 has the instantiation; at the sizes where deeper passes run the
+            // boundary-cell launch is 0.5 % of a pass and the deep kernels keep round 3's form)
+            const int rest = n - it - d;
+            const bool next_is_two = d == 2 && rest >= 2 && next_depth(pl, two, rest) == 2;
+            c->pass_flags = (c->pass_chain && d == 2) ? ((prev_skipped ? NS3D_PASS_INPUT_OBEYS_BC : 0) | (next_is_two ? NS3D_PASS_SKIP_FACES : 0)) : 0;
+            prev_skipped = (c->pass_flags & NS3D_PASS_SKIP_FACES) != 0;
             e = launch_pass<T>(c, s, d, pl, src, dst, dsrc, ddst, divV, p, 1, p->nz - 1);
             T *t = dsrc; dsrc = ddst; ddst = t;
-        } else
+        } else {
+            prev_skipped = false;
             e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_sweep<T>(s, c->pt_variant, src, dst, dsrc, divV, *p, 1, p->nz - 1));
+        }
         it += d;
         T *t = src; src = dst; dst = t;
     }
+    c->pass_flags = user_flags;
     return e;
 }
 

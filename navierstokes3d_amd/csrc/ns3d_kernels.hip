@@ -1375,6 +1375,8 @@ struct SweepArgs {
     int bc_kind, owns_outlet, zlo_halo, zhi_halo;
     int k0, k1; // interior planes [k0,k1) handled by this launch
     int kz;     // planes per block
+    int l1_bc;    // NS3D_PASS_INPUT_OBEYS_BC: level 1 substitutes the boundary rule too and never uses the face cells of its input
+    int no_faces; // NS3D_PASS_SKIP_FACES: the y/z boundary cells of the output are not written (no k_pt_faces launch)
 };
 
 // value stored on the x planes for target plane kk (0-based)
@@ -1728,7 +1730,11 @@ static hipError_t launch_pipe_auto(hipStream_t s, SweepArgs<T> &a, int kz)
 // sweep, or (SEPF) only the x-face cell beside an interior cell, the y/z faces following in k_pt_faces_*.  z planes that
 // are inter-slab halos are not supported here: z-slab ranks pass buffers extended by a second ghost plane (slab.py).
 // =========================================================================================================
-template <class T, int WX, int WY, int CPT, bool NT, int MINW = 1, bool SEPF = false>
+// L1BC (round 4, NS3D_PASS_INPUT_OBEYS_BC): level 1 forms the boundary cells of its INPUT from the boundary rule as level 2 does
+// with those of P¹, instead of reading them — the pass in front then need not write them (NS3D_PASS_SKIP_FACES: no k_pt_faces
+// launch behind its sweep).  A template parameter, not a run-time flag: the L1BC = false instantiation is round 3's kernel, bit
+// for bit and instruction for instruction (a run-time test in the hot loop cost 5 % at 512³ whether it was taken or not).
+template <class T, int WX, int WY, int CPT, bool NT, int MINW = 1, bool SEPF = false, bool L1BC = false>
 __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a, int ntx, int nty)
 {
     constexpr int TX = 64 * WX, TY = CPT * WY, PX = TX + 2;
@@ -1891,12 +1897,26 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
         for (int r = 0; r < CPT; ++r) {
             const int lr = wy * CPT + r;
             const T c = p0c[r];
-            const T w = l0[(lr + 1) * PX + lx], e = l0[(lr + 1) * PX + lx + 2];
-            const T sv = r == 0 ? l0[lr * PX + lx + 1] : p0c[r - 1 < 0 ? 0 : r - 1];
-            const T nv = r == CPT - 1 ? l0[(lr + 2) * PX + lx + 1] : p0c[r + 1 > CPT - 1 ? CPT - 1 : r + 1];
+            T w = l0[(lr + 1) * PX + lx], e = l0[(lr + 1) * PX + lx + 2];
+            T sv = r == 0 ? l0[lr * PX + lx + 1] : p0c[r - 1 < 0 ? 0 : r - 1];
+            T nv = r == CPT - 1 ? l0[(lr + 2) * PX + lx + 1] : p0c[r + 1 > CPT - 1 ? CPT - 1 : r + 1];
+            T bv = p0m[r], tv = p0p[r];
+            if constexpr (L1BC) {           // the input's boundary cells are formed, not used (they may never have been written)
+                if (tile_on_xy_face) {
+                    const int gjf = oy + lr;
+                    if (xlo_adj) w = xface_val<T>(a, false, c, k1);
+                    if (xhi_adj) e = xface_val<T>(a, true, c, k1);
+                    if (gjf == 1) sv = c;
+                    if (gjf == ny - 2) nv = c;
+                }
+                if constexpr (EDGE) {
+                    if (k1 == 1) bv = c;
+                    if (k1 == nz - 2) tv = c;
+                }
+            }
             const T res = decltype(slow_tag)::value
-                              ? poisson_rhs_slow<T>(c, w, e, sv, nv, p0m[r], p0p[r], r0[r], a.rho_dt, g)
-                              : poisson_rhs_nochk<T>(c, w, e, sv, nv, p0m[r], p0p[r], r0[r], a.rho_dt, g);
+                              ? poisson_rhs_slow<T>(c, w, e, sv, nv, bv, tv, r0[r], a.rho_dt, g)
+                              : poisson_rhs_nochk<T>(c, w, e, sv, nv, bv, tv, r0[r], a.rho_dt, g);
             d1n[r] = d0[r] * a.one_m_damp + a.dtau * res;
             p1p[r] = c + a.dtau * d1n[r];
         }
@@ -2016,7 +2036,8 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
     constexpr int UNR = NS3D_STEP_UNROLL > 0 ? NS3D_STEP_UNROLL : (CPT <= 2 ? 4 : 1);
     int s = 0;
     if constexpr (UNR > 1) {
-        const int hot_lo = max(2, 4 - kb), hot_hi = min(nsteps, nz - kb);       // bulk: s ≥ 2 and plane k2 = kb−2+s in [2, nz−3]
+        // bulk: s ≥ 2 and plane k2 = kb−2+s in [2, nz−3]; with L1BC level 1's plane k1 = k2+1 must stay below nz−2 as well
+        const int hot_lo = max(2, 4 - kb), hot_hi = min(nsteps, nz - kb - (L1BC ? 1 : 0));
         const int h0 = min(nsteps, (hot_lo + 1) & ~1);                          // an even number of edge steps first (parity)
         for (; s + 2 <= h0; s += 2) {
             step(s, std::true_type{});
@@ -2111,6 +2132,7 @@ static int workgroups_per_cu(const void *kernel, int threads)
 template <class T, int WX, int WY, int CPT, bool NT, int MINW = 1, bool SEPF = false>
 static hipError_t launch_sweep2(hipStream_t s, SweepArgs<T> &a, int kz)
 {
+    auto kern = a.l1_bc ? k_pt_sweep2<T, WX, WY, CPT, NT, MINW, SEPF, true> : k_pt_sweep2<T, WX, WY, CPT, NT, MINW, SEPF, false>;
     constexpr int TX = 64 * WX, TY = CPT * WY;
     const int nk = a.k1 - a.k0;
     const int ntx = max(1, (a.nx - 4 + (TX - 2) - 1) / (TX - 2)), nty = max(1, (a.ny - 4 + (TY - 2) - 1) / (TY - 2));
@@ -2134,10 +2156,9 @@ static hipError_t launch_sweep2(hipStream_t s, SweepArgs<T> &a, int kz)
     }
     a.kz = kz;
     const int ntz = (nk + kz - 1) / kz;
-    hipLaunchKernelGGL((k_pt_sweep2<T, WX, WY, CPT, NT, MINW, SEPF>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX, WY, 1), 0,
-                       s, a, ntx, nty);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ntx * nty * ntz)), dim3(TX, WY, 1), 0, s, a, ntx, nty);
     hipError_t e = hipGetLastError();
-    if (SEPF && e == hipSuccess) e = launch_faces<T>(s, a);
+    if (SEPF && e == hipSuccess && !a.no_faces) e = launch_faces<T>(s, a);
     return e;
 }
 
@@ -2217,6 +2238,22 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
         roff[r] = cjj * nx + cii;
         doff[r] = (cjj - 1) * (nx - 2) + (cii - 1);
         outc[r] = x_out && (gj <= ny - 2) && (lr >= NL - 1 || tile_y_lo) && (lr <= TY - NL || tile_y_hi);
+    }
+    // Wave-uniform level skipping (round 4, VERDICT r3 #1a; -DNS3D_LEVEL_SKIP=1).  Level ℓ is exact on the rows ℓ−1 … TY−ℓ of a tile
+    // (all rows on a side that is a face of the domain); a wave none of whose CPT rows lies in that range computes nothing any
+    // valid row ever reads, so it may skip level ℓ's arithmetic and the publish of its Pˡ: with 12 waves × 2 rows, waves 0 and 11
+    // skip levels 3 and 4 of an interior tile, 4 of 48 wave-levels.  Same bits (138 sweepN tests) — and the same time: the pass
+    // is not bound by the instructions it issues (profiles/r4_levelskip_dma_ab.log), so the default build leaves it out.
+#ifndef NS3D_LEVEL_SKIP
+#define NS3D_LEVEL_SKIP 0
+#endif
+    bool act[NL + 1];
+    {
+        const int wyu = __builtin_amdgcn_readfirstlane(wy);
+        act[0] = act[1] = true;
+#pragma unroll
+        for (int l = 2; l <= NL; ++l)
+            act[l] = !NS3D_LEVEL_SKIP || ((wyu * CPT + CPT - 1 >= l - 1 || tile_y_lo) && (wyu * CPT <= TY - l || tile_y_hi));
     }
     // halo ring duties (P⁰ only): A = row below the tile, B = row above, C = the two columns beside it
     const bool hasA = (wy == 0), hasB = (wy == WY - 1), hasC = (tid < 2 * TY);
@@ -2348,15 +2385,17 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
             const int kl = k1 - (l - 1);
             T *__restrict__ npub = LN[l - 2][cur ^ 1];
             // publish Pˡ⁻¹ of the plane just produced (x/y neighbours of level l in the NEXT step)
+            if (act[l - 1]) {
 #pragma unroll
-            for (int r = 0; r < CPT; ++r) npub[(wy * CPT + r) * TX + lx] = fresh[r];
+                for (int r = 0; r < CPT; ++r) npub[(wy * CPT + r) * TX + lx] = fresh[r];
+            }
 #if NS3D_HAS_SLOW_PATH
 #pragma unroll
             for (int r = 0; r < CPT; ++r) bad |= !val_ok<T>(fresh[r]);   // top neighbour of level l below
             slow = slow || (__builtin_amdgcn_ballot_w64(bad) != 0);
 #endif
             T out_p[CPT], out_d[CPT];
-            if (!EDGE || s >= 2 * (l - 1)) {
+            if ((!EDGE || s >= 2 * (l - 1)) && act[l]) {
                 const T *__restrict__ ll = LN[l - 2][cur];
                 const bool zlo = EDGE && (kl == 1), zhi = EDGE && (kl == nz - 2);
                 auto level = [&](auto slow_tag) {
@@ -2494,6 +2533,7 @@ static hipError_t launch_sweepN(hipStream_t s, SweepArgs<T> &a, int kz)
     if constexpr (!(TX > OV + 2 && TY > OV + 2 && lds <= 160ul * 1024)) {
         return hipErrorInvalidValue;            // tile too small for this many levels, or its planes exceed the 160 KB of LDS
     } else {
+    if (a.l1_bc || a.no_faces) return hipErrorInvalidValue;      // NS3D_PASS_*: the two-iteration sweep only
     const int nk = a.k1 - a.k0;
     const int ntx = max(1, (a.nx - 2 - OV + (TX - OV) - 1) / (TX - OV)), nty = max(1, (a.ny - 2 - OV + (TY - OV) - 1) / (TY - OV));
     if (kz <= 0) {
@@ -2539,6 +2579,396 @@ static hipError_t launch_sweepN(hipStream_t s, SweepArgs<T> &a, int kz)
     }
 }
 
+// =========================================================================================================
+// k_pt_sweepD  —  the NL-iteration pass with the planes of P⁰ staged by LDS-DMA  (round 4, VERDICT r3 #1b)
+//
+// Same levels, same trapezoid, same arithmetic per cell as k_pt_sweepN (bit-identical to NL k_pt_sweep launches); what changes
+// is how P⁰ reaches the stencils.  k_pt_sweepN carries four planes of P⁰ per column in registers (k1−1, k1, k1+1 and the staging
+// copy of k1+2) plus the halo ring twice, and republishes every plane into LDS with ds_write.  Here the whole (TY+2)×66 image of
+// a plane — tile, halo rows and halo columns alike — is one lane-linear run of 4-byte words in a ring of NSL LDS slots, filled
+// by `global_load_lds_dword` (each lane's source address is precomputed once: clamped row / column of the word it owns; the
+// destination is wave-uniform base + 4·lane, so no register ever holds the data), and level 1 reads c, w, e, s, n of plane k1
+// and t of plane k1+1 from LDS; only b = P⁰[k1−1] stays in a register (it is last step's c).  Per column that is 1 live value
+// of P⁰ instead of 4 and no halo registers: the 768-thread 64×24 shape loses its spills, and fp64 fits a 1024-thread 64×32
+// tile (four waves per SIMD, 73.6 % of the lanes produce output against 68 %).
+//
+// Ordering (cdna_hip_programming.md §5 "Pipelining across barriers"; MI355X_MICROARCH.md item 7: nothing orders a ds_read
+// behind a pending LDS-DMA except the issuing wave's vmcnt and a barrier): the DMA is inline asm, invisible to hipcc's
+// s_waitcnt bookkeeping (a builtin DMA makes it drain vmcnt(0) before every later ds_read).  In step s the words of plane
+// k1+NSL−1 are issued AFTER level 1 — so that no hidden operation is younger than the d⁰/∇V loads whose results level 1 of the
+// next step waits for with hipcc's own counted vmcnt — followed by this step's 2·CPT d⁰/∇V loads; the step ends with
+//     s_waitcnt vmcnt(N) lgkmcnt(0);  s_barrier        N = 2·CPT (NSL = 3)  or  CW + 4·CPT (NSL = 4: one more step in flight)
+// which retires the DMA of plane k1+2 whatever number of output stores followed it (N counts only operations that are ALWAYS
+// issued; stores on top make the wait stricter, never looser), and the plane is first read in step s+1, behind that barrier.
+// WAR: a slot is refilled in the step after its last readers passed lgkmcnt(0) + barrier.
+// =========================================================================================================
+__device__ __forceinline__ void glds_word(const void *plane, unsigned byte_off, unsigned lds_byte)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(byte_off), "s"(lds_byte), "s"(plane)
+                 : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm_lgkm_barrier()
+{
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(N) : "memory");
+}
+
+template <class T, int NL, int WY, int CPT, int NSL, int UNR, int OPT>
+__global__ __launch_bounds__(64 * WY) void k_pt_sweepD(SweepArgs<T> a, int ntx, int nty)
+{
+    static_assert(NL >= 2 && NL <= 5, "levels");
+    static_assert(NSL == 3 || NSL == 4, "slots");
+    constexpr bool CLDS = (OPT & 1) != 0;    // levels ≥ 2 read their centre value from the LDS plane too: one register pair per level and row less
+    constexpr int TX = 64, TY = CPT * WY, PX = TX + 2, PR = TY + 2, OV = 2 * (NL - 1);
+    constexpr int W = (int)sizeof(T) / 4;                       // DMA words per element
+    constexpr int NW = PR * PX * W, NCH = (NW + 63) / 64;       // words / 64-word chunks of one plane image
+    constexpr int CW = (NCH + WY - 1) / WY;                     // chunks per wave (the last one may be missing: wave-uniform test)
+    constexpr int SLOT = NCH * 64 / W;                          // elements per slot
+    constexpr int LEAD = NSL - 1;                               // the plane issued in step s is k1 + LEAD
+    constexpr int WAITN = NSL == 3 ? 2 * CPT : CW + 4 * CPT;
+    static_assert(TX > OV + 2 && TY > OV + 2, "tile too small for this many levels");
+    __shared__ T L0[NSL][SLOT];              // ring of P⁰ plane images: element (row + 1) * PX + (column + 1)
+    __shared__ T LN[NL - 1][2][TY * TX];     // planes of P¹ … P^{NL−1}
+#if NS3D_HAS_SLOW_PATH
+    __shared__ int Lbad;
+#endif
+    const int nx = a.nx, ny = a.ny, nz = a.nz;
+    const Geo<T> &g = a.g;
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int q = nb >> 3, rem = nb & 7, xcd = b & 7, loc = b >> 3;
+    const int tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
+    const int tx_t = tile % ntx, ty_t = (tile / ntx) % nty, tz_t = tile / (ntx * nty);
+    const int ox = 1 + tx_t * (TX - OV), oy = 1 + ty_t * (TY - OV);
+    const int kb = a.k0 + tz_t * a.kz;
+    const int ke = min(kb + a.kz, a.k1);
+    if (kb >= ke) return; // workgroup-uniform, before any barrier
+
+    const int lx = threadIdx.x, wy = threadIdx.y;
+    const int wyu = __builtin_amdgcn_readfirstlane(wy);
+    const int gi = ox + lx;
+    const int ci = min(gi, nx - 1), cii = min(gi, nx - 2);
+    const idx_t sz = (idx_t)nx * ny;
+    const idx_t dsz = (idx_t)(nx - 2) * (ny - 2);
+    const bool xlo_adj = (gi == 1), xhi_adj = (gi == nx - 2);
+    const bool tile_x_lo = (ox <= 1), tile_x_hi = (ox + TX - 1 >= nx - 2);
+    const bool tile_y_lo = (oy <= 1), tile_y_hi = (oy + TY - 1 >= ny - 2);
+    const bool tile_on_xy_face = tile_x_lo || tile_x_hi || tile_y_lo || tile_y_hi;
+    const bool tile_on_x_face = tile_x_lo || tile_x_hi;
+    const bool x_out = (gi <= nx - 2) && (lx >= NL - 1 || tile_x_lo) && (lx <= TX - NL || tile_x_hi);
+
+    // rows are wave-uniform (one wave = one threadIdx.y): the row part of every offset is scalar, only the column part is per lane
+    int roff[CPT], doff[CPT];
+    bool outr[CPT];
+#pragma unroll
+    for (int r = 0; r < CPT; ++r) {
+        const int lr = wyu * CPT + r, gj = oy + lr;
+        const int cjj = min(gj, ny - 2);
+        roff[r] = cjj * nx;
+        doff[r] = (cjj - 1) * (nx - 2) - 1;
+        outr[r] = (gj <= ny - 2) && (lr >= NL - 1 || tile_y_lo) && (lr <= TY - NL || tile_y_hi);
+    }
+    bool act[NL + 1];                        // wave-uniform level skipping, as in k_pt_sweepN
+    act[0] = act[1] = true;
+#pragma unroll
+    for (int l = 2; l <= NL; ++l) act[l] = (wyu * CPT + CPT - 1 >= l - 1 || tile_y_lo) && (wyu * CPT <= TY - l || tile_y_hi);
+
+    // the words of a plane image this lane moves: chunk c = wy + j·WY, word c·64 + lane → element (row, col) of the image →
+    // cell (oy−1+row, ox−1+col) clamped into the plane (the clamped copies are the cells no valid stencil reads)
+    unsigned goff[CW];
+#pragma unroll
+    for (int j = 0; j < CW; ++j) {
+        const int wi = (wyu + j * WY) * 64 + lx;
+        const int el = min(wi / W, PR * PX - 1), h = wi % W;
+        const int row = el / PX, col = el - row * PX;
+        const unsigned gj = (unsigned)min(oy - 1 + row, ny - 1), gc = (unsigned)min(ox - 1 + col, nx - 1);
+        goff[j] = ((gj * (unsigned)nx + gc) * (unsigned)W + (unsigned)h) * 4u;
+    }
+    const unsigned lds0 = (unsigned)(unsigned long long)(&L0[0][0]);
+    const T *__restrict__ P = a.Pin;
+    auto issue_plane = [&](int kplane, int slot) __attribute__((always_inline)) {
+        const T *__restrict__ Pn = P + (idx_t)min(max(kplane, 0), nz - 1) * sz;
+        const unsigned base = lds0 + (unsigned)slot * (unsigned)(SLOT * sizeof(T)) + (unsigned)wyu * 256u;
+#pragma unroll
+        for (int j = 0; j < CW; ++j)
+            if ((j + 1) * WY <= NCH || wyu + j * WY < NCH) glds_word(Pn, goff[j], base + (unsigned)(j * WY) * 256u);
+    };
+
+    const T *__restrict__ RHS = a.RHS;
+    const T *__restrict__ Din = a.Din;
+    T *__restrict__ D = a.D;
+
+    const int idx00 = (wyu * CPT + 1) * PX + lx + 1;     // this thread's first cell in a plane image; row r is r·PX further
+    const int lnb = wyu * CPT * TX;                      // its first row in a plane of Pˡ
+    const int lxm = max(lx - 1, 0), lxp = min(lx + 1, TX - 1);
+
+    T p0m[CPT];                               // P⁰ plane k1−1 (last step's c)
+    T pm[NL - 1][CPT], pc[NL - 1][CPT];       // Pˡ planes kℓ₊₁−1, kℓ₊₁
+    T dc[NL - 1][CPT];                        // dˡ[kℓ₊₁]
+    T rr[NL][CPT];                            // ∇V[k1] … ∇V[k_NL]
+    T d0[CPT];                                // d⁰[k1]
+    bool bad = false;
+    (void)bad;
+#if NS3D_HAS_SLOW_PATH
+    if (a.bc_kind == NS3D_BC_GPU) {
+        const T hmin = (a.rho_g * (T)1.5) * g.dz, hmax = (a.rho_g * ((T)(nz - 2) + (T)0.5)) * g.dz;
+        bad = !(val_ok<T>(hmin) && val_ok<T>(hmax) && val_ok<T>(hmin + (T)100) && val_ok<T>(hmax + (T)100));
+    } else if (a.owns_outlet) bad = !val_ok<T>(a.outlet_val);
+    if (wy == 0 && lx == 0) Lbad = 0;
+#endif
+    const int kfirst = kb - (NL - 1);         // plane of level 1 at step 0
+    // ---- prologue: planes kfirst … kfirst+LEAD−1 into the ring, plane kfirst−1 and the streams of plane kfirst into registers ----
+    {
+#pragma unroll
+        for (int q0 = 0; q0 < LEAD; ++q0) issue_plane(kfirst + q0, q0);
+        const T *__restrict__ Pm = P + (idx_t)min(max(kfirst - 1, 0), nz - 1) * sz;
+        const int ka = min(max(kfirst, 1), nz - 2);
+#pragma unroll
+        for (int r = 0; r < CPT; ++r) {
+            const int gj = min(oy + wyu * CPT + r, ny - 1);
+            p0m[r] = Pm[gj * nx + ci];
+            d0[r] = ld_stream<T, true>(Din + ((idx_t)(ka - 1) * dsz + doff[r]) + cii);
+            rr[0][r] = ld_stream<T, true>(RHS + ((idx_t)ka * sz + roff[r]) + cii);
+#pragma unroll
+            for (int l = 0; l < NL - 1; ++l) { pm[l][r] = pc[l][r] = dc[l][r] = (T)0; rr[l + 1][r] = (T)0; }
+        }
+    }
+    wait_vm_lgkm_barrier<0>();
+
+    const int nsteps = (ke - kb) + OV;
+    int cur = 0;
+    int sc = 0, sn = 1, s2 = NSL == 4 ? 2 : 0, sl = NSL - 1;   // slots of planes k1, k1+1, (k1+2,) and the one being filled
+    auto step = [&](const int s, auto edge_tag) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        const int k1 = kfirst + s;
+        T d0n[CPT], r0n[CPT];
+        T fresh[CPT], dnew[CPT];
+        // ---------------- level 1 at plane k1: everything of P⁰ but the plane below comes from the ring ----------------
+        {
+            const T *__restrict__ lc = &L0[0][0] + sc * SLOT;
+            const T *__restrict__ lt = &L0[0][0] + sn * SLOT;
+            T c[CPT], t[CPT], w[CPT], e[CPT];
+#pragma unroll
+            for (int r = 0; r < CPT; ++r) { c[r] = lc[(idx00 + r * PX)]; w[r] = lc[(idx00 + r * PX) - 1]; e[r] = lc[(idx00 + r * PX) + 1]; t[r] = lt[(idx00 + r * PX)]; }
+            const T s_lo = lc[idx00 - PX], n_hi = lc[(idx00 + (CPT - 1) * PX) + PX];
+#if NS3D_HAS_SLOW_PATH
+#pragma unroll
+            for (int r = 0; r < CPT; ++r) {
+                bad |= !val_ok<T>(t[r]); bad |= !val_ok<T>(w[r]); bad |= !val_ok<T>(e[r]);
+                if (EDGE) { bad |= !val_ok<T>(c[r]); bad |= !val_ok<T>(p0m[r]); }
+            }
+            bad |= !val_ok<T>(s_lo); bad |= !val_ok<T>(n_hi);
+            bool slow = (__builtin_amdgcn_readfirstlane(Lbad) != 0) || (__builtin_amdgcn_ballot_w64(bad) != 0);   // wave-uniform
+#else
+            const bool slow = false;
+#endif
+            auto level1 = [&](auto slow_tag) {
+#pragma unroll
+                for (int r = 0; r < CPT; ++r) {
+                    const T sv = r == 0 ? s_lo : c[r - 1 < 0 ? 0 : r - 1];
+                    const T nv = r == CPT - 1 ? n_hi : c[r + 1 > CPT - 1 ? CPT - 1 : r + 1];
+                    const T res = decltype(slow_tag)::value
+                                      ? poisson_rhs_slow<T>(c[r], w[r], e[r], sv, nv, p0m[r], t[r], rr[0][r], a.rho_dt, g)
+                                      : poisson_rhs_nochk<T>(c[r], w[r], e[r], sv, nv, p0m[r], t[r], rr[0][r], a.rho_dt, g);
+                    dnew[r] = d0[r] * a.one_m_damp + a.dtau * res;
+                    fresh[r] = c[r] + a.dtau * dnew[r];
+                }
+            };
+            if (__builtin_expect(slow, 0)) level1(std::true_type{});
+            else level1(std::false_type{});
+#pragma unroll
+            for (int r = 0; r < CPT; ++r) p0m[r] = c[r];
+            // ---------------- the plane LEAD steps ahead → the free slot; d⁰ / ∇V of plane k1+1 → registers ----------------
+            issue_plane(k1 + LEAD, sl);
+            {
+                const int ka = min(max(k1 + 1, 1), nz - 2);
+#pragma unroll
+                for (int r = 0; r < CPT; ++r) {
+                    d0n[r] = ld_stream<T, true>(Din + ((idx_t)(ka - 1) * dsz + doff[r]) + cii);
+                    r0n[r] = ld_stream<T, true>(RHS + ((idx_t)ka * sz + roff[r]) + cii);
+                }
+            }
+            // ---------------- levels 2 … NL, each one plane behind the previous one ----------------
+#pragma unroll
+            for (int l = 2; l <= NL; ++l) {
+                const int kl = k1 - (l - 1);
+                T *__restrict__ npub = LN[l - 2][cur ^ 1];
+#ifdef NS3D_SCHED_FENCE      // keep the scheduler from interleaving the levels of the branch-free bulk step (register pressure)
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                if (act[l - 1]) {
+#pragma unroll
+                    for (int r = 0; r < CPT; ++r) npub[lnb + r * TX + lx] = fresh[r];
+                }
+#if NS3D_HAS_SLOW_PATH
+#pragma unroll
+                for (int r = 0; r < CPT; ++r) bad |= !val_ok<T>(fresh[r]);
+                slow = slow || (__builtin_amdgcn_ballot_w64(bad) != 0);
+#endif
+                T out_p[CPT], out_d[CPT], ccv[CPT];
+                // centre values: also in the pipeline-fill steps — the one read in the step before level l first runs is that
+                // step's plane below (what it reads before the plane was ever published is overwritten before anything uses it)
+#pragma unroll
+                for (int r = 0; r < CPT; ++r) ccv[r] = CLDS ? (act[l] ? LN[l - 2][cur][lnb + r * TX + lx] : (T)0) : pc[l - 2][r];
+                if ((!EDGE || s >= 2 * (l - 1)) && act[l]) {
+                    const T *__restrict__ ll = LN[l - 2][cur];
+                    const bool zlo = EDGE && (kl == 1), zhi = EDGE && (kl == nz - 2);
+                    // The boundary rule, lean (round 4): the x-face value — copy, outlet value or gpu.jl's hydrostatic profile, a
+                    // function of the plane only — is formed once per level; per row an interior tile pays one scalar branch; rows
+                    // are wave-uniform, so the y-face tests are scalar too.
+                    T xlo_v = (T)0, xhi_v = (T)0;
+                    bool xlo_copy = true, xhi_copy = true;
+                    if (tile_on_x_face) {
+                        if (a.bc_kind == NS3D_BC_GPU) {      // gpu.jl:258-259 at plane kl (xface_val)
+                            xhi_v = (a.rho_g * ((T)(nz - (kl + 1)) + (T)0.5)) * g.dz;
+                            xlo_v = xhi_v + (T)100;
+                            xlo_copy = xhi_copy = false;
+                        } else if (a.owns_outlet) { xhi_v = a.outlet_val; xhi_copy = false; }
+                    }
+                    auto level = [&](auto slow_tag) {
+#pragma unroll
+                        for (int r = 0; r < CPT; ++r) {
+                            const int lr = wyu * CPT + r;
+                            const T cc = ccv[r];
+                            T ww = ll[lnb + r * TX + lxm], ee = ll[lnb + r * TX + lxp];
+                            T sv = r == 0 ? ll[max(lr - 1, 0) * TX + lx] : ccv[r - 1 < 0 ? 0 : r - 1];
+                            T nv = r == CPT - 1 ? ll[min(lr + 1, TY - 1) * TX + lx] : ccv[r + 1 > CPT - 1 ? CPT - 1 : r + 1];
+                            T bv = pm[l - 2][r], tv = fresh[r];
+                            if (tile_on_xy_face) {
+                                if (tile_on_x_face) {
+                                    if (xlo_adj) ww = xlo_copy ? cc : xlo_v;
+                                    if (xhi_adj) ee = xhi_copy ? cc : xhi_v;
+                                }
+                                const int gjf = oy + lr;
+                                if (gjf == 1) sv = cc;
+                                if (gjf == ny - 2) nv = cc;
+                            }
+                            if constexpr (EDGE) {
+                                if (zlo) bv = cc;
+                                if (zhi) tv = cc;
+                            }
+                            const T res = decltype(slow_tag)::value
+                                              ? poisson_rhs_slow<T>(cc, ww, ee, sv, nv, bv, tv, rr[l - 1][r], a.rho_dt, g)
+                                              : poisson_rhs_nochk<T>(cc, ww, ee, sv, nv, bv, tv, rr[l - 1][r], a.rho_dt, g);
+                            out_d[r] = dc[l - 2][r] * a.one_m_damp + a.dtau * res;
+                            out_p[r] = cc + a.dtau * out_d[r];
+                        }
+                    };
+                    if (__builtin_expect(slow, 0)) level(std::true_type{});
+                    else level(std::false_type{});
+                    if (l == NL) {
+                        T *__restrict__ Dk = D + (idx_t)(kl - 1) * dsz;
+#pragma unroll
+                        for (int r = 0; r < CPT; ++r) {
+                            if (outr[r] && x_out) {
+                                st_stream<T, true>(Dk + doff[r] + cii, out_d[r]);
+                                const int gj = oy + wyu * CPT + r;
+                                T *__restrict__ po = a.Pout + ((idx_t)kl * sz + gj * nx) + gi;
+                                st_stream<T, true>(po, out_p[r]);
+                                if (tile_on_x_face) {   // the x-face cell beside it shares its cache line: one more store
+                                    if (xlo_adj) po[-1] = xlo_copy ? out_p[r] : xlo_v;
+                                    if (xhi_adj) po[1] = xhi_copy ? out_p[r] : xhi_v;
+                                }
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < CPT; ++r) { out_p[r] = (T)0; out_d[r] = (T)0; }
+                }
+#pragma unroll
+                for (int r = 0; r < CPT; ++r) {
+                    if constexpr (CLDS) {
+                        // the centre value just read is next step's plane below — where the level did not run (pipeline fill, a
+                        // skipped wave) nothing valid reads it
+                        pm[l - 2][r] = ccv[r];
+                    } else {
+                        pm[l - 2][r] = pc[l - 2][r]; pc[l - 2][r] = fresh[r];
+                    }
+                    dc[l - 2][r] = dnew[r];
+                    fresh[r] = out_p[r]; dnew[r] = out_d[r];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < CPT; ++r) {
+#pragma unroll
+            for (int l = NL - 1; l >= 1; --l) rr[l][r] = rr[l - 1][r];
+            d0[r] = d0n[r];
+            rr[0][r] = r0n[r];
+        }
+#if NS3D_HAS_SLOW_PATH
+        if (bad) Lbad = 1;
+#endif
+        wait_vm_lgkm_barrier<WAITN>();
+        cur ^= 1;
+        const int tfree = sc;
+        if constexpr (NSL == 3) { sc = sn; sn = sl; sl = tfree; }
+        else { sc = sn; sn = s2; s2 = sl; sl = tfree; }
+    };
+    // UNR written-out bulk steps per trip (no edge tests, ring rotations renamed away) as in k_pt_sweepN; UNR = 1 keeps the one
+    // general step form for every plane: fewer registers (the 1024-thread fp64 shape: 119 and no spill, against 128 + 58 spilled)
+    static_assert(UNR == 1 || UNR == 2 || UNR == 4, "UNR");
+    int s = 0;
+    if constexpr (UNR > 1) {
+        const int hot_lo = max(OV, NL + 1 - kfirst), hot_hi = min(nsteps, nz - 1 - kfirst);
+        const int h0 = min(nsteps, (hot_lo + 1) & ~1);
+        for (; s + 2 <= h0; s += 2) {
+            step(s, std::true_type{});
+            step(s + 1, std::true_type{});
+        }
+        if (s == h0)
+            for (; s + UNR <= hot_hi; s += UNR) {
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+#ifdef NS3D_D_BULK_EDGE
+                    step(s + u, std::true_type{});
+#else
+                    step(s + u, std::false_type{});
+#endif
+            }
+    }
+    for (; s < nsteps; ++s) step(s, std::true_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA words still in flight land before the LDS is released
+}
+
+template <class T, int NL, int WY, int CPT, int NSL, int UNR, int OPT>
+static hipError_t launch_sweepD(hipStream_t s, SweepArgs<T> &a, int kz)
+{
+    constexpr int TX = 64, TY = CPT * WY, OV = 2 * (NL - 1), W = (int)sizeof(T) / 4;
+    constexpr size_t slot = (size_t)(((TY + 2) * (TX + 2) * W + 63) / 64) * 256;
+    constexpr size_t lds = NSL * slot + 2ul * (NL - 1) * TY * TX * sizeof(T) + 64;
+    if constexpr (!(TX > OV + 2 && TY > OV + 2 && lds <= 160ul * 1024)) {
+        return hipErrorInvalidValue;
+    } else {
+        const int nk = a.k1 - a.k0;
+        if (a.l1_bc || a.no_faces) return hipErrorInvalidValue;      // NS3D_PASS_*: the two-iteration sweep only
+        if (a.nx < 4 || a.ny < 4 || (size_t)a.nx * a.ny * sizeof(T) >= (1ull << 32)) return hipErrorInvalidValue;   // 32-bit in-plane byte offsets
+        const int ntx = max(1, (a.nx - 2 - OV + (TX - OV) - 1) / (TX - OV)), nty = max(1, (a.ny - 2 - OV + (TY - OV) - 1) / (TY - OV));
+        if (kz <= 0 || kz > 90) {
+            static const int per_cu = workgroups_per_cu((const void *)k_pt_sweepD<T, NL, WY, CPT, NSL, UNR, OPT>, 64 * WY);
+            const long slots = (long)device_cus() * per_cu, tiles = (long)ntx * nty;
+            const int cmax = max(1, nk / (6 * NL));
+            long best_c = 1, best_cost = -1;
+            for (long c = 1; c <= cmax && c <= 64; ++c) {
+                const int kzc = (int)((nk + c - 1) / c);
+                const long wgs = tiles * ((nk + kzc - 1) / kzc);
+                const long cost = ((wgs + slots - 1) / slots) * (kzc + OV);
+                if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_c = c; }
+                if (kz > 90) break;             // 91: one chunk per tile column
+            }
+            kz = (int)((nk + best_c - 1) / best_c);
+        }
+        a.kz = kz;
+        const int ntz = (nk + kz - 1) / kz;
+        hipLaunchKernelGGL((k_pt_sweepD<T, NL, WY, CPT, NSL, UNR, OPT>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX, WY, 1), 0, s, a, ntx, nty);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = launch_faces<T>(s, a);
+        return e;
+    }
+}
+
 // (Round 3 tried the opposite of overlapped tiles — tiles WITHOUT overlap whose workgroups exchange the edges of every intermediate
 // plane through the L2, cooperative launch, level ℓ three planes behind level ℓ−1 so that an edge has two steps to cross the
 // chip: bit-identical, 2.16 ms per four-iteration pass at 512³ against 1.45 for k_pt_sweepN, 1.36 with the exchange compiled
@@ -2551,7 +2981,7 @@ static hipError_t launch_sweepN(hipStream_t s, SweepArgs<T> &a, int kz)
 // rows per thread, one wave per SIMD, 64×20/64×24 with 256 threads, 64×48 with 1024 — are no longer instantiated.)
 template <class T>
 hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout, const T *Din, T *Dout, const T *RHS,
-                     const ns3d_pt_params &p, int k0, int k1)
+                     const ns3d_pt_params &p, int k0, int k1, int pass_flags)
 {
     SweepArgs<T> a;
     a.Pin = Pin; a.Pout = Pout; a.D = Dout; a.Din = Din; a.RHS = RHS;
@@ -2561,6 +2991,7 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
     a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
     a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = 0; a.zhi_halo = 0;
     a.k0 = k0; a.k1 = k1; a.kz = 1;
+    a.l1_bc = (pass_flags & NS3D_PASS_INPUT_OBEYS_BC) ? 1 : 0; a.no_faces = (pass_flags & NS3D_PASS_SKIP_FACES) ? 1 : 0;
     if (k1 <= k0) return hipSuccess;
     int shape = variant / 100, kz = variant % 100;
     // built-in: 64×32 columns, next step's loads issued before level 1 (measured best at 512³ for three levels); four levels
@@ -2582,6 +3013,27 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
     case 12: NS3D_SWN(NLV, 2, 4, 4, true);                                                                  \
     default: return hipErrorInvalidValue;                                                                   \
     }
+    // shapes 31…39: k_pt_sweepD — P⁰ through an LDS-DMA ring.  31: 64×24 columns / 768 threads, two rows per thread, three slots,
+    // four written-out steps per trip; 37: the same with the one general step form; 35: four slots (the DMA one more step ahead);
+    // 32 / 36: 64×32 / 1024 threads (four waves per SIMD), general step form / two written-out steps; 33: 64×33 / 704 threads and
+    // 34: 64×30 / 640 threads with three rows per thread; 38 / 39: 36 / 35 with the centre values of levels ≥ 2 from LDS
+    if (shape >= 31 && shape <= 39) {
+#define NS3D_SWD(NLV)                                                                                        \
+        switch (shape) {                                                                                     \
+        case 31: return launch_sweepD<T, NLV, 12, 2, 3, 4, 0>(s, a, kz);                                     \
+        case 32: return launch_sweepD<T, NLV, 16, 2, 3, 1, 0>(s, a, kz);                                     \
+        case 33: return launch_sweepD<T, NLV, 11, 3, 3, 1, 0>(s, a, kz);                                     \
+        case 34: return launch_sweepD<T, NLV, 10, 3, 3, 1, 0>(s, a, kz);                                     \
+        case 35: return launch_sweepD<T, NLV, 12, 2, 4, 4, 0>(s, a, kz);                                     \
+        case 36: return launch_sweepD<T, NLV, 16, 2, 3, 2, 0>(s, a, kz);                                     \
+        case 38: return launch_sweepD<T, NLV, 16, 2, 3, 2, 1>(s, a, kz);                                     \
+        case 39: return launch_sweepD<T, NLV, 12, 2, 4, 4, 1>(s, a, kz);                                     \
+        default: return launch_sweepD<T, NLV, 12, 2, 3, 1, 0>(s, a, kz);                                     \
+        }
+        if (nlev == 2) { NS3D_SWD(2) } else if (nlev == 3) { NS3D_SWD(3) } else if (nlev == 4) { NS3D_SWD(4) }
+        return hipErrorInvalidValue;
+#undef NS3D_SWD
+    }
     switch (nlev) {
     case 2: NS3D_SWN_SHAPES(2)
     case 3: NS3D_SWN_SHAPES(3)
@@ -2602,7 +3054,7 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
 // Two fused PT iterations (Pin,Din) → (Pout,Dout) for the output planes [k0,k1) (k0 = 1, k1 = nz-1: the whole slab).
 template <class T>
 hipError_t pt_sweep2(hipStream_t s, int variant, const T *Pin, T *Pout, const T *Din, T *Dout, const T *RHS,
-                     const ns3d_pt_params &p, int k0, int k1)
+                     const ns3d_pt_params &p, int k0, int k1, int pass_flags)
 {
     SweepArgs<T> a;
     a.Pin = Pin; a.Pout = Pout; a.D = Dout; a.Din = Din; a.RHS = RHS;
@@ -2612,6 +3064,7 @@ hipError_t pt_sweep2(hipStream_t s, int variant, const T *Pin, T *Pout, const T 
     a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
     a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = 0; a.zhi_halo = 0;
     a.k0 = k0; a.k1 = k1; a.kz = 1;
+    a.l1_bc = (pass_flags & NS3D_PASS_INPUT_OBEYS_BC) ? 1 : 0; a.no_faces = (pass_flags & NS3D_PASS_SKIP_FACES) ? 1 : 0;
     if (k1 <= k0) return hipSuccess;
     int shape = variant / 100;
     int kz = variant % 100;
@@ -2865,7 +3318,7 @@ hipError_t pt_persist(hipStream_t s, const T *Pin, T *Pout, T *D, const T *RHS, 
     a.outlet_val = (T)p.outlet_val; a.rho_g = (T)p.rho * (T)p.g;
     a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
     a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = 0; a.zhi_halo = 0;
-    a.k0 = 1; a.k1 = p.nz - 1; a.kz = 1;
+    a.k0 = 1; a.k1 = p.nz - 1; a.kz = 1; a.l1_bc = 0; a.no_faces = 0;
     // the iteration is arithmetic on the CUs the grid occupies plus one hand-over: the smallest workgroup the chip still holds
     // all at once spreads the cells over the most CUs.  NS3D_PERSIST_SHAPE=22|42|44 pins a shape (A/B).
     static const int pin = std::getenv("NS3D_PERSIST_SHAPE") ? std::atoi(std::getenv("NS3D_PERSIST_SHAPE")) : 0;
@@ -2889,7 +3342,7 @@ hipError_t pt_sweep(hipStream_t s, int variant, const T *Pin, T *Pout, T *D, con
     a.outlet_val = (T)p.outlet_val; a.rho_g = (T)p.rho * (T)p.g;
     a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
     a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = p.z_lo_is_halo; a.zhi_halo = p.z_hi_is_halo;
-    a.k0 = k0; a.k1 = k1; a.kz = 1;
+    a.k0 = k0; a.k1 = k1; a.kz = 1; a.l1_bc = 0; a.no_faces = 0;
     if (k1 <= k0) return hipSuccess;
     // variant = family*100 + kz  (kz = planes marched per block; 0 → default); variant 0 = choose by grid size:
     // grids whose four PT arrays stay resident in L2 / Infinity Cache run best with one thread per cell (neighbours are
@@ -3052,17 +3505,21 @@ hipError_t divtest(hipStream_t s, double d, long n, unsigned long long seed, uns
                                     int, int);                                                               \
     template hipError_t pt_persist<T>(hipStream_t, const T *, T *, T *, const T *, const ns3d_pt_params &, int, ns3d_persist_state *); \
     template hipError_t pt_sweep2<T>(hipStream_t, int, const T *, T *, const T *, T *, const T *,            \
-                                     const ns3d_pt_params &, int, int);                                      \
+                                     const ns3d_pt_params &, int, int, int);                                 \
     template hipError_t pt_sweepn<T>(hipStream_t, int, int, const T *, T *, const T *, T *, const T *,       \
-                                     const ns3d_pt_params &, int, int);                                      \
+                                     const ns3d_pt_params &, int, int, int);                                 \
     template hipError_t residual_max_key<T>(hipStream_t, const T *, const T *, const ns3d_pt_params &,       \
                                             unsigned long long *);                                           \
     template hipError_t divtest<T>(hipStream_t, double, long, unsigned long long, unsigned long long *);   \
     template hipError_t strip_inner<T>(hipStream_t, const T *, T *, int, int, int);                          \
     template hipError_t face_copy<T>(hipStream_t, T *, T *, int, int, int, int, int, int);                  \
     template hipError_t subbox_copy<T>(hipStream_t, const ns3d_subbox_batch<T> &);
+#ifdef NS3D_PROBE   // tools/ab/resources.sh: ONE kernel instance per compilation (seconds instead of minutes)
+hipError_t probe_launch(hipStream_t s, SweepArgs<NS3D_PROBE_T> &a) { return NS3D_PROBE(s, a, 0); }
+#else
 INST(double)
 INST(float)
+#endif
 #undef INST
 
 } // namespace NS3D_NS

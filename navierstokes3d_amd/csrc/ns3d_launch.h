@@ -81,10 +81,10 @@ struct ns3d_subbox_batch {
                           ns3d_persist_state *);                                                              \
     template <class T>                                                                                       \
     hipError_t pt_sweep2(hipStream_t, int variant, const T *, T *, const T *, T *, const T *,                \
-                         const ns3d_pt_params &, int k0, int k1);                                            \
+                         const ns3d_pt_params &, int k0, int k1, int pass_flags);                            \
     template <class T>                                                                                       \
     hipError_t pt_sweepn(hipStream_t, int nlev, int variant, const T *, T *, const T *, T *, const T *,      \
-                         const ns3d_pt_params &, int k0, int k1);                                            \
+                         const ns3d_pt_params &, int k0, int k1, int pass_flags);                            \
     template <class T>                                                                                       \
     hipError_t residual_max_key(hipStream_t, const T *, const T *, const ns3d_pt_params &,                   \
                                 unsigned long long *key_dev);                                                \

@@ -3,7 +3,7 @@
 #   cp navierstokes3d_amd/libns3d.so tools/ab/libns3d_old.so;  …edit, rebuild…;  cp navierstokes3d_amd/libns3d.so tools/ab/libns3d_new.so
 #   gpurun -- 'BENCH_ARGS="--variant2 1392" bash tools/ab/ab.sh'
 # Every tools/ab/libns3d_*.so is benchmarked twice, interleaved, through the NS3D_LIB override of navierstokes3d_amd/lib.py.
-export NS3D_BENCH_NO_TRAFFIC=1   # these runs are timed or profiled themselves: no nested rocprofv3 --pmc child runs (bench.py --no-traffic)
+export NS3D_BENCH_NO_TRAFFIC=1 NS3D_BENCH_NO_CONFIG_B=1   # these runs are timed or profiled themselves: no nested rocprofv3 --pmc child runs (bench.py --no-traffic)
 set -e
 cd $GRAFT_REPO_ROOT
 if [ -z "$SKIP_TESTS" ]; then

@@ -3,7 +3,7 @@
 #   gpurun -- 'bash tools/ab/libs_ab.sh "--depth 4 --variantn 2891" "--depth 4 --variantn 2800" "--dtype f32"'
 # every tools/ab/libns3d_*.so, interleaved, twice per argument set; prints value, ms per pass, verified.
 # (profiles/r3_pace_order_ab.log: pacing hint, tile order, halo-ring duties, compiler scheduling strategies)
-export NS3D_BENCH_NO_TRAFFIC=1   # these runs are timed or profiled themselves: no nested rocprofv3 --pmc child runs (bench.py --no-traffic)
+export NS3D_BENCH_NO_TRAFFIC=1 NS3D_BENCH_NO_CONFIG_B=${NS3D_BENCH_NO_CONFIG_B:-1}   # these runs are timed or profiled themselves: no nested rocprofv3 --pmc child runs (bench.py --no-traffic)
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
@@ -22,5 +22,7 @@ python - <<'PY'
 import json,glob
 for f in sorted(glob.glob('gpurun_out/pace_*.json')):
     d=json.loads(open(f).read().strip().splitlines()[-1])
-    print(f, round(d['value']), 'ms/pass', round(d['roofline']['kernel_ms'],4), 'frac', round(d['roofline']['frac'],3), 'v', d['config'].get('ptn_variant'), 'verified', d['config'].get('verified'))
+    cb = d.get('config_b') or {}
+    print(f, round(d['value']), 'ms/pass', round(d['roofline']['kernel_ms'],4), 'frac', round(d['roofline']['frac'],3), 'v', d['config'].get('ptn_variant'), 'verified', d['config'].get('verified'),
+          'config_b', {m: (round(v['value']), v.get('verified')) for m, v in cb.items() if isinstance(v, dict) and 'value' in v})
 PY

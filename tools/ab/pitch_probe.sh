@@ -2,7 +2,7 @@
 # Does the power-of-two row / plane pitch of the 512^3 grid cost bandwidth?  The same tiling (9 x 29 tiles of 64x24, one round,
 # 512 planes) on grids n x n x 512 with n around 512, FAST mode (no arithmetic difference between spacings) and fp64:
 #   gpurun -- 'bash tools/ab/pitch_probe.sh'
-export NS3D_BENCH_NO_TRAFFIC=1
+export NS3D_BENCH_NO_TRAFFIC=1 NS3D_BENCH_NO_CONFIG_B=1
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 for rep in 1 2; do

@@ -3,13 +3,13 @@
 #   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r3'
 # Outputs land in gpurun_out/<tag>_*; copy the ones to be judged into profiles/.
 # The profiler gets `python3 bench.py …` itself after `--` (no shell / env hop); PMC passes are kernel-trace only.
-export NS3D_BENCH_NO_TRAFFIC=1   # these runs are timed or profiled themselves: no nested rocprofv3 --pmc child runs (bench.py --no-traffic)
+export NS3D_BENCH_NO_TRAFFIC=1 NS3D_BENCH_NO_CONFIG_B=1   # these runs are timed or profiled themselves: no nested rocprofv3 --pmc child runs (bench.py --no-traffic)
 set -u
 TAG=${1:-r3}
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
 b() { name=$1; shift; python3 bench.py "$@" > $O/${TAG}_bench_$name.json 2> $O/${TAG}_bench_$name.err; echo "$name: $(python3 -c "import json,sys; d=json.loads(open('$O/${TAG}_bench_$name.json').read().strip().splitlines()[-1]); r=d['roofline']; print(round(d['value']), 'Mcells*it/s', 'depth', d['config']['pt_depth'], 'frac', round(r['frac'],3), 'eff', round(r['effective_frac'],3), 'kernel_ms', round(r['kernel_ms'],4))" 2>&1)"; }
-NS3D_BENCH_NO_TRAFFIC=0 b strict                       # the headline line measures roofline.traffic live
+NS3D_BENCH_NO_TRAFFIC=0 NS3D_BENCH_NO_CONFIG_B=0 b strict                     # the headline line measures roofline.traffic live
 NS3D_BENCH_NO_TRAFFIC=0 b fast --mode fast --no-cpu-baseline
 NS3D_BENCH_NO_TRAFFIC=0 b f32_strict --dtype f32 --no-cpu-baseline
 b f32_fast --dtype f32 --mode fast --no-cpu-baseline
