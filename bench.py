@@ -214,6 +214,10 @@ def main():
     ap.add_argument("--no-strong", action="store_true",
                     help="N>1: skip the second measurement (the same GLOBAL grid split in z) reported as `strong`")
     ap.add_argument("--cpu-iters", type=int, default=12)
+    ap.add_argument("--reserve-cus", type=int, default=int(os.environ.get("NS3D_BENCH_RESERVE_CUS", "0")),
+                    help="compute launches leave this many CUs out (ns3d_reserve_cus: room for RCCL's kernels beside the interior sweep)")
+    ap.add_argument("--interior-chunks", type=int, default=int(os.environ.get("NS3D_BENCH_INTERIOR_CHUNKS", "1")),
+                    help="N>1: the interior sweep of a z-slab pass in this many launches (ns3d_mgpu_set_interior_chunks)")
     ap.add_argument("--pass-chain", dest="no_pass_chain", action="store_false", default=os.environ.get("NS3D_PASS_CHAIN") != "1",
                     help="A/B: two-iteration passes neither write nor read the boundary cells between them (include/ns3d.h NS3D_PASS_*; "
                          "measured slower on the reference's grid, so off by default, as in ns3d_pt_iterate)")
@@ -378,6 +382,14 @@ def run_case(a, world, rank, device, ndev, shared_gpu, p, scaling):
         ctx.set_pt_depth(a.depth)
     if a.no_autotune:
         ctx.set_autotune(False)
+    if a.reserve_cus > 0:
+        # the compute launches leave CUs to the exchange's kernels (include/ns3d.h ns3d_reserve_cus); from here on this process's
+        # torch work and timing events go to the same CU-masked stream
+        torch.cuda.synchronize()
+        st_masked = (mg.reserve_cus(a.reserve_cus) if mg is not None else [ctx.reserve_cus(a.reserve_cus)])[0]
+        torch.cuda.set_stream(st_masked)
+    if mg is not None and a.interior_chunks > 1:
+        mg.set_interior_chunks(a.interior_chunks)
     grid = ZSlabGrid(nx, ny, nz, transport="host") if world > 1 else ZSlabGrid(nx, ny, nz)
 
     # synthetic right-hand side ∇V = U(-1e-3,1e-3), seeded per rank; Pr = dPrdτ = 0 (SURVEY §8d Config 3)
@@ -683,6 +695,7 @@ def json_line(a, world, r):
                    "local_grid": r["local_grid"], "global_grid": r["global_grid"],
                    "decomposition": "z-slabs x%d" % world,
                    "transport": r["transport"], "rccl_ranks": r["rccl_ranks"],
+                   "reserved_cus": a.reserve_cus, "interior_chunks": a.interior_chunks, "pass_chain": not a.no_pass_chain,
                    "arith_mode": a.mode, "arith_build": r["arith_build"], "variant": a.variant,
                    "pt_depth": its_per_launch, "pt2_variant": r["pt2_variant"],
                    "ptn_variant": r["ptn_variant"], "residual_after_run": r["err"], "finite": r["finite"],

@@ -74,6 +74,16 @@ int ns3d_flags(const ns3d_ctx *ctx);
  * launches on a private non-blocking stream; ns3d_use_own_stream() returns to it. */
 int ns3d_set_stream(ns3d_ctx *ctx, void *hip_stream);
 int ns3d_use_own_stream(ns3d_ctx *ctx);
+/* Leave `n_cus` compute units of the device OUT of this context's launches: the context gets a stream of its own created with a CU
+ * mask (hipExtStreamCreateWithCUMask) and launches there from now on; 0 = back to the unmasked own stream.  Why: the interior sweep
+ * of a z-slab rank holds every CU of the chip for ≈150 µs per pass (one workgroup per CU), and RCCL's send/recv kernels on the
+ * communication stream need CUs to start — the reference reserves `b_width` cells "for comm / comp overlap" (multi.jl:326) and never
+ * uses them; this is the knob that makes room on the device instead.  n_cus is spread over the 8 XCDs (rounded up to a multiple
+ * of 8, at most half the device).  NS3D_RESERVE_CUS=n presets it for every context created afterwards.  Results do not depend
+ * on it.  Cost measured on one MI355X: profiles/r4_cu_mask_ab.log.  ns3d_get_stream returns the stream (wrap it to order other
+ * work with it). */
+int ns3d_reserve_cus(ns3d_ctx *ctx, int n_cus);
+int ns3d_reserved_cus(const ns3d_ctx *ctx);
 void *ns3d_get_stream(ns3d_ctx *ctx);
 int ns3d_sync(ns3d_ctx *ctx);
 /* Tuning knob for the fused PT sweep (0 = default); see DESIGN.md. */
@@ -340,6 +350,13 @@ int ns3d_max_g(ns3d_mgpu *m, const double *local_max, double *out);    /* NaN-pr
  * or four pay on this grid; every rank uses the same depth. */
 int ns3d_mgpu_set_temporal(ns3d_mgpu *m, int depth);
 int ns3d_mgpu_pass_depth(const ns3d_mgpu *m);
+/* Making room for the exchange's kernels while the interior sweep runs (round 4; results do not depend on either):
+ * ns3d_mgpu_reserve_cus — ns3d_reserve_cus on every local rank's context (the seam sweeps and the exchange stay on the unmasked
+ * high-priority communication stream); ns3d_mgpu_set_interior_chunks — the interior sweep of a z-slab pass goes out as `chunks`
+ * launches over consecutive plane ranges (1 = one launch; NS3D_SLAB_INTERIOR_CHUNKS presets it), so that a pending send/recv
+ * finds CUs at the latest when a chunk ends. */
+int ns3d_mgpu_reserve_cus(ns3d_mgpu *m, int n_cus);
+int ns3d_mgpu_set_interior_chunks(ns3d_mgpu *m, int chunks);
 /* ghost planes per seam of the loaded solve state: (deepest pass allowed) - 1 after ns3d_slab_load, pass depth - 1 once
  * ns3d_slab_plan has agreed on the iterations per pass; -1 when nothing is loaded */
 int ns3d_mgpu_ghost_depth(const ns3d_mgpu *m);

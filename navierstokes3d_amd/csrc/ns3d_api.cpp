@@ -26,7 +26,11 @@ int ns3d_fail(int code, const char *fmt, ...)
 
 // tile choices measured so far in this process (per device and grid): contexts come and go (one per driver call), the
 // measurement should not be repeated
-struct Tuned { int device, nx, ny, nz, nk, esize, mode, variant, depth, variantn; };
+// `pinned`: the pass depth that was FORCED when the entry was measured (ns3d_set_pt_depth, or ns3d_slab_plan / box_plan pinning the
+// depth their ghosts allow) — 0 for a free choice; `cus_off`: compute units left out of the launches (ns3d_reserve_cus).  Both are
+// part of the key: an entry tuned under a pin or a CU mask must not answer a lookup made without it, nor the other way round
+// (a forced-depth entry used to supply its depth to later unpinned lookups).
+struct Tuned { int device, nx, ny, nz, nk, esize, mode, pinned, cus_off, variant, depth, variantn; };
 static std::vector<Tuned> g_tuned;
 static std::mutex g_tuned_mutex;
 
@@ -135,6 +139,8 @@ ns3d_ctx *ns3d_create(int device, int flags)
         return nullptr;
     }
     c->stream = c->own_stream;
+    if (const char *ev = std::getenv("NS3D_RESERVE_CUS"))
+        if (std::atoi(ev) > 0 && ns3d_reserve_cus(c, std::atoi(ev)) != NS3D_OK) { ns3d_destroy(c); return nullptr; }
     return c;
 }
 
@@ -154,6 +160,7 @@ void ns3d_destroy(ns3d_ctx *c)
     if (c->pingpong_d) (void)hipFree(c->pingpong_d);
     if (c->key_dev) (void)hipFree(c->key_dev);
     if (c->key_host) (void)hipHostFree(c->key_host);
+    if (c->masked_stream) { (void)hipStreamSynchronize(c->masked_stream); (void)hipStreamDestroy(c->masked_stream); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -173,6 +180,43 @@ int ns3d_use_own_stream(ns3d_ctx *c)
     return NS3D_OK;
 }
 void *ns3d_get_stream(ns3d_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+// CU mask: bit i of the mask words = compute unit i as the runtime numbers them.  How those numbers map onto the 8 XCDs is not
+// documented for this part, so both plausible layouts exist (NS3D_RESERVE_CUS_LAYOUT): 0 = numbers interleave the XCDs (CU i sits
+// on XCD i mod 8: drop the n highest numbers), 1 = 32 consecutive numbers per XCD (drop the n/8 highest of every 32).  Measured
+// (profiles/r4_cu_mask_ab.log): the interleaved reading is the one under which the masked sweep loses time in proportion to the CUs.
+int ns3d_reserve_cus(ns3d_ctx *c, int n)
+{
+    if (!c) return fail(NS3D_ERR_ARG, "ns3d_reserve_cus: null context");
+    ns3d_device_guard guard(c->device);
+    int cus = 0;
+    HIPCHK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    if (n < 0 || n > cus / 2) return fail(NS3D_ERR_ARG, "ns3d_reserve_cus: %d of %d compute units (0 … half the device)", n, cus);
+    n = (n + 7) / 8 * 8;
+    if (c->masked_stream) {
+        HIPCHK(c, hipStreamSynchronize(c->masked_stream));
+        if (c->stream == c->masked_stream) c->stream = c->own_stream;
+        c->clear_graphs();
+        HIPCHK(c, hipStreamDestroy(c->masked_stream));
+        c->masked_stream = nullptr;
+        c->reserved_cus = 0;
+    }
+    if (n == 0) return NS3D_OK;
+    static const int layout = std::getenv("NS3D_RESERVE_CUS_LAYOUT") ? std::atoi(std::getenv("NS3D_RESERVE_CUS_LAYOUT")) : 0;
+    const int words = (cus + 31) / 32;
+    std::vector<uint32_t> mask((size_t)words, 0u);
+    for (int i = 0; i < cus; ++i) {
+        bool keep;
+        if (layout == 1) keep = (i % 32) < 32 - n / 8 || cus % 32 != 0;      // n/8 off the top of every 32-CU group
+        else keep = i < cus - n;                                               // the n highest numbers
+        if (keep) mask[(size_t)(i / 32)] |= 1u << (i % 32);
+    }
+    HIPCHK(c, hipExtStreamCreateWithCUMask(&c->masked_stream, (uint32_t)words, mask.data()));
+    c->reserved_cus = n;
+    c->stream = c->masked_stream;
+    return NS3D_OK;
+}
+int ns3d_reserved_cus(const ns3d_ctx *c) { return c ? c->reserved_cus : -1; }
 
 int ns3d_sync(ns3d_ctx *c)
 {
@@ -361,7 +405,7 @@ static Plan lookup_plan(const ns3d_ctx *c, int mode, const ns3d_pt_params *p, in
     std::lock_guard<std::mutex> lock(g_tuned_mutex);
     for (const auto &t : g_tuned)
         if (t.device == c->device && t.nx == p->nx && t.ny == p->ny && t.nz == p->nz && t.nk == nk &&
-            t.esize == (int)sizeof(T) && t.mode == mode) {
+            t.esize == (int)sizeof(T) && t.mode == mode && t.pinned == c->pt_depth && t.cus_off == c->reserved_cus) {
             if (c->pt2_variant <= 0) pl.v2 = t.variant;
             if (c->pt_depth <= 0) pl.depth = t.depth;
             if (c->ptn_variant <= 0) pl.vn = t.variantn;
@@ -391,7 +435,7 @@ static Plan tune_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
         for (int rep = 0; rep <= timed && ok; ++rep) {     // one untimed launch, then `timed` timed ones
             if (rep == 1) ok = hipEventRecord(c->tune_ev[0], s) == hipSuccess;
             // timed as the passes inside a block run: without the boundary-cell launch behind the sweep (interior results unchanged)
-            const int tf = (c->pass_chain && depth == 2) ? NS3D_PASS_SKIP_FACES : 0;
+            const int tf = ((c->pass_chain && depth == 2) ? NS3D_PASS_SKIP_FACES : 0) | ((c->reserved_cus / 8) << 8);
             hipError_t e = depth == 2 ? DISPATCHM(mode, pt_sweep2<T>(s, v, src, dst, dsrc, ddst, divV, *p, k0, k1, tf))
                                       : DISPATCHM(mode, pt_sweepn<T>(s, depth, v, src, dst, dsrc, ddst, divV, *p, k0, k1, tf));
             ok = ok && e == hipSuccess;
@@ -513,7 +557,7 @@ static Plan tune_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
     }
     {
         std::lock_guard<std::mutex> lock(g_tuned_mutex);
-        g_tuned.push_back({c->device, p->nx, p->ny, p->nz, nk, (int)sizeof(T), mode, pl.v2, pl.depth, pl.vn});
+        g_tuned.push_back({c->device, p->nx, p->ny, p->nz, nk, (int)sizeof(T), mode, c->pt_depth, c->reserved_cus, pl.v2, pl.depth, pl.vn});
     }
     return pl;
 }
@@ -532,7 +576,7 @@ static hipError_t launch_pass(ns3d_ctx *c, hipStream_t s, int depth, const Plan 
 {
     const int mode = mode_of(c, p->dx, p->dy, p->dz);
     c->last_depth = depth;
-    const int flags = c->pass_flags;
+    const int flags = c->pass_flags | ((c->reserved_cus / 8) << 8);   // bits 8…: compute units the launch must not count on (in eights)
     if (depth == 2) {
         c->last_pt2 = pl.v2;
         return DISPATCHM(mode, pt_sweep2<T>(s, pl.v2, src, dst, dsrc, ddst, divV, *p, k0, k1, flags));
@@ -564,9 +608,11 @@ hipError_t ns3d_enqueue_pt2(ns3d_ctx *c, hipStream_t s, const T *src, T *dst, co
 }
 template <class T>
 hipError_t ns3d_enqueue_pass(ns3d_ctx *c, hipStream_t s, int depth, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV,
-                             const ns3d_pt_params *p, int k0, int k1)
+                             const ns3d_pt_params *p, int k0, int k1, int v2, int vn)
 {
-    const Plan pl = lookup_plan<T>(c, mode_of(c, p->dx, p->dy, p->dz), p, k0, k1);
+    Plan pl = lookup_plan<T>(c, mode_of(c, p->dx, p->dy, p->dz), p, k0, k1);
+    if (v2 >= 0 && c->pt2_variant <= 0) pl.v2 = v2;        // the caller's own plan; explicit context settings still win
+    if (vn >= 0 && c->ptn_variant <= 0) pl.vn = vn;
     return launch_pass<T>(c, s, depth, pl, src, dst, dsrc, ddst, divV, p, k0, k1);
 }
 template <class T>
@@ -617,7 +663,7 @@ hipError_t ns3d_enqueue_advect(ns3d_ctx *c, hipStream_t s, T *Vx, const T *Vx_o,
     template hipError_t ns3d_enqueue_pt2<T>(ns3d_ctx *, hipStream_t, const T *, T *, const T *, T *, const T *,      \
                                             const ns3d_pt_params *, int, int);                                      \
     template hipError_t ns3d_enqueue_pass<T>(ns3d_ctx *, hipStream_t, int, const T *, T *, const T *, T *, const T *, \
-                                             const ns3d_pt_params *, int, int);                                     \
+                                             const ns3d_pt_params *, int, int, int, int);                           \
     template int ns3d_plan_pt_internal<T>(ns3d_ctx *, const T *, T *, const T *, T *, const T *,                     \
                                           const ns3d_pt_params *, int, int);                                        \
     template hipError_t ns3d_enqueue_pt1<T>(ns3d_ctx *, hipStream_t, const T *, T *, T *, const T *,                 \

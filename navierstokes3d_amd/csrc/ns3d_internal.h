@@ -14,6 +14,8 @@ struct ns3d_ctx {
     int device;
     int flags;
     hipStream_t own_stream;
+    hipStream_t masked_stream = nullptr;  // ns3d_reserve_cus: a stream whose CU mask leaves `reserved_cus` compute units out
+    int reserved_cus = 0;
     hipStream_t stream;
     unsigned long long *key_dev;  // device scratch for max reductions
     unsigned long long *key_host; // pinned host mirror
@@ -109,10 +111,12 @@ int ns3d_check_pt_params(const ns3d_pt_params *p, const char *fn);
 template <class T>
 hipError_t ns3d_enqueue_pt2(ns3d_ctx *c, hipStream_t s, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV,
                             const ns3d_pt_params *p, int k0, int k1);
-// one pass of `depth` (2…4) PT iterations on stream s with the planned tile shapes (looked up; never measured here)
+// one pass of `depth` (2…4) PT iterations on stream s with the planned tile shapes (looked up; never measured here) — or with the
+// shapes the caller kept from its own plan phase (v2 / vn ≥ 0: ns3d_slab_plan and box_plan measure under a depth they pin for the
+// measurement only, and such entries do not answer unpinned look-ups)
 template <class T>
 hipError_t ns3d_enqueue_pass(ns3d_ctx *c, hipStream_t s, int depth, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV,
-                             const ns3d_pt_params *p, int k0, int k1);
+                             const ns3d_pt_params *p, int k0, int k1, int v2 = -1, int vn = -1);
 // the plan phase of ns3d_plan_pt on the context's stream (blocks on its own events); returns the planned depth
 template <class T>
 int ns3d_plan_pt_internal(ns3d_ctx *c, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV, const ns3d_pt_params *p,

@@ -1375,6 +1375,7 @@ struct SweepArgs {
     int bc_kind, owns_outlet, zlo_halo, zhi_halo;
     int k0, k1; // interior planes [k0,k1) handled by this launch
     int kz;     // planes per block
+    int cus_off;  // host side only: compute units the stream's CU mask leaves out (ns3d_reserve_cus) — the z-chunking counts the rest
     int l1_bc;    // NS3D_PASS_INPUT_OBEYS_BC: level 1 substitutes the boundary rule too and never uses the face cells of its input
     int no_faces; // NS3D_PASS_SKIP_FACES: the y/z boundary cells of the output are not written (no k_pt_faces launch)
 };
@@ -2138,7 +2139,7 @@ static hipError_t launch_sweep2(hipStream_t s, SweepArgs<T> &a, int kz)
     const int ntx = max(1, (a.nx - 4 + (TX - 2) - 1) / (TX - 2)), nty = max(1, (a.ny - 4 + (TY - 2) - 1) / (TY - 2));
     if (kz <= 0 || kz > 90) {
         static const int per_cu = workgroups_per_cu((const void *)k_pt_sweep2<T, WX, WY, CPT, NT, MINW, SEPF>, 64 * WX * WY);
-        const long slots = (long)device_cus() * per_cu, tiles = (long)ntx * nty;
+        const long slots = (long)max(8, device_cus() - a.cus_off) * per_cu, tiles = (long)ntx * nty;
         const int want = kz > 90 ? kz - 90 : 2;
         const int cmax = max(1, nk / 8);                     // chunks shorter than 8 planes are mostly pipeline fill
         long best_c = 1;
@@ -2541,7 +2542,7 @@ static hipError_t launch_sweepN(hipStream_t s, SweepArgs<T> &a, int kz)
         // 2(NL−1) steps a chunk spends filling its pipeline) — the tail round of an unlucky tile count (1024²: 1026 tiles on 256
         // CUs) costs a whole chunk, so such grids want shorter chunks
         static const int per_cu = workgroups_per_cu((const void *)k_pt_sweepN<T, NL, WX, WY, CPT, PF, MINW>, 64 * WX * WY);
-        const long slots = (long)device_cus() * per_cu, tiles = (long)ntx * nty;
+        const long slots = (long)max(8, device_cus() - a.cus_off) * per_cu, tiles = (long)ntx * nty;
         const int cmax = max(1, nk / (6 * NL));
         long best_c = 1, best_cost = -1;
         for (long c = 1; c <= cmax && c <= 64; ++c) {
@@ -2553,7 +2554,7 @@ static hipError_t launch_sweepN(hipStream_t s, SweepArgs<T> &a, int kz)
         kz = (int)((nk + best_c - 1) / best_c);
     } else if (kz > 90) {
         static const int per_cu = workgroups_per_cu((const void *)k_pt_sweepN<T, NL, WX, WY, CPT, PF, MINW>, 64 * WX * WY);
-        const long slots = (long)device_cus() * per_cu, tiles = (long)ntx * nty;
+        const long slots = (long)max(8, device_cus() - a.cus_off) * per_cu, tiles = (long)ntx * nty;
         const int want = kz - 90;
         const int cmax = max(1, nk / (6 * NL));              // short chunks are mostly pipeline fill (2(NL−1) steps each)
         long best_c = 1;
@@ -2948,7 +2949,7 @@ static hipError_t launch_sweepD(hipStream_t s, SweepArgs<T> &a, int kz)
         const int ntx = max(1, (a.nx - 2 - OV + (TX - OV) - 1) / (TX - OV)), nty = max(1, (a.ny - 2 - OV + (TY - OV) - 1) / (TY - OV));
         if (kz <= 0 || kz > 90) {
             static const int per_cu = workgroups_per_cu((const void *)k_pt_sweepD<T, NL, WY, CPT, NSL, UNR, OPT>, 64 * WY);
-            const long slots = (long)device_cus() * per_cu, tiles = (long)ntx * nty;
+            const long slots = (long)max(8, device_cus() - a.cus_off) * per_cu, tiles = (long)ntx * nty;
             const int cmax = max(1, nk / (6 * NL));
             long best_c = 1, best_cost = -1;
             for (long c = 1; c <= cmax && c <= 64; ++c) {
@@ -2992,6 +2993,7 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
     a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = 0; a.zhi_halo = 0;
     a.k0 = k0; a.k1 = k1; a.kz = 1;
     a.l1_bc = (pass_flags & NS3D_PASS_INPUT_OBEYS_BC) ? 1 : 0; a.no_faces = (pass_flags & NS3D_PASS_SKIP_FACES) ? 1 : 0;
+    a.cus_off = ((pass_flags >> 8) & 0xff) * 8;
     if (k1 <= k0) return hipSuccess;
     int shape = variant / 100, kz = variant % 100;
     // built-in: 64×32 columns, next step's loads issued before level 1 (measured best at 512³ for three levels); four levels
@@ -3065,6 +3067,7 @@ hipError_t pt_sweep2(hipStream_t s, int variant, const T *Pin, T *Pout, const T 
     a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = 0; a.zhi_halo = 0;
     a.k0 = k0; a.k1 = k1; a.kz = 1;
     a.l1_bc = (pass_flags & NS3D_PASS_INPUT_OBEYS_BC) ? 1 : 0; a.no_faces = (pass_flags & NS3D_PASS_SKIP_FACES) ? 1 : 0;
+    a.cus_off = ((pass_flags >> 8) & 0xff) * 8;
     if (k1 <= k0) return hipSuccess;
     int shape = variant / 100;
     int kz = variant % 100;
@@ -3318,7 +3321,7 @@ hipError_t pt_persist(hipStream_t s, const T *Pin, T *Pout, T *D, const T *RHS, 
     a.outlet_val = (T)p.outlet_val; a.rho_g = (T)p.rho * (T)p.g;
     a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
     a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = 0; a.zhi_halo = 0;
-    a.k0 = 1; a.k1 = p.nz - 1; a.kz = 1; a.l1_bc = 0; a.no_faces = 0;
+    a.k0 = 1; a.k1 = p.nz - 1; a.kz = 1; a.l1_bc = 0; a.no_faces = 0; a.cus_off = 0;
     // the iteration is arithmetic on the CUs the grid occupies plus one hand-over: the smallest workgroup the chip still holds
     // all at once spreads the cells over the most CUs.  NS3D_PERSIST_SHAPE=22|42|44 pins a shape (A/B).
     static const int pin = std::getenv("NS3D_PERSIST_SHAPE") ? std::atoi(std::getenv("NS3D_PERSIST_SHAPE")) : 0;
@@ -3342,7 +3345,7 @@ hipError_t pt_sweep(hipStream_t s, int variant, const T *Pin, T *Pout, T *D, con
     a.outlet_val = (T)p.outlet_val; a.rho_g = (T)p.rho * (T)p.g;
     a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
     a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = p.z_lo_is_halo; a.zhi_halo = p.z_hi_is_halo;
-    a.k0 = k0; a.k1 = k1; a.kz = 1; a.l1_bc = 0; a.no_faces = 0;
+    a.k0 = k0; a.k1 = k1; a.kz = 1; a.l1_bc = 0; a.no_faces = 0; a.cus_off = 0;
     if (k1 <= k0) return hipSuccess;
     // variant = family*100 + kz  (kz = planes marched per block; 0 → default); variant 0 = choose by grid size:
     // grids whose four PT arrays stay resident in L2 / Infinity Cache run best with one thread per cell (neighbours are

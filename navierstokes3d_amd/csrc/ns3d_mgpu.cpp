@@ -114,6 +114,8 @@ struct MRank {
     hipStream_t comm = nullptr;                    // halo traffic (high priority)
     hipEvent_t ev_ready = nullptr, ev_landed = nullptr;
     hipEvent_t ev_pass = nullptr;                  // slab_pass: everything the compute stream held when the pass began
+    int plan_v2 = -1, plan_vn = -1;                // tile shapes ns3d_slab_plan / box_plan measured for this rank's interior sweeps
+    int plan_lo = 0, plan_hi = 0;                  // … and the plane range they were measured on (sub-ranges of it use them too)
     SlabState st;
     void *cbuf = nullptr;                          // solve_cart: the second pressure buffer
     size_t cbuf_bytes = 0;
@@ -141,6 +143,7 @@ struct ns3d_mgpu {
     int rccl_ranks = 0;
     int depth = 4;                // most PT iterations a pass may advance = ghost depth + 1 (1: single sweeps, plain one-plane halo)
     bool serial_seams = false;    // A/B switch (NS3D_SLAB_SERIAL_SEAMS=1): the round-2 schedule, seam sweeps ahead of the interior on one stream
+    int interior_chunks = 1;      // ns3d_mgpu_set_interior_chunks: launches the interior sweep of a z-slab pass is cut into
     int pass_depth = 2;           // iterations per pass actually used (ns3d_slab_plan may raise it to `depth`; same on every rank)
     // loaded solve
     bool loaded = false;
@@ -297,6 +300,7 @@ ns3d_mgpu *new_mgpu(const int *dims, int nx, int ny, int nz, int flags, const ch
     if (const char *ev = std::getenv("NS3D_SLAB_DEPTH")) m->depth = std::max(1, std::min(4, std::atoi(ev)));
     m->pass_depth = std::min(2, m->depth);
     if (const char *ev = std::getenv("NS3D_SLAB_SERIAL_SEAMS")) m->serial_seams = std::atoi(ev) != 0;
+    if (const char *ev = std::getenv("NS3D_SLAB_INTERIOR_CHUNKS")) m->interior_chunks = std::max(1, std::min(16, std::atoi(ev)));
     return m;
 }
 
@@ -374,9 +378,11 @@ int slab_pass(ns3d_mgpu *m, int its)
         const ns3d_pt_params pe = ext_params(m, r);
         ns3d_device_guard g(r.device);
         hipError_t e;
-        if (its >= 2)
+        if (its >= 2) {
+            const bool planned = a >= r.plan_lo && b <= r.plan_hi;              // the interior (or a chunk of it): the rank's own plan
             e = ns3d_enqueue_pass<T>(r.ctx, st, its, (const T *)r.st.P[ip], (T *)r.st.P[ip ^ 1], (const T *)r.st.D[idd],
-                                     (T *)r.st.D[idd_out], (const T *)r.st.R, &pe, a, b);
+                                     (T *)r.st.D[idd_out], (const T *)r.st.R, &pe, a, b, planned ? r.plan_v2 : -1, planned ? r.plan_vn : -1);
+        }
         else
             e = ns3d_enqueue_pt1<T>(r.ctx, st, (const T *)r.st.P[ip], (T *)r.st.P[ip ^ 1], (T *)r.st.D[idd],
                                     (const T *)r.st.R, &pe, a, b);
@@ -403,8 +409,14 @@ int slab_pass(ns3d_mgpu *m, int its)
     std::vector<std::vector<Block>> blocks;
     for (MRank &r : m->loc) blocks.push_back(ghost_blocks<T>(m, r, ip ^ 1, idd_out));
     if ((rc = exchange_begin(m, blocks, 2, split))) return rc;
-    for (size_t l = 0; l < m->loc.size(); ++l)
-        if ((rc = sweep(m->loc[l], compute(m->loc[l]), rng[l].lo_end, rng[l].hi_beg))) return rc;
+    // the interior, in `interior_chunks` launches over consecutive plane ranges while an exchange is pending (ns3d.h: a kernel of the
+    // exchange finds CUs at the latest when a chunk ends; every chunk pays its own pipeline fill, so one launch unless asked)
+    for (size_t l = 0; l < m->loc.size(); ++l) {
+        const int a = rng[l].lo_end, b = rng[l].hi_beg;
+        const int nch = (m->P > 1 && b - a >= 8 * m->interior_chunks) ? m->interior_chunks : 1;
+        for (int q = 0; q < nch; ++q)
+            if ((rc = sweep(m->loc[l], compute(m->loc[l]), a + (int)((long)(b - a) * q / nch), a + (int)((long)(b - a) * (q + 1) / nch)))) return rc;
+    }
     if ((rc = exchange_end(m))) return rc;
     for (MRank &r : m->loc) { r.st.ip = ip ^ 1; r.st.id = idd_out; }
     return NS3D_OK;
@@ -510,6 +522,7 @@ int slab_load(ns3d_mgpu *m, const T *const *Pr, const T *const *D, const T *cons
                                      e.plane * sizeof(T), hipMemcpyDeviceToDevice, s));
         }
     }
+    for (MRank &r : m->loc) { r.plan_v2 = r.plan_vn = -1; r.plan_lo = r.plan_hi = 0; }      // a new state: planned again by ns3d_slab_plan
     m->loaded = true;
     // deep ghosts of the incoming state — and of the right-hand side: level 1 on a ghost plane needs ∇V there, one or two
     // planes beyond the one-plane halo the caller's update_halo!(∇V) filled (that plane is re-sent too: same value)
@@ -586,6 +599,7 @@ int slab_plan(ns3d_mgpu *m)
             const int d = ns3d_plan_pt_internal<T>(r.ctx, (const T *)r.st.P[r.st.ip], (T *)r.st.P[r.st.ip ^ 1],
                                                    (const T *)r.st.D[r.st.id], (T *)r.st.D[r.st.id ^ 1], (const T *)r.st.R, &pe, a, b);
             r.ctx->pt_depth = pinned;
+            r.plan_v2 = ns3d_last_pt2_variant(r.ctx); r.plan_vn = ns3d_last_ptn_variant(r.ctx); r.plan_lo = a; r.plan_hi = b;
             depth = std::min(depth, std::max(2, d));
         }
     }
@@ -1062,7 +1076,7 @@ int box_pass(ns3d_mgpu *m, int its)
         hipError_t e;
         if (its >= 2)
             e = ns3d_enqueue_pass<T>(r.ctx, compute(r), its, (const T *)r.st.P[ip], (T *)r.st.P[ip ^ 1], (const T *)r.st.D[idd],
-                                     (T *)r.st.D[idd_out], (const T *)r.st.R, &pe, 1, pe.nz - 1);
+                                     (T *)r.st.D[idd_out], (const T *)r.st.R, &pe, 1, pe.nz - 1, r.plan_v2, r.plan_vn);
         else
             e = ns3d_enqueue_pt1<T>(r.ctx, compute(r), (const T *)r.st.P[ip], (T *)r.st.P[ip ^ 1], (T *)r.st.D[idd], (const T *)r.st.R,
                                     &pe, 1, pe.nz - 1);
@@ -1092,6 +1106,7 @@ int box_plan(ns3d_mgpu *m)
             const int d = ns3d_plan_pt_internal<T>(r.ctx, (const T *)r.st.P[r.st.ip], (T *)r.st.P[r.st.ip ^ 1], (const T *)r.st.D[r.st.id],
                                                    (T *)r.st.D[r.st.id ^ 1], (const T *)r.st.R, &pe, 1, pe.nz - 1);
             r.ctx->pt_depth = pinned;
+            r.plan_v2 = ns3d_last_pt2_variant(r.ctx); r.plan_vn = ns3d_last_ptn_variant(r.ctx);
             depth = std::min(depth, std::max(2, d));
         }
     const int rc = agree_min_depth(m, depth);
@@ -1488,6 +1503,22 @@ int ns3d_mgpu_rccl_ranks(const ns3d_mgpu *m) { return m ? m->rccl_ranks : -1; }
 int ns3d_mgpu_pass_depth(const ns3d_mgpu *m) { return m ? m->pass_depth : -1; }
 int ns3d_mgpu_ghost_depth(const ns3d_mgpu *m) { return (m && m->loaded) ? m->G : -1; }
 
+int ns3d_mgpu_reserve_cus(ns3d_mgpu *m, int n_cus)
+{
+    CHECK_M(m);
+    for (MRank &r : m->loc) {
+        const int rc = ns3d_reserve_cus(r.ctx, n_cus);
+        if (rc) return rc;
+    }
+    return NS3D_OK;
+}
+int ns3d_mgpu_set_interior_chunks(ns3d_mgpu *m, int chunks)
+{
+    CHECK_M(m);
+    if (chunks < 1 || chunks > 16) return fail(NS3D_ERR_ARG, "ns3d_mgpu_set_interior_chunks: %d (1 … 16)", chunks);
+    m->interior_chunks = chunks;
+    return NS3D_OK;
+}
 int ns3d_mgpu_set_temporal(ns3d_mgpu *m, int depth)
 {
     CHECK_M(m);

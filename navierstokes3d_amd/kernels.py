@@ -98,6 +98,19 @@ class Context:
     def sync(self):
         L.check(self.lib.ns3d_sync(self.handle))
 
+    def reserve_cus(self, n):
+        """Leave n compute units out of this context's launches (ns3d_reserve_cus: a stream with a CU mask, so that RCCL's kernels
+        find room beside a sweep that would hold every CU).  Returns the stream as a torch stream — tensor work that must be
+        ordered with the kernels belongs on it (`with torch.cuda.stream(s): …`); n = 0 goes back to PyTorch's current stream."""
+        L.check(self.lib.ns3d_reserve_cus(self.handle, int(n)))
+        if int(n) <= 0:
+            self._ext = None
+            self.use_torch_stream()
+            return torch.cuda.current_stream(self.device)
+        self._ext = torch.cuda.ExternalStream(int(self.lib.ns3d_get_stream(self.handle)), device=self.device)
+        self._pinned, self._stream = True, self._ext.cuda_stream
+        return self._ext
+
     def set_pt_variant(self, v):
         L.check(self.lib.ns3d_set_pt_variant(self.handle, int(v)))
 

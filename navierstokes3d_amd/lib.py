@@ -68,7 +68,7 @@ SIGNATURES = {
     "pt_solve": [_P] * 3 + [C.POINTER(PtParams), _D, _I, _I, _D, _D, C.POINTER(_I), C.POINTER(_D), _I, C.POINTER(_I)],
 }
 CONTEXT_SYMBOLS = ["ns3d_version", "ns3d_last_error", "ns3d_create", "ns3d_destroy", "ns3d_flags",
-                   "ns3d_set_stream", "ns3d_use_own_stream", "ns3d_get_stream", "ns3d_sync", "ns3d_set_pt_variant",
+                   "ns3d_set_stream", "ns3d_use_own_stream", "ns3d_get_stream", "ns3d_sync", "ns3d_reserve_cus", "ns3d_reserved_cus", "ns3d_set_pt_variant",
                    "ns3d_set_pt2_variant", "ns3d_set_ptn_variant", "ns3d_set_pt_depth", "ns3d_set_pt_pass_flags", "ns3d_set_pass_chain", "ns3d_set_graph_mode", "ns3d_set_autotune", "ns3d_last_pt2_variant", "ns3d_last_ptn_variant", "ns3d_last_pt_depth",
                    "ns3d_arith_build", "ns3d_cached_graphs", "ns3d_set_persist_mode"]
 
@@ -79,6 +79,8 @@ MGPU_SYMBOLS = {
     "ns3d_mgpu_create": (_P, [_I, C.POINTER(_I), _I, _I, _I, _I]),
     "ns3d_mgpu_create_cart": (_P, [C.POINTER(_I), C.POINTER(_I), _I, _I, _I, _I]),
     "ns3d_dims_create": (_I, [_I, C.POINTER(_I)]),
+    "ns3d_mgpu_reserve_cus": (_I, [_P, _I]),
+    "ns3d_mgpu_set_interior_chunks": (_I, [_P, _I]),
     "ns3d_mgpu_unique_id": (_I, [C.c_char_p]),
     "ns3d_mgpu_create_rank": (_P, [_I, _I, _I, C.c_char_p, _I, _I, _I, _I]),
     "ns3d_mgpu_create_rank_cart": (_P, [C.POINTER(_I), _I, _I, C.c_char_p, _I, _I, _I, _I]),
@@ -146,6 +148,8 @@ def load():
     lib.ns3d_get_stream.restype = _P
     lib.ns3d_get_stream.argtypes = [_P]
     lib.ns3d_sync.argtypes = [_P]
+    lib.ns3d_reserve_cus.argtypes = [_P, _I]
+    lib.ns3d_reserved_cus.argtypes = [_P]
     lib.ns3d_set_pt_variant.argtypes = [_P, _I]
     lib.ns3d_set_pt2_variant.argtypes = [_P, _I]
     lib.ns3d_set_ptn_variant.argtypes = [_P, _I]

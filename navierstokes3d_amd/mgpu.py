@@ -212,6 +212,15 @@ class MultiGpu:
                                                 C.c_double(dt), C.c_double(dx), C.c_double(dy), C.c_double(dz), 1 if faithful else 0))
 
     # ---- pseudo-transient loop of the z-slab ranks -------------------------------------------------------------
+    def reserve_cus(self, n):
+        """ns3d_mgpu_reserve_cus: every local rank's compute launches leave n compute units to the exchange's kernels.  Returns the
+        ranks' compute streams (torch streams) — order tensor work with them."""
+        return [c.reserve_cus(n) for c in self.contexts]
+
+    def set_interior_chunks(self, chunks):
+        """ns3d_mgpu_set_interior_chunks: the interior sweep of a z-slab pass in `chunks` launches (1: one)."""
+        L.check(self.lib.ns3d_mgpu_set_interior_chunks(self.handle, int(chunks)))
+
     def set_temporal(self, depth):
         L.check(self.lib.ns3d_mgpu_set_temporal(self.handle, int(depth)))
 

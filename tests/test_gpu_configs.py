@@ -4,7 +4,9 @@ configs[3] "512×512×1024 cylinder, 2- and 4-GPU z-slab decomposition": Implici
 1024 reachable for P = 2 (two slabs of 512×512×513) and not for P = 4 (257.5 planes) — the 4-slab case runs at its nearest
 shape, 512×512×258 per rank = 1026 global (SURVEY.md §8d Config 4).  The ranks are virtual ranks of ONE process on device 0
 (ns3d_mgpu_create): the schedule, events and peer copies are those of the multi-GPU node, only the link is not xGMI.
-configs[4]'s one-GPU point (1024³) is tests/test_gpu_pt.py::test_full_size_1024_cubed_properties.
+configs[4] "1024³, 8×MI355X": its decomposition — eight z-slabs of 1024×1024×130, fp32 and fp64 — and the 512³ strong-scaling shape
+(eight of 512×512×66) run here as eight virtual ranks (round 4); its one-GPU point (1024³) is
+tests/test_gpu_pt.py::test_full_size_1024_cubed_properties.
 configs[1] (255×153×153) uncapped: one full second time step, 2 280 PT iterations, against the oracle."""
 import numpy as np
 import pytest
@@ -54,6 +56,60 @@ def test_config_D_slabs_equal_global_poisson_solve(hip, P, nz_loc):
         assert torch.equal(D[r].view(torch.int64), Dg[:, :, lo:lo + nz_loc - 2].view(torch.int64)), "dPrdτ of rank %d" % r
     assert res == hip.residual_max(Pg, Rg, pg, ctx=ctx)
     ctx.close()
+    mg.close()
+
+
+@pytest.mark.parametrize("own_streams", [False, True])
+@pytest.mark.parametrize("n,nz_loc,dtype", [(1024, 130, "f32"), (1024, 130, "f64"), (512, 66, "f64")])
+def test_config_E_eight_z_slabs_equal_global_poisson_solve(hip, n, nz_loc, dtype, own_streams):
+    """configs[4]'s decomposition: EIGHT z-slab ranks (scripts/runme3D.sh:18 `srun -n8`; multi.jl:325,458-471) — 8 × 1024×1024×130
+    (nz_g = 8·128+2 = 1026: ImplicitGlobalGrid cannot make exactly 1024 from eight slabs, SURVEY §8d Config 5) in fp64 and fp32, and
+    the 512³ strong-scaling shape 8 × 512×512×66 (nz_g = 514).  Eight virtual ranks of ONE process on device 0, each with its own
+    communication stream (and, `own_streams`, its own non-blocking compute stream, so that the ready/landed events carry the ordering
+    as between devices): slab_load / plan / iterate(9) / residual / store — six interior ranks with TWO seams each, the ranks'
+    agreement on the pass depth, the ghost shrink after planning — against ns3d_pt_iterate on the global grid, every local plane,
+    halo planes included, compared on the device (≈115 GB of HBM in the fp64 1024² case with the library's ghost-extended buffers)."""
+    import torch
+    from navierstokes3d_amd.mgpu import MultiGpu
+    from util import geometry
+    P = 8
+    nx = ny = n
+    nz_g = P * (nz_loc - 2) + 2
+    tdt, bits = (torch.float64, torch.int64) if dtype == "f64" else (torch.float32, torch.int32)
+    g = geometry(nx, ny, nz_g)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(8128)
+
+    def rnd_dev(*shape):
+        t = hip.zeros(shape, tdt)
+        t.permute(2, 1, 0).uniform_(-1.0, 1.0, generator=gen)
+        return t
+
+    Pg, Dg, Rg = rnd_dev(nx, ny, nz_g), rnd_dev(nx - 2, ny - 2, nz_g - 2), rnd_dev(nx, ny, nz_g)
+    cut = lambda A, lo, m: hip.clone(A[:, :, lo:lo + m])
+    Pr = [cut(Pg, r * (nz_loc - 2), nz_loc) for r in range(P)]
+    D = [cut(Dg, r * (nz_loc - 2), nz_loc - 2) for r in range(P)]
+    R = [cut(Rg, r * (nz_loc - 2), nz_loc) for r in range(P)]
+    ctx = hip.Context(0, "strict")
+    pg = hip.pt_params(Pg, g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, True, 0.25, 0.0)
+    hip.pt_iterate(Pg, Dg, Rg, pg, 9, ctx=ctx)
+    ref_res = hip.residual_max(Pg, Rg, pg, ctx=ctx)
+    ctx.sync()
+    ctx.close()
+    torch.cuda.empty_cache()
+    mg = MultiGpu.create([0] * P, nx, ny, nz_loc, "strict", own_streams=own_streams)
+    p = hip.pt_params(Pr[0], g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, True, 0.25, 0.0)
+    mg.slab_load(Pr, D, R, p)
+    depth = mg.slab_plan()
+    assert 1 <= depth <= (5 if dtype == "f32" else 4) and mg.ghost_depth() == depth - 1
+    mg.slab_iterate(9)
+    res = mg.slab_residual()
+    mg.slab_store(Pr, D)
+    mg.sync()
+    for r in range(P):
+        lo = r * (nz_loc - 2)
+        assert torch.equal(Pr[r].view(bits), Pg[:, :, lo:lo + nz_loc].view(bits)), "Pr of rank %d" % r
+        assert torch.equal(D[r].view(bits), Dg[:, :, lo:lo + nz_loc - 2].view(bits)), "dPrdτ of rank %d" % r
+    assert res == ref_res
     mg.close()
 
 

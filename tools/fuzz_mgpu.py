@@ -20,7 +20,8 @@ from navierstokes3d_amd import kernels as K  # noqa: E402
 from navierstokes3d_amd.mgpu import MultiGpu  # noqa: E402
 from util import fields, geometry  # noqa: E402
 
-DIMS = [(1, 1, 2), (1, 1, 3), (2, 1, 1), (1, 2, 1), (2, 2, 1), (2, 1, 2), (1, 2, 2), (2, 2, 2), (3, 1, 1), (1, 3, 1), (3, 2, 1), (1, 1, 4)]
+DIMS = [(1, 1, 2), (1, 1, 3), (2, 1, 1), (1, 2, 1), (2, 2, 1), (2, 1, 2), (1, 2, 2), (2, 2, 2), (3, 1, 1), (1, 3, 1), (3, 2, 1), (1, 1, 4),
+        (1, 1, 8), (1, 1, 8), (1, 1, 6), (2, 1, 4)]      # eight z-slabs: scripts/runme3D.sh:18, BASELINE configs[4]
 
 
 def coords(r, dims):
