@@ -141,8 +141,13 @@ int ns3d_set_graph_mode(ns3d_ctx *ctx, int mode);
  * cooperative launch that keeps the grid on the chip (k_pt_persist: a cell per thread, faces handed between workgroups through
  * global memory after every iteration): -1 = automatically where it was measured to win (up to 170 000 cells, nx <= 66, no
  * explicit depth / tile / graph request) and the workgroups fit the chip together, 0 = never, 1 = wherever they fit.  Same
- * results either way; a hand-over that never arrives (bounded wait) leaves NaN in Pr and d.  Env NS3D_PT_PERSIST sets the default. */
+ * results either way.  A hand-over that never arrives (bounded wait: the workgroups were not all resident at once — another context
+ * or process holding CUs) voids that launch only: it writes its outputs to buffers of its own, the library reads the launch's error
+ * word where it synchronises anyway (the residual read-back of ns3d_pt_solve; ns3d_pt_iterate synchronises once for it), redoes
+ * the block by launches from the untouched inputs and leaves the cooperative form off for this context; ns3d_persist_faults counts
+ * such launches.  (NS3D_COOP_CHECK=1: the launch itself blocks, checks and fails with NS3D_ERR_HIP instead.)  Env NS3D_PT_PERSIST sets the default. */
 int ns3d_set_persist_mode(ns3d_ctx *ctx, int mode);
+int ns3d_persist_faults(const ns3d_ctx *ctx);
 int ns3d_cached_graphs(const ns3d_ctx *ctx);      /* residual-check blocks this context holds as instantiated HIP graphs */
 
 /* Parameters of the fused pseudo-transient path (ns3d_pt_iterate / ns3d_pt_solve). */

@@ -152,6 +152,8 @@ void ns3d_destroy(ns3d_ctx *c)
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     c->clear_graphs();
     if (c->persist.H) (void)hipFree(c->persist.H);
+    if (c->persist.err_host) (void)hipHostFree(c->persist.err_host);
+    if (c->persist.ev) (void)hipEventDestroy(c->persist.ev);
     if (c->direct_plan && c->direct_free) c->direct_free(c->direct_plan);
     if (c->fence) (void)hipEventDestroy(c->fence);
     for (int q = 0; q < 2; ++q)
@@ -268,6 +270,7 @@ int ns3d_set_ptn_variant(ns3d_ctx *c, int v)
     return NS3D_OK;
 }
 
+int ns3d_persist_faults(const ns3d_ctx *c) { return c ? (int)c->persist.faults : -1; }
 int ns3d_set_pt_pass_flags(ns3d_ctx *c, int flags)
 {
     if (!c) return fail(NS3D_ERR_ARG, "ns3d_set_pt_pass_flags: null context");
@@ -309,6 +312,20 @@ static int fetch_key(ns3d_ctx *c, hipStream_t s, double *out)
     std::memcpy(&v, c->key_host, sizeof v);
     *out = v;
     return NS3D_OK;
+}
+
+// After a synchronisation of the stream the persist launches ran on: did a bounded wait expire in any of them since the last check?
+// (k_pt_persist writes its ticket into pinned host memory when one does.)  A failure turns the cooperative form off for this context:
+// what made the workgroups non-resident — another context or process holding CUs — is unlikely to have gone away.
+static bool persist_failed(ns3d_ctx *c)
+{
+    ns3d_persist_state &ps = c->persist;
+    if (!ps.err_host || ps.checked == ps.ticket) return false;
+    const unsigned seen = *(volatile unsigned *)ps.err_host;
+    const bool failed = seen != 0u && (int)(seen - ps.checked) > 0 && (int)(seen - ps.ticket) <= 0;
+    ps.checked = ps.ticket;
+    if (failed) { ++ps.faults; c->persist_mode = 0; }
+    return failed;
 }
 
 int ns3d_check_pt_params(const ns3d_pt_params *p, const char *fn)
@@ -701,8 +718,21 @@ static int pt_iterate_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_p
     T *dsrc = D, *ddst = nullptr;
     const bool two = use_two(c, p) && !p->z_lo_is_halo && !p->z_hi_is_halo && n_iters >= 2;
     if (two && (rc = ensure_pingpong_d<T>(c, p, &ddst))) return rc;
+    const unsigned ticket0 = c->persist.ticket;
     hipError_t e = enqueue_iters<T>(c, c->stream, n_iters, two, src, dst, dsrc, ddst, divV, p, true);
     if (e != hipSuccess) return fail(NS3D_ERR_HIP, "pt_sweep launch: %s", hipGetErrorString(e));
+    if (c->persist.ticket != ticket0) {
+        // the block ran as ONE cooperative launch: before its result replaces the caller's arrays, make sure no hand-over timed out
+        // (a stream synchronisation: these are launch-bound grids, the wait is the block itself); if one did, the inputs are
+        // untouched — redo the block by launches (the cooperative form is off for this context from here on)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (persist_failed(c)) {
+            src = Pr; dst = other; dsrc = D; ddst = nullptr;
+            if (two && (rc = ensure_pingpong_d<T>(c, p, &ddst))) return rc;
+            e = enqueue_iters<T>(c, c->stream, n_iters, two, src, dst, dsrc, ddst, divV, p, true);
+            if (e != hipSuccess) return fail(NS3D_ERR_HIP, "pt_sweep launch: %s", hipGetErrorString(e));
+        }
+    }
     if (dsrc != D)
         HIPCHK(c, hipMemcpyAsync(D, dsrc, (size_t)(p->nx - 2) * (p->ny - 2) * (p->nz - 2) * sizeof(T),
                                  hipMemcpyDeviceToDevice, c->stream));
@@ -720,9 +750,16 @@ static hipError_t enqueue_iters(ns3d_ctx *c, hipStream_t s, int n, bool two, T *
     hipError_t e = hipSuccess;
     // small grids: the whole block of n iterations in one cooperative launch (k_pt_persist), where it applies
     if (n >= 2 && use_persist<T>(c, p)) {
-        e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_persist<T>(s, src, dst, dsrc, divV, *p, n, &c->persist));
+        // outputs in buffers of their own (dPrdτ too): a launch whose bounded waits expire — its workgroups were not all resident at
+        // once: another context or process on the device — leaves the block's inputs intact, and whoever synchronises the stream
+        // next (persist_failed below) redoes the block by launches
+        T *dout = ddst;
+        if (!dout && ensure_pingpong_d<T>(c, p, &dout) != NS3D_OK) return hipErrorOutOfMemory;
+        e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_persist<T>(s, src, dst, dsrc, dout, divV, *p, n, &c->persist));
         if (e == hipSuccess) {
             T *t = src; src = dst; dst = t;
+            if (ddst) { t = dsrc; dsrc = ddst; ddst = t; }
+            else { ddst = dsrc; dsrc = dout; }       // the caller had no second dPrdτ buffer: it has one now (copied back at the end)
             return e;
         }
         if (e != hipErrorInvalidValue) return e;     // invalid value: the form does not apply here → the ordinary path
@@ -817,7 +854,7 @@ static bool use_persist(const ns3d_ctx *c, const ns3d_pt_params *p)
         // where it was measured to win (profiles/r3_persist_ab.log): up to ≈170 000 cells, one workgroup across x
         if ((long long)p->nx * p->ny * p->nz > 170ll * 1000 || p->nx > 66) return false;
     }
-    const hipError_t e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_persist<T>(nullptr, nullptr, nullptr, nullptr, nullptr, *p, 2, nullptr));
+    const hipError_t e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_persist<T>(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, *p, 2, nullptr));
     if (e != hipSuccess) (void)hipGetLastError();
     return e == hipSuccess;                                         // the chip holds the whole grid at once
 }
@@ -841,6 +878,7 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
     const size_t plane = (size_t)p->nx * p->ny;
     T *src = Pr, *dst = other;
     int checks = 0, iter = 0, done = niter;
+    bool converged = false;
     const bool two = use_two(c, p) && niter >= 2;
     T *dsrc = D, *ddst = nullptr;
     if (two && (rc = ensure_pingpong_d<T>(c, p, &ddst))) return rc;
@@ -859,6 +897,8 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
     while (iter < niter) {
         // iterations until the next residual check (multi.jl:464) or the end of the budget
         const int n = nchk > 0 ? std::min(nchk - iter % nchk, niter - iter) : niter - iter;
+        T *const in_src = src, *const in_dst = dst, *const in_dsrc = dsrc, *const in_ddst = ddst;     // the block's inputs
+        const unsigned ticket0 = c->persist.ticket;
         if (graphs && n == nchk) {
             if ((rc = run_block_graph<T>(c, s, n, two, src, dst, dsrc, ddst, divV, p))) return rc;
         } else {
@@ -866,16 +906,31 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
             if (e != hipSuccess) return fail(NS3D_ERR_HIP, "pt_sweep launch: %s", hipGetErrorString(e));
         }
         iter += n;
-        if (nchk > 0 && iter % nchk == 0) { // multi.jl:464-469
-            hipError_t e = DISPATCHG(c, p->dx, p->dy, p->dz, residual_max_key<T>(s, src, divV, *p, c->key_dev));
-            if (e != hipSuccess) return fail(NS3D_ERR_HIP, "residual launch: %s", hipGetErrorString(e));
-            double mx;
-            if ((rc = fetch_key(c, s, &mx))) return rc;
+        const bool check_now = nchk > 0 && iter % nchk == 0;
+        if (c->persist.ticket != ticket0 && !check_now) HIPCHK(c, hipStreamSynchronize(s));     // a last, partial block: no read-back follows
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            double mx = 0.0;
+            if (check_now) { // multi.jl:464-469
+                hipError_t e = DISPATCHG(c, p->dx, p->dy, p->dz, residual_max_key<T>(s, src, divV, *p, c->key_dev));
+                if (e != hipSuccess) return fail(NS3D_ERR_HIP, "residual launch: %s", hipGetErrorString(e));
+                if ((rc = fetch_key(c, s, &mx))) return rc;
+            }
+            // the read-back synchronised the stream: if the block ran as one cooperative launch and a hand-over in it timed out, its
+            // inputs are still there — redo it by launches (once; the cooperative form is off for this context afterwards)
+            if (attempt == 0 && c->persist.ticket != ticket0 && persist_failed(c)) {
+                src = in_src; dst = in_dst; dsrc = in_dsrc; ddst = in_ddst;
+                hipError_t e = enqueue_iters<T>(c, s, n, two, src, dst, dsrc, ddst, divV, p, true);
+                if (e != hipSuccess) return fail(NS3D_ERR_HIP, "pt_sweep launch: %s", hipGetErrorString(e));
+                continue;
+            }
+            if (!check_now) break;
             const double err = mx * err_mul / err_div; // maximum(abs.(Rp))*ly^2/psc, multi.jl:466
             if (err_hist && checks < max_checks) err_hist[checks] = err;
             ++checks;
-            if (eps >= 0 && (err < eps || !std::isfinite(err))) { done = iter; break; }
+            if (eps >= 0 && (err < eps || !std::isfinite(err))) { done = iter; converged = true; }
+            break;
         }
+        if (converged) break;
     }
     if (src != Pr)
         HIPCHK(c, hipMemcpyAsync(Pr, src, plane * p->nz * sizeof(T), hipMemcpyDeviceToDevice, s));

@@ -3131,9 +3131,11 @@ template <class T>
 struct PersistArgs {
     SweepArgs<T> a;
     unsigned long long *H;
-    unsigned *err;
+    unsigned *err, *err_host;   // device word (read back by every thread at the end) and its pinned-host twin (read by the host)
     unsigned long long epoch;
+    unsigned ticket;            // this launch's number: what an expired wait leaves in the error words
     int nbx, nby, nbz, n_iters, xcds;
+    int fault;                  // test hook (NS3D_PERSIST_FAULT=1): workgroup 0 never publishes and the waits give up early
 };
 __device__ __forceinline__ unsigned long long xkey(unsigned long long id) { return (id + 1ull) * 0x9E3779B97F4A7C15ull; }
 __device__ __forceinline__ unsigned long long xbits(double v) { return (unsigned long long)__double_as_longlong(v); }
@@ -3146,16 +3148,21 @@ template <class T> __device__ __forceinline__ void xpublish(unsigned long long *
     __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(p + 1, w ^ key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-template <class T> __device__ __forceinline__ T xfetch(const unsigned long long *p, unsigned long long key, unsigned *err)
+template <class T, class PA> __device__ __forceinline__ T xfetch(const unsigned long long *p, unsigned long long key, const PA &pa)
 {
     unsigned long long w1 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long w2 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned spins = 0;
+    const unsigned limit = pa.fault ? (1u << 12) : (1u << 22);
     while ((w1 ^ w2) != key) {
         __builtin_amdgcn_s_sleep(1);
         w1 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         w2 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (++spins > (1u << 22)) { atomicOr(err, 1u); break; }
+        if (++spins > limit) {      // the neighbour never arrived (workgroups not resident together): this launch's result is void
+            atomicMax(pa.err, pa.ticket);
+            __hip_atomic_store(pa.err_host, pa.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
     }
     T v;
     xunbits(w1, v);
@@ -3193,7 +3200,7 @@ __global__ __launch_bounds__(64 * BY * BZ) void k_pt_persist(PersistArgs<T> pa)
     const int oyl = lz * BX + lx, oyh = FY + oyl, ozl = 2 * FY + ly * BX + lx, ozh = ozl + FZ, oxl = 2 * FY + 2 * FZ + lz * BY + ly, oxh = oxl + FX;
     unsigned long long *__restrict__ Hme = pa.H + 2 * (size_t)b * R * FACE;
     const int nbxy = pa.nbx * pa.nby;
-    T c = a.Pin[pc], d = a.D[dc];
+    T c = a.Pin[pc], d = a.Din[dc];      // dPrdτ goes to a buffer of its own: a launch whose waits expire leaves its inputs intact
     const T rv = a.RHS[pc];
     Lp[0][ctr] = c;
     // the initial halo: the cells beyond my faces as the input array holds them
@@ -3229,20 +3236,22 @@ __global__ __launch_bounds__(64 * BY * BZ) void k_pt_persist(PersistArgs<T> pa)
         if (!last) {
             const unsigned long long key = xkey(pa.epoch + (unsigned long long)it);
             unsigned long long *__restrict__ hp = Hme + 2 * (size_t)((it & (R - 1)) * FACE);
+            if (pa.fault && b == 0) { /* test hook: a workgroup that never hands its faces over */ } else {
             if (fyl) xpublish<T>(hp + 2 * oyl, c, key);
             if (fyh) xpublish<T>(hp + 2 * oyh, c, key);
             if (fzl) xpublish<T>(hp + 2 * ozl, c, key);
             if (fzh) xpublish<T>(hp + 2 * ozh, c, key);
             if (fxl) xpublish<T>(hp + 2 * oxl, c, key);
             if (fxh) xpublish<T>(hp + 2 * oxh, c, key);
+            }
             const size_t so = 2 * (size_t)((it & (R - 1)) * FACE);
             // my low-side halo ← the neighbour's high face and vice versa
-            if (fyl) ln[ctr - PX] = xfetch<T>(pa.H + 2 * (size_t)(b - pa.nbx) * R * FACE + so + 2 * oyh, key, pa.err);
-            if (fyh) ln[ctr + PX] = xfetch<T>(pa.H + 2 * (size_t)(b + pa.nbx) * R * FACE + so + 2 * oyl, key, pa.err);
-            if (fzl) ln[ctr - PX * PY] = xfetch<T>(pa.H + 2 * (size_t)(b - nbxy) * R * FACE + so + 2 * ozh, key, pa.err);
-            if (fzh) ln[ctr + PX * PY] = xfetch<T>(pa.H + 2 * (size_t)(b + nbxy) * R * FACE + so + 2 * ozl, key, pa.err);
-            if (fxl) ln[ctr - 1] = xfetch<T>(pa.H + 2 * (size_t)(b - 1) * R * FACE + so + 2 * oxh, key, pa.err);
-            if (fxh) ln[ctr + 1] = xfetch<T>(pa.H + 2 * (size_t)(b + 1) * R * FACE + so + 2 * oxl, key, pa.err);
+            if (fyl) ln[ctr - PX] = xfetch<T>(pa.H + 2 * (size_t)(b - pa.nbx) * R * FACE + so + 2 * oyh, key, pa);
+            if (fyh) ln[ctr + PX] = xfetch<T>(pa.H + 2 * (size_t)(b + pa.nbx) * R * FACE + so + 2 * oyl, key, pa);
+            if (fzl) ln[ctr - PX * PY] = xfetch<T>(pa.H + 2 * (size_t)(b - nbxy) * R * FACE + so + 2 * ozh, key, pa);
+            if (fzh) ln[ctr + PX * PY] = xfetch<T>(pa.H + 2 * (size_t)(b + nbxy) * R * FACE + so + 2 * ozl, key, pa);
+            if (fxl) ln[ctr - 1] = xfetch<T>(pa.H + 2 * (size_t)(b - 1) * R * FACE + so + 2 * oxh, key, pa);
+            if (fxh) ln[ctr + 1] = xfetch<T>(pa.H + 2 * (size_t)(b + 1) * R * FACE + so + 2 * oxl, key, pa);
         }
         __syncthreads();
         cur ^= 1;
@@ -3250,7 +3259,9 @@ __global__ __launch_bounds__(64 * BY * BZ) void k_pt_persist(PersistArgs<T> pa)
     if (act) {
         // a wait that expired anywhere in the grid: the result is not the iteration's — poison it, so that the residual norm of
         // the block is NaN and the caller sees a failed solve rather than a plausible field
-        if (__hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) c = d = (T)__builtin_nan("");
+        // (second line of defence: the host reads the error word at its next synchronisation and redoes the block by launches —
+        // ns3d_api.cpp persist_failed — from the inputs, which this launch did not touch)
+        if (__hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pa.ticket) c = d = (T)__builtin_nan("");
         a.D[dc] = d;
         store_with_bc<T>(a, gi, gj, gk, c);
     }
@@ -3261,10 +3272,14 @@ __global__ __launch_bounds__(64 * BY * BZ) void k_pt_persist(PersistArgs<T> pa)
 static hipError_t persist_scratch(ns3d_persist_state *st, hipStream_t s, size_t bytes)
 {
     hipError_t e;
-    if (st->used && st->stream != s && (e = hipStreamSynchronize(st->stream)) != hipSuccess) return e;
-    st->stream = s; st->used = true;
+    if (!st->ev) {
+        if ((e = hipEventCreateWithFlags(&st->ev, hipEventDisableTiming)) != hipSuccess) return e;
+        if ((e = hipHostMalloc((void **)&st->err_host, 64, hipHostMallocMapped)) != hipSuccess) return e;
+        *st->err_host = 0u;
+        if ((e = hipHostGetDevicePointer((void **)&st->err_host_dev, st->err_host, 0)) != hipSuccess) return e;
+    } else if ((e = hipStreamWaitEvent(s, st->ev, 0)) != hipSuccess) return e;      // the previous launch, whatever stream it ran on
     if (st->bytes < bytes) {
-        if (st->H) { if ((e = hipStreamSynchronize(s)) != hipSuccess) return e; (void)hipFree(st->H); st->H = nullptr; st->bytes = 0; }
+        if (st->H) { if ((e = hipEventSynchronize(st->ev)) != hipSuccess) return e; (void)hipFree(st->H); st->H = nullptr; st->bytes = 0; }
         if ((e = hipMalloc(&st->H, bytes + 64)) != hipSuccess) return e;
         if ((e = hipMemset(st->H, 0, bytes + 64)) != hipSuccess) return e;
         st->err = (unsigned *)((char *)st->H + bytes);
@@ -3294,28 +3309,34 @@ static hipError_t pt_persist_shape(hipStream_t s, const SweepArgs<T> &a, int n_i
     // NS3D_PERSIST_XCDMAP=1: contiguous runs of blocks per XCD instead of round-robin — measured slower (profiles/r3_persist_ab.log)
     static const bool remap = std::getenv("NS3D_PERSIST_XCDMAP") && *std::getenv("NS3D_PERSIST_XCDMAP") == '1';
     PersistArgs<T> pa;
-    pa.a = a; pa.H = (unsigned long long *)ps->H; pa.err = ps->err;
+    pa.a = a; pa.H = (unsigned long long *)ps->H; pa.err = ps->err; pa.err_host = ps->err_host_dev;
     pa.epoch = (++ps->launches) << 16;
+    pa.ticket = ++ps->ticket;
+    if (ps->ticket == 0u) pa.ticket = ps->ticket = 1u;       // 2³² launches later: tickets start over (0 means "never failed")
     pa.nbx = nbx; pa.nby = nby; pa.nbz = nbz; pa.n_iters = n_iters; pa.xcds = remap ? 8 : 1;
+    { const char *fv = std::getenv("NS3D_PERSIST_FAULT"); pa.fault = (fv && *fv == '1') ? 1 : 0; }      // read per launch: a test hook
     void *kargs[] = {(void *)&pa};
     e = hipLaunchCooperativeKernel((const void *)k_pt_persist<T, BY, BZ>, dim3((unsigned)blocks), dim3(BX, BY, BZ), kargs, 0, s);
     if (e != hipSuccess) return e;
-    static const bool check = std::getenv("NS3D_COOP_CHECK") && *std::getenv("NS3D_COOP_CHECK") == '1';
-    if (check) {
-        unsigned err = 0;
+    if ((e = hipEventRecord(ps->ev, s)) != hipSuccess) return e;
+    // NS3D_COOP_CHECK=1: check at once (blocking) and fail the launch instead of leaving the redo to the caller's next synchronisation
+    const char *cv = std::getenv("NS3D_COOP_CHECK");
+    if (cv && *cv == '1') {
         if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
-        if ((e = hipMemcpy(&err, ps->err, sizeof err, hipMemcpyDeviceToHost)) != hipSuccess) return e;
-        if (err) { (void)hipMemset(ps->err, 0, sizeof err); return hipErrorLaunchTimeOut; }
+        const bool failed = *(volatile unsigned *)ps->err_host == ps->ticket;
+        ps->checked = ps->ticket;
+        if (failed) { ++ps->faults; return hipErrorLaunchTimeOut; }
     }
     return hipSuccess;
 }
 
 template <class T>
-hipError_t pt_persist(hipStream_t s, const T *Pin, T *Pout, T *D, const T *RHS, const ns3d_pt_params &p, int n_iters, ns3d_persist_state *st)
+hipError_t pt_persist(hipStream_t s, const T *Pin, T *Pout, const T *Din, T *Dout, const T *RHS, const ns3d_pt_params &p, int n_iters,
+                      ns3d_persist_state *st)
 {
     if (n_iters < 1 || n_iters > 60000 || p.z_lo_is_halo || p.z_hi_is_halo) return hipErrorInvalidValue;
     SweepArgs<T> a;
-    a.Pin = Pin; a.Pout = Pout; a.D = D; a.Din = D; a.RHS = RHS;
+    a.Pin = Pin; a.Pout = Pout; a.D = Dout; a.Din = Din; a.RHS = RHS;
     a.g = make_geo<T>(p.dx, p.dy, p.dz);
     a.rho_dt = (T)p.rho / (T)p.dt; a.dtau = (T)p.dtau; a.one_m_damp = (T)1.0 - (T)p.damp;
     a.outlet_val = (T)p.outlet_val; a.rho_g = (T)p.rho * (T)p.g;
@@ -3506,7 +3527,7 @@ hipError_t divtest(hipStream_t s, double d, long n, unsigned long long seed, uns
                                   const T *, double, double, double, double, int, int, int, int, int, int);  \
     template hipError_t pt_sweep<T>(hipStream_t, int, const T *, T *, T *, const T *, const ns3d_pt_params &,\
                                     int, int);                                                               \
-    template hipError_t pt_persist<T>(hipStream_t, const T *, T *, T *, const T *, const ns3d_pt_params &, int, ns3d_persist_state *); \
+    template hipError_t pt_persist<T>(hipStream_t, const T *, T *, const T *, T *, const T *, const ns3d_pt_params &, int, ns3d_persist_state *); \
     template hipError_t pt_sweep2<T>(hipStream_t, int, const T *, T *, const T *, T *, const T *,            \
                                      const ns3d_pt_params &, int, int, int);                                 \
     template hipError_t pt_sweepn<T>(hipStream_t, int, int, const T *, T *, const T *, T *, const T *,       \

@@ -8,11 +8,16 @@
 // k_pt_persist's exchange area (face values handed between workgroups) and error word: owned by a context, freed with it
 struct ns3d_persist_state {
     void *H = nullptr;
-    unsigned *err = nullptr;
+    unsigned *err = nullptr;            // device word: ticket of the latest launch in which a bounded wait expired
+    unsigned *err_host = nullptr;       // the same, in pinned host memory the device writes straight into: the host reads it after any
+    unsigned *err_host_dev = nullptr;   //   synchronisation of the stream, without a copy (device-side address of err_host)
     size_t bytes = 0;
     unsigned long long launches = 0;    // key epoch: a launch never accepts a value an earlier one left in a slot
-    hipStream_t stream = nullptr;       // of the latest launch
-    bool used = false;
+    unsigned ticket = 0;                // number of the latest launch (what a failing launch leaves in the error words)
+    unsigned checked = 0;               // launches up to this ticket have been checked by the host
+    unsigned faults = 0;                // launches found failed (and redone by the launch-per-iteration path) so far
+    hipEvent_t ev = nullptr;            // recorded behind every launch: a launch on ANOTHER stream waits for it (two grids must
+                                        // not meet in the same slots) — no stream handle is kept
 };
 
 // k_subbox_copy: one cx·cy·cz block between two column-major arrays (pitches in elements), and a batch of them for one launch
@@ -77,8 +82,8 @@ struct ns3d_subbox_batch {
     hipError_t predict_fused(hipStream_t, T *, T *, T *, const T *, const T *, const T *, double mu, double rho, \
                              double g, double dt, double dx, double dy, double dz, int, int, int);           \
     template <class T>                                                                                       \
-    hipError_t pt_persist(hipStream_t, const T *, T *, T *, const T *, const ns3d_pt_params &, int n_iters,   \
-                          ns3d_persist_state *);                                                              \
+    hipError_t pt_persist(hipStream_t, const T *, T *, const T *, T *, const T *, const ns3d_pt_params &,    \
+                          int n_iters, ns3d_persist_state *);                                                 \
     template <class T>                                                                                       \
     hipError_t pt_sweep2(hipStream_t, int variant, const T *, T *, const T *, T *, const T *,                \
                          const ns3d_pt_params &, int k0, int k1, int pass_flags);                            \

@@ -123,6 +123,10 @@ class Context:
         -1 automatic (small grids), 0 never, 1 wherever it applies.  Same results."""
         L.check(self.lib.ns3d_set_persist_mode(self.handle, int(mode)))
 
+    def persist_faults(self):
+        """Cooperative launches (k_pt_persist) of this context in which a hand-over timed out; each was redone by launches."""
+        return int(self.lib.ns3d_persist_faults(self.handle))
+
     def set_autotune(self, on):
         """Time the tile shapes of the two-iteration sweep on the first launch per grid (default on; same results)."""
         L.check(self.lib.ns3d_set_autotune(self.handle, int(bool(on))))

@@ -70,7 +70,7 @@ SIGNATURES = {
 CONTEXT_SYMBOLS = ["ns3d_version", "ns3d_last_error", "ns3d_create", "ns3d_destroy", "ns3d_flags",
                    "ns3d_set_stream", "ns3d_use_own_stream", "ns3d_get_stream", "ns3d_sync", "ns3d_reserve_cus", "ns3d_reserved_cus", "ns3d_set_pt_variant",
                    "ns3d_set_pt2_variant", "ns3d_set_ptn_variant", "ns3d_set_pt_depth", "ns3d_set_pt_pass_flags", "ns3d_set_pass_chain", "ns3d_set_graph_mode", "ns3d_set_autotune", "ns3d_last_pt2_variant", "ns3d_last_ptn_variant", "ns3d_last_pt_depth",
-                   "ns3d_arith_build", "ns3d_cached_graphs", "ns3d_set_persist_mode"]
+                   "ns3d_arith_build", "ns3d_cached_graphs", "ns3d_set_persist_mode", "ns3d_persist_faults"]
 
 
 _PP = C.POINTER(C.c_void_p)      # T *const *  — one device pointer per local rank (field-major for field lists)
@@ -166,6 +166,8 @@ def load():
     lib.ns3d_last_pt_depth.restype = _I
     lib.ns3d_set_persist_mode.argtypes = [_P, _I]
     lib.ns3d_set_persist_mode.restype = _I
+    lib.ns3d_persist_faults.argtypes = [_P]
+    lib.ns3d_persist_faults.restype = _I
     lib.ns3d_cached_graphs.argtypes = [_P]
     lib.ns3d_cached_graphs.restype = _I
     lib.ns3d_arith_build.argtypes = [_P, _D, _D, _D]

@@ -1095,3 +1095,57 @@ def test_pt_iterate_chained_equals_unchained(hip, oracle, depth):
                 torch.cuda.synchronize()
                 assert np.array_equal(hip.to_numpy(dPr), Pr) and np.array_equal(hip.to_numpy(dd), d), (depth, n, chain, bc_kind)
                 ctx.close()
+
+
+def test_pt_persist_expired_hand_over_is_detected_and_the_block_redone(hip, oracle, monkeypatch):
+    """a cooperative block (k_pt_persist) in which a neighbour never arrives — forced here by NS3D_PERSIST_FAULT=1: workgroup 0
+    publishes nothing and the bounded waits give up early — must not come back as a plausible-looking or NaN field behind an OK status.
+    The launch writes to buffers of its own; ns3d_pt_solve (at its residual read-back) and ns3d_pt_iterate (one synchronisation)
+    find the launch's ticket in the error word, redo the block by launches from the untouched inputs and switch the cooperative form
+    off for the context: results equal the oracle's, ns3d_persist_faults says what happened.  With NS3D_COOP_CHECK=1 (how the rest of
+    the suite runs) the launch itself fails with an error code."""
+    import torch
+    from navierstokes3d_amd import lib as L
+    grid = (63, 38, 38)                              # BASELINE configs[0]: several workgroups in y and z
+    nx, ny, nz = grid
+    g = geometry(*grid)
+    Pr0, d0, rhs = fields(nx, ny, nz, ["c", "i", "c"], 101)
+    rhs *= 1e-3
+    drhs = hip.from_numpy(rhs)
+    bc = (0, True, 0.25)
+    Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
+    _oracle_iters(oracle, Pr, d, rhs, g, 9, *bc)
+    monkeypatch.setenv("NS3D_PERSIST_FAULT", "1")
+    # (1) the suite's default NS3D_COOP_CHECK=1: an error code, inputs untouched
+    ctx = hip.Context(0, "strict"); ctx.set_persist_mode(1)
+    dP, dD = hip.from_numpy(Pr0), hip.from_numpy(d0)
+    with pytest.raises(L.Ns3dError):
+        hip.pt_iterate(dP, dD, drhs, _params(hip, dP, g, *bc), 9, ctx=ctx)
+    torch.cuda.synchronize()
+    assert np.array_equal(hip.to_numpy(dP), Pr0) and np.array_equal(hip.to_numpy(dD), d0) and ctx.persist_faults() == 1
+    ctx.close()
+    # (2) the product's default: detected where the library synchronises, block redone by launches, same bits as the oracle
+    monkeypatch.setenv("NS3D_COOP_CHECK", "0")
+    ctx = hip.Context(0, "strict"); ctx.set_persist_mode(1)
+    dP, dD = hip.from_numpy(Pr0), hip.from_numpy(d0)
+    hip.pt_iterate(dP, dD, drhs, _params(hip, dP, g, *bc), 9, ctx=ctx)
+    torch.cuda.synchronize()
+    assert ctx.persist_faults() == 1
+    assert np.array_equal(hip.to_numpy(dP), Pr) and np.array_equal(hip.to_numpy(dD), d)
+    # … and the cooperative form stays off for this context: the next block runs by launches although the fault is still armed
+    hip.pt_iterate(dP, dD, drhs, _params(hip, dP, g, *bc), 5, ctx=ctx)
+    torch.cuda.synchronize()
+    assert ctx.persist_faults() == 1
+    ctx.close()
+    # (3) ns3d_pt_solve: the check rides on the residual read-back; counts and residual history equal a run without the cooperative form
+    res = []
+    for persist in (1, 0):
+        ctx = hip.Context(0, "strict"); ctx.set_persist_mode(persist); ctx.set_graph_mode(0)
+        dP, dD = hip.from_numpy(Pr0), hip.from_numpy(d0)
+        it, errs = hip.pt_solve(dP, dD, drhs, _params(hip, dP, g, *bc), -1.0, 45, 7, 0.36, 1000.0, ctx=ctx)
+        torch.cuda.synchronize()
+        res.append((it, errs, hip.to_numpy(dP), hip.to_numpy(dD), ctx.persist_faults()))
+        ctx.close()
+    assert res[0][4] == 1 and res[1][4] == 0
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and np.isfinite(res[0][1]).all()
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
