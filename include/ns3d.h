@@ -163,7 +163,38 @@ typedef struct ns3d_pt_params {
     int z_hi_is_halo;           /*   filled by the halo exchange instead of bc_z! (multi.jl:182)        */
 } ns3d_pt_params;
 
+/* One whole time step in ONE call (round 4): ns3d_time_step enqueues multi.jl:449-477 (one rank) or gpu.jl:121-142 — predictor,
+ * set_cylinder!, update_∇V!, the pressure solve, correct_V!, set_cylinder!, set_bc_Vel!, {X_o .= X; advect!} — on the context's
+ * stream in its fused form (ns3d_predict_fused, ns3d_pt_solve, ns3d_copy_advect); the residual read-backs of the pressure loop are
+ * its only synchronisations.  The fields are device pointers to the reference's arrays (multi.jl:343-360); the struct is IN/OUT:
+ * the fused step swaps the roles of X and X_o instead of copying (multi.jl:475 `X_o .= X` becomes a change of names), so after the
+ * call `Vx` is the current field and `Vx_o` the previous one, wherever they live.  In `faithful` mode Vz is never advected
+ * (App. B1): it keeps its buffer, and Vz_o is what the caller brings up to date once at the end of a run (ns3d_copy).  The stress
+ * arrays may be NULL unless write_stress is set (the reference's τ after its last step).  Results: those of the same sequence
+ * of single calls, bit for bit (tests/test_gpu_driver.py). */
+typedef struct ns3d_step_fields {
+    void *Pr, *dPrdtau, *divV;
+    void *Vx, *Vy, *Vz, *Vx_o, *Vy_o, *Vz_o, *C, *C_o;
+    void *txx, *tyy, *tzz, *txy, *txz, *tyz;
+} ns3d_step_fields;
+typedef struct ns3d_step_params {
+    int script;                 /* NS3D_BC_MULTI: multi.jl:449-477 on one rank; NS3D_BC_GPU: gpu.jl:121-142 */
+    int nx, ny, nz;
+    double mu, rho, g, dt, dtau, damp, dx, dy, dz;
+    double eps; int niter, nchk; double err_mul, err_div;    /* multi.jl:458-471: err = max|Rp|·err_mul/err_div (ly², psc) */
+    double a2, b2, ox, oy, sinb, cosb;                       /* set_cylinder! */
+    double xco_g, yco_g, zco_g;                              /*   multi.jl form: global coordinates of the rank's first cell centre */
+    double lx, ly, lz;
+    int owns_inlet, owns_outlet; double vin;                 /* multi.jl:164,179 */
+    int faithful;               /* advect!'s third branch as committed (1) or re-writing Vz (0) */
+    int pressure;               /* 0: the PT loop (parity); 1: ns3d_poisson_direct (outside parity) */
+    int write_stress;           /* also run update_τ! into txx … tyz (the reference's state after its last step) */
+} ns3d_step_params;
+
 #define NS3D_DECL(T, S)                                                                                     \
+    /* the whole step (above); iters_done / err_hist / n_checks as in ns3d_pt_solve */                          \
+    int ns3d_time_step_##S(ns3d_ctx *, ns3d_step_fields *f, const ns3d_step_params *p, int *iters_done,        \
+                           double *err_hist, int max_checks, int *n_checks);                                   \
     /* update_τ!(τxx,τyy,τzz,τxy,τxz,τyz,Vx,Vy,Vz,μ,dx,dy,dz)      multi.jl:36-44   gpu.jl:177-185 */         \
     int ns3d_update_tau_##S(ns3d_ctx *, T *txx, T *tyy, T *tzz, T *txy, T *txz, T *tyz, const T *Vx,         \
                             const T *Vy, const T *Vz, double mu, double dx, double dy, double dz, int nx,    \

@@ -1232,3 +1232,84 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
 
 NS3D_DEFINE(double, f64)
 NS3D_DEFINE(float, f32)
+
+// ---- one whole time step per call (include/ns3d.h ns3d_time_step) -----------------------------------------------------------
+// multi.jl:449-477 on one rank / gpu.jl:121-142 as the fused sequence the Python driver issues call by call — through the SAME entry
+// points (argument checks, arithmetic builds and all), with the context switched to non-blocking for the duration so that the residual
+// read-backs inside ns3d_pt_solve are the only synchronisations; one synchronisation at the end restores a blocking context's
+// contract.  ≈40 host calls per step become one: with the direct pressure solve a step of the 255×153×153 case is otherwise mostly
+// the driver's calls.
+extern "C" int ns3d_poisson_direct_f64(ns3d_ctx *, double *, double *, const double *, const ns3d_pt_params *);
+extern "C" int ns3d_poisson_direct_f32(ns3d_ctx *, float *, float *, const float *, const ns3d_pt_params *);
+#define NS3D_DEFINE_STEP(T, S)                                                                                \
+    extern "C" int ns3d_time_step_##S(ns3d_ctx *c, ns3d_step_fields *f, const ns3d_step_params *p, int *iters_done, \
+                                      double *err_hist, int max_checks, int *n_checks)                       \
+    {                                                                                                        \
+        CHECK_CTX(c);                                                                                        \
+        if (!f || !p) return fail(NS3D_ERR_ARG, "ns3d_time_step: null argument");                            \
+        if (p->script != NS3D_BC_MULTI && p->script != NS3D_BC_GPU)                                          \
+            return fail(NS3D_ERR_ARG, "ns3d_time_step: script %d (NS3D_BC_MULTI: multi.jl, NS3D_BC_GPU: gpu.jl)", p->script); \
+        if (p->write_stress && !(f->txx && f->tyy && f->tzz && f->txy && f->txz && f->tyz))                  \
+            return fail(NS3D_ERR_ARG, "ns3d_time_step: write_stress needs the six stress arrays");           \
+        const int nx = p->nx, ny = p->ny, nz = p->nz;                                                        \
+        const int was = c->flags;                                                                            \
+        c->flags |= NS3D_ASYNC;                                                                              \
+        int rc = NS3D_OK;                                                                                    \
+        bool deferred_residual = false;                                                                      \
+        T *Vx = (T *)f->Vx, *Vy = (T *)f->Vy, *Vz = (T *)f->Vz, *Vxo = (T *)f->Vx_o, *Vyo = (T *)f->Vy_o, *Vzo = (T *)f->Vz_o; \
+        T *C = (T *)f->C, *Co = (T *)f->C_o, *Pr = (T *)f->Pr, *D = (T *)f->dPrdtau, *divV = (T *)f->divV;    \
+        auto cylinder = [&]() -> int {          /* multi.jl:249-281 (global coordinates) / gpu.jl:336-368 (local) */ \
+            return p->script == NS3D_BC_MULTI                                                                \
+                       ? ns3d_set_cylinder_##S(c, C, Vx, Vy, Vz, p->a2, p->b2, p->ox, p->oy, p->sinb, p->cosb, p->xco_g, p->yco_g, \
+                                               p->zco_g, p->lx, p->ly, p->lz, p->dx, p->dy, p->dz, nx, ny, nz)  \
+                       : ns3d_set_cylinder_local_##S(c, C, Vx, Vy, Vz, p->a2, p->b2, p->ox, p->oy, p->sinb, p->cosb, p->lx,    \
+                                                     p->ly, p->lz, p->dx, p->dy, p->dz, nx, ny, nz);            \
+        };                                                                                                   \
+        do {                                                                                                 \
+            if (p->write_stress &&                                                                           \
+                (rc = ns3d_update_tau_##S(c, (T *)f->txx, (T *)f->tyy, (T *)f->tzz, (T *)f->txy, (T *)f->txz, (T *)f->tyz, Vx, Vy, Vz, \
+                                          p->mu, p->dx, p->dy, p->dz, nx, ny, nz))) break;                   \
+            /* :449-451 / :121-122 in one pass; the predicted fields land in the *_o buffers and the names swap */ \
+            if ((rc = ns3d_predict_fused_##S(c, Vxo, Vyo, Vzo, Vx, Vy, Vz, p->mu, p->rho, p->g, p->dt, p->dx, p->dy, p->dz, nx, ny, nz))) break; \
+            std::swap(Vx, Vxo); std::swap(Vy, Vyo); std::swap(Vz, Vzo);                                      \
+            if ((rc = cylinder())) break;                                                   /* :452 / :123 */ \
+            if ((rc = ns3d_update_divV_##S(c, divV, Vx, Vy, Vz, p->dx, p->dy, p->dz, nx, ny, nz))) break;     /* :454 / :124 */ \
+            ns3d_pt_params pt;                                                                               \
+            pt.rho = p->rho; pt.dt = p->dt; pt.dtau = p->dtau; pt.damp = p->damp; pt.dx = p->dx; pt.dy = p->dy; pt.dz = p->dz; \
+            pt.nx = nx; pt.ny = ny; pt.nz = nz; pt.bc_kind = p->script; pt.owns_outlet = p->script == NS3D_BC_MULTI ? p->owns_outlet : 0; \
+            pt.outlet_val = 0.0; pt.g = p->g; pt.z_lo_is_halo = 0; pt.z_hi_is_halo = 0;                        \
+            if (p->pressure == 1) {             /* outside parity: the exact solution of what :458-471 iterates towards */ \
+                if ((rc = ns3d_poisson_direct_##S(c, Pr, D, divV, &pt))) break;                              \
+                /* its residual steers nothing: the 8 bytes come back behind the REST of the step (read after the final            \
+                 * synchronisation) instead of stalling the stream in the middle of it */                     \
+                hipError_t e = DISPATCHG(c, p->dx, p->dy, p->dz, residual_max_key<T>(c->stream, Pr, divV, pt, c->key_dev)); \
+                if (e == hipSuccess) e = hipMemcpyAsync(c->key_host, c->key_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream); \
+                if (e != hipSuccess) { rc = fail(NS3D_ERR_HIP, "ns3d_time_step: residual launch: %s", hipGetErrorString(e)); break; } \
+                deferred_residual = true;                                                                    \
+            } else if ((rc = ns3d_pt_solve_##S(c, Pr, D, divV, &pt, p->eps, p->niter, p->nchk, p->err_mul, p->err_div, iters_done, \
+                                               err_hist, max_checks, n_checks))) break;     /* :458-471 / :126-137 */ \
+            if ((rc = ns3d_correct_V_##S(c, Vx, Vy, Vz, Pr, p->dt, p->rho, p->dx, p->dy, p->dz, nx, ny, nz))) break;   /* :472 / :138 */ \
+            if ((rc = cylinder())) break;                                                   /* :473 / :139 */ \
+            if ((rc = ns3d_set_bc_Vel_##S(c, Vx, Vy, Vz, p->script, p->script == NS3D_BC_MULTI ? p->owns_inlet : 0, p->vin, nx, ny, nz))) break; \
+            /* :475-476 / :141-142 in one pass: complete new fields into the *_o buffers, then the roles swap */ \
+            if ((rc = ns3d_copy_advect_##S(c, Vxo, Vx, Vyo, Vy, p->faithful ? Vz : Vzo, Vz, Co, C, p->dt, p->dx, p->dy, p->dz, nx, ny, nz, \
+                                           p->faithful ? 1 : 0))) break;                                     \
+            std::swap(Vx, Vxo); std::swap(Vy, Vyo); std::swap(C, Co);                                        \
+            if (!p->faithful) std::swap(Vz, Vzo);                                                            \
+        } while (0);                                                                                         \
+        c->flags = was;                                                                                      \
+        f->Vx = Vx; f->Vy = Vy; f->Vz = Vz; f->Vx_o = Vxo; f->Vy_o = Vyo; f->Vz_o = Vzo; f->C = C; f->C_o = Co; \
+        if (rc) return rc;                                                                                   \
+        if (deferred_residual) {                                                                             \
+            HIPCHK(c, hipStreamSynchronize(c->stream));                                                      \
+            double mx;                                                                                       \
+            std::memcpy(&mx, c->key_host, sizeof mx);                                                        \
+            if (iters_done) *iters_done = 0;                                                                 \
+            if (err_hist && max_checks > 0) err_hist[0] = mx * p->err_mul / p->err_div;                      \
+            if (n_checks) *n_checks = 1;                                                                     \
+            return NS3D_OK;                                                                                  \
+        }                                                                                                    \
+        return finish(c, hipSuccess, "time_step");                                                           \
+    }
+NS3D_DEFINE_STEP(double, f64)
+NS3D_DEFINE_STEP(float, f32)

@@ -136,7 +136,7 @@ def pt_loop_fused_slab(ctx, grid, f, p, pt, niter, do_print=False, scratch=None)
 
 def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=10, *, mode="strict", fused=True,
                        temporal=True, dtype=torch.float64, faithful=True, grid=None, device=None, niter_cap=None,
-                       return_info=False, shape=None, pressure="pt", wide_advect_halo=False):
+                       return_info=False, shape=None, pressure="pt", wide_advect_halo=False, one_call=True):
     """run_navierstokes3D (multi.jl:287-536).  nx is the LOCAL streamwise size (ny = nz = ceil(0.6 nx) local).
     `grid` decides the decomposition: None = one rank; a halo.ZSlabGrid = this process is one z-slab rank of an
     initialised torch.distributed group; a mgpu.MgpuGrid = the C-ABI grid (this process drives every local rank of an
@@ -222,8 +222,46 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
     info = SimpleNamespace(iters=[], errs=[], params=p)
     nsave = nvis = 10                                                                         # :330,332
     root = _is_root(grid)
+    # :450's halo update of the normal stresses may only go with the stress arrays where the interior planes two ranks both compute
+    # are identical.  backtrack! clamps to the LOCAL array and rounds iz − δ rank by rank, so with the fixed third branch
+    # (faithful=False: Vz IS advected) on several ranks and without the wide halo the two copies of a seam's Vz plane can differ —
+    # and the reference sequence would ship one rank's τzz to the other.  That combination keeps :449-451 literal.
+    fuse_predictor = fused and (P == 1 or faithful or wide_advect_halo)
+    # one rank, fused: the whole step :449-477 is ONE library call (ns3d_time_step: the same entry points, enqueued from C) — a step
+    # of the 255×153×153 case with the direct pressure solve is otherwise mostly this loop's ≈40 calls
+    step_params = None
+    if fused and one_call and P == 1 and getattr(grid, "mg", None) is None:
+        q = ps[0]
+        step_params = L.StepParams(script=L.NS3D_BC_MULTI, nx=nx, ny=ny, nz=nz, mu=p.mu, rho=p.rho, g=p.g, dt=p.dt, dtau=p.dtau,
+                                   damp=p.damp, dx=p.dx, dy=p.dy, dz=p.dz, eps=p.eps, niter=niter, nchk=p.nchk, err_mul=p.ly * p.ly,
+                                   err_div=p.psc, a2=q.a2, b2=q.b2, ox=q.ox, oy=q.oy, sinb=q.sinb, cosb=q.cosb, xco_g=q.xco_g,
+                                   yco_g=q.yco_g, zco_g=q.zco_g, lx=q.lx, ly=q.ly, lz=q.lz, owns_inlet=int(bool(q.owns_inlet)),
+                                   owns_outlet=int(bool(q.owns_outlet)), vin=p.vin, faithful=int(bool(faithful)),
+                                   pressure=1 if pressure == "direct" else 0, write_stress=0)
+
+    def frames(it):                                                                           # :479-525 (one frame counter)
+        nonlocal iframe
+        if (do_vis and it % nvis == 0) or (do_save and it % nsave == 0):
+            sync()
+            gathered = _gather_all(grid, fs)
+            if do_vis and it % nvis == 0 and root:                                            # :486-513
+                save_frame_multi(gathered, ny_g_all, nz_g_all, iframe)
+            if do_save and it % nsave == 0:                                                   # :515-522
+                _save_frame(grid, gathered, iframe)
+            iframe += 1
+
     for it in range(1, nt + 1):                                                               # :446
-        if fused:
+        if step_params is not None:
+            step_params.write_stress = 1 if it == nt else 0     # the stress arrays as the reference leaves them after its last step
+            done, errs = K.time_step(fs[0], step_params, ctx=ctxs[0])
+            if root and do_print:
+                print("#it = %d" % it)                                                        # :456
+                for q_, e in enumerate(errs):
+                    print("  #iter = %d, err = %1.3e" % ((q_ + 1) * p.nchk, e))
+            info.iters.append(done); info.errs.append(errs)
+            frames(it)
+            continue
+        if fuse_predictor:
             # :449-451 in one pass (ns3d_predict_fused): the stresses evaluated on the fly, the predicted fields written into the
             # *_o buffers (free until :475), the names swapped.  :450's halo update of τxx, τyy, τzz moves values every rank has
             # already computed itself — the velocities it computes them from are consistent across ranks after :477 / :373 —
@@ -296,14 +334,7 @@ def run_navierstokes3D(do_vis=False, do_save=False, do_print=False, nx=255, nt=1
             K.advect(f.Vx, f.Vx_o, f.Vy, f.Vy_o, f.Vz, f.Vz_o, f.C, f.C_o, p.dt, p.dx, p.dy, p.dz, faithful, ctx=c)  # :476
         if not (wide_advect_halo and P > 1):
             grid.update_halo(col("Vx"), col("Vy"), col("Vz"))                                 # :477 (not C)
-        if (do_vis and it % nvis == 0) or (do_save and it % nsave == 0):                      # :479-525 (one frame counter)
-            sync()
-            gathered = _gather_all(grid, fs)
-            if do_vis and it % nvis == 0 and root:                                            # :486-513
-                save_frame_multi(gathered, ny_g_all, nz_g_all, iframe)
-            if do_save and it % nsave == 0:                                                   # :515-522
-                _save_frame(grid, gathered, iframe)
-            iframe += 1
+        frames(it)
     if fused and faithful and nt > 0 and not (wide_advect_halo and P > 1):
         for f, c in zip(fs, ctxs):
             K.copy(f.Vz_o, f.Vz, ctx=c)     # the one copy of :475 the swaps skipped (Vz is never advected): same final state
@@ -366,7 +397,7 @@ def _save_mat(path, f, p, step0):
 
 
 def runme(do_vis=False, do_save=False, *, nx=255, nt=10000, mode="strict", fused=True, dtype=torch.float64,
-          faithful=True, device=None, niter_cap=None, do_print=False, initial=None, pressure="pt"):
+          faithful=True, device=None, niter_cap=None, do_print=False, initial=None, pressure="pt", one_call=True):
     """runme (gpu.jl:12-173): single device, gravity, hydrostatic x-planes.  Returns (fields, info).
     nx/nt are literals in the reference (gpu.jl:44,51: 255, 10000) and keyword options here.  do_save writes the MAT files
     of gpu.jl:89,168-170 (step 0 and every nsave = 10 steps); do_vis the heat maps of gpu.jl:90-117,143-167 (frame 0 and
@@ -396,7 +427,30 @@ def runme(do_vis=False, do_save=False, *, nx=255, nt=10000, mode="strict", fused
         ctx.sync()
         save_frame_gpu(host(), ny, nz, iframe)
         iframe += 1
+    step_params = None
+    if fused and one_call:      # the whole step :121-142 as ONE library call (ns3d_time_step)
+        step_params = L.StepParams(script=L.NS3D_BC_GPU, nx=nx, ny=ny, nz=nz, mu=p.mu, rho=p.rho, g=p.g, dt=p.dt, dtau=p.dtau,
+                                   damp=p.damp, dx=p.dx, dy=p.dy, dz=p.dz, eps=p.eps, niter=niter, nchk=p.nchk, err_mul=p.ly * p.ly,
+                                   err_div=p.psc, a2=p.a2, b2=p.b2, ox=p.ox, oy=p.oy, sinb=p.sinb, cosb=p.cosb, xco_g=0.0, yco_g=0.0,
+                                   zco_g=0.0, lx=p.lx, ly=p.ly, lz=p.lz, owns_inlet=0, owns_outlet=0, vin=0.0,
+                                   faithful=int(bool(faithful)), pressure=1 if pressure == "direct" else 0, write_stress=0)
     for it in range(1, nt + 1):                                                               # :119
+        if step_params is not None:
+            step_params.write_stress = 1 if it == nt else 0
+            done, errs = K.time_step(f, step_params, ctx=ctx)
+            if do_print:
+                print("#it = %d" % it)                                                        # :125
+                for q_, e in enumerate(errs):
+                    print("  #iter = %d, err = %1.3e" % ((q_ + 1) * p.nchk, e))                # :134
+            info.iters.append(done); info.errs.append(errs)
+            if do_vis and it % nvis == 0:                                                     # :143-167
+                ctx.sync()
+                save_frame_gpu(host(), ny, nz, iframe)
+                iframe += 1
+            if do_save and it % nsave == 0:                                                   # :168-170
+                ctx.sync()
+                _save_mat("out_save/step_%d.mat" % it, f, p, False)
+            continue
         if fused:
             if it == nt:            # the stress arrays as the reference leaves them after its last step: same final state
                 K.update_tau(f.txx, f.tyy, f.tzz, f.txy, f.txz, f.tyz, f.Vx, f.Vy, f.Vz, p.mu, p.dx, p.dy, p.dz, ctx=ctx)

@@ -479,6 +479,35 @@ def residual_max(Pr, divV, p, ctx=None):
     return out.value
 
 
+_STEP_SWAP = ("Vx", "Vy", "Vz", "Vx_o", "Vy_o", "Vz_o", "C", "C_o")
+
+
+def time_step(f, sp, ctx=None):
+    """One whole time step in one library call (ns3d_time_step: multi.jl:449-477 on one rank / gpu.jl:121-142 in its fused form).
+    f: a namespace of the reference's arrays as tensors (Pr, dPrdtau, divV, Vx, …, C_o, txx … tyz); sp: lib.StepParams.  The step
+    swaps the roles of X and X_o instead of copying: on return f.Vx is the current field and f.Vx_o the previous one.  Returns
+    (iters_done, [err …]) like pt_solve."""
+    nx, ny, nz = f.Pr.shape
+    if (sp.nx, sp.ny, sp.nz) != (nx, ny, nz):
+        raise L.Ns3dError("time_step: params grid %r differs from Pr's %r" % ((sp.nx, sp.ny, sp.nz), (nx, ny, nz)))
+    shapes = {"Pr": (nx, ny, nz), "dPrdtau": (nx - 2, ny - 2, nz - 2), "divV": (nx, ny, nz), "Vx": (nx + 1, ny, nz),
+              "Vy": (nx, ny + 1, nz), "Vz": (nx, ny, nz + 1), "Vx_o": (nx + 1, ny, nz), "Vy_o": (nx, ny + 1, nz),
+              "Vz_o": (nx, ny, nz + 1), "C": (nx, ny, nz), "C_o": (nx, ny, nz), "txx": (nx, ny, nz), "tyy": (nx, ny, nz),
+              "tzz": (nx, ny, nz), "txy": (nx - 1, ny - 1, nz - 1), "txz": (nx - 1, ny - 1, nz - 1), "tyz": (nx - 1, ny - 1, nz - 1)}
+    sf = L.StepFields()
+    for n, shp in shapes.items():
+        t = getattr(f, n, None)
+        setattr(sf, n, None if t is None else _chk(t, shp, n))
+    by_ptr = {getattr(f, n).data_ptr(): getattr(f, n) for n in _STEP_SWAP}
+    cap = sp.niter // max(sp.nchk, 1) + 1
+    hist = (C.c_double * cap)()
+    it, nchecks = C.c_int(0), C.c_int(0)
+    _ctx(ctx, f.Pr).call("time_step", f.Pr, C.byref(sf), C.byref(sp), C.byref(it), hist, cap, C.byref(nchecks))
+    for n in _STEP_SWAP:
+        setattr(f, n, by_ptr[getattr(sf, n)])
+    return it.value, list(hist[: nchecks.value])
+
+
 def pt_solve(Pr, dPrdtau, divV, p, eps, niter, nchk, err_mul, err_div, ctx=None):
     """The inner loop multi.jl:458-471 / gpu.jl:126-137 on one rank; err = max|Rp|*err_mul/err_div
     (= maximum(abs.(Rp))*ly^2/psc). Returns (iters_done, [err …])."""

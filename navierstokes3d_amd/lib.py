@@ -30,6 +30,22 @@ class PtParams(C.Structure):
     ]
 
 
+class StepFields(C.Structure):
+    """struct ns3d_step_fields (include/ns3d.h): device pointers, in/out (the fused step swaps X and X_o)."""
+    _fields_ = [(n, C.c_void_p) for n in ("Pr", "dPrdtau", "divV", "Vx", "Vy", "Vz", "Vx_o", "Vy_o", "Vz_o", "C", "C_o",
+                                          "txx", "tyy", "tzz", "txy", "txz", "tyz")]
+
+
+class StepParams(C.Structure):
+    """struct ns3d_step_params (include/ns3d.h)."""
+    _fields_ = [("script", C.c_int), ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int)] + \
+               [(n, C.c_double) for n in ("mu", "rho", "g", "dt", "dtau", "damp", "dx", "dy", "dz", "eps")] + \
+               [("niter", C.c_int), ("nchk", C.c_int), ("err_mul", C.c_double), ("err_div", C.c_double)] + \
+               [(n, C.c_double) for n in ("a2", "b2", "ox", "oy", "sinb", "cosb", "xco_g", "yco_g", "zco_g", "lx", "ly", "lz")] + \
+               [("owns_inlet", C.c_int), ("owns_outlet", C.c_int), ("vin", C.c_double), ("faithful", C.c_int), ("pressure", C.c_int),
+                ("write_stress", C.c_int)]
+
+
 _P, _D, _I, _L = C.c_void_p, C.c_double, C.c_int, C.c_long
 
 # name → argument ctypes after the leading ctx pointer (same for _f64 and _f32)
@@ -66,6 +82,7 @@ SIGNATURES = {
     "residual_max": [_P] * 2 + [C.POINTER(PtParams), C.POINTER(_D)],
     "selftest_exact_div": [_D, _L, C.c_ulonglong, C.POINTER(_L)],
     "pt_solve": [_P] * 3 + [C.POINTER(PtParams), _D, _I, _I, _D, _D, C.POINTER(_I), C.POINTER(_D), _I, C.POINTER(_I)],
+    "time_step": [C.POINTER(StepFields), C.POINTER(StepParams), C.POINTER(_I), C.POINTER(_D), _I, C.POINTER(_I)],
 }
 CONTEXT_SYMBOLS = ["ns3d_version", "ns3d_last_error", "ns3d_create", "ns3d_destroy", "ns3d_flags",
                    "ns3d_set_stream", "ns3d_use_own_stream", "ns3d_get_stream", "ns3d_sync", "ns3d_reserve_cus", "ns3d_reserved_cus", "ns3d_set_pt_variant",

@@ -319,22 +319,25 @@ def test_deep_ghosts_on_a_cartesian_topology_equal_the_global_pt_solve(hip, dims
         mg.close()
 
 
-@pytest.mark.parametrize("P,fused,temporal", [(2, True, True), (3, True, True), (2, True, False), (2, False, False)])
-def test_driver_on_mgpu_grid_vs_oracle_virtual_ranks(hip, P, fused, temporal):
+@pytest.mark.parametrize("P,fused,temporal,faithful,nt", [(2, True, True, True, 2), (3, True, True, True, 2), (2, True, False, True, 2),
+                                                          (2, False, False, True, 2), (2, True, True, False, 3), (3, True, True, False, 3)])
+def test_driver_on_mgpu_grid_vs_oracle_virtual_ranks(hip, P, fused, temporal, faithful, nt):
     """The product driver (multi.jl:287-536) on the C-ABI grid — update_halo!, max_g, gather!, and the inner loop as
     ns3d_pt_solve_slab (fused) or as the literal per-kernel sequence — against the oracle's P virtual ranks: iteration
-    counts, every local field and the gathered return arrays, bit for bit."""
+    counts, every local field and the gathered return arrays, bit for bit.  faithful=False on several ranks: the fixed
+    third branch advects Vz with backtrack!'s rank-local clamp and rounding, so the fused driver keeps update_τ! / update_halo!(τ) /
+    predict_V! literal there (three steps: the advected Vz of step 2 feeds the stresses of step 3)."""
     from navierstokes3d_amd.driver import run_navierstokes3D
     from navierstokes3d_amd.mgpu import MgpuGrid, MultiGpu
     from navierstokes3d_amd.params import multi_params
     from oracle.driver_ref import run_navierstokes3D_ref
-    nx, nt = 32, 2
+    nx = 32
     p0 = multi_params(nx)
     mg = MultiGpu.create([0] * P, p0.nx, p0.ny, p0.nz, "strict", own_streams=OWN_STREAMS)
-    out = run_navierstokes3D(nx=nx, nt=nt, mode="strict", fused=fused, temporal=temporal,
+    out = run_navierstokes3D(nx=nx, nt=nt, mode="strict", fused=fused, temporal=temporal, faithful=faithful,
                              grid=MgpuGrid(mg, p0.nx, p0.ny, p0.nz), return_info=True)
     info = out[-1]
-    ref = run_navierstokes3D_ref(nx=nx, nt=nt, dims_z=P)
+    ref = run_navierstokes3D_ref(nx=nx, nt=nt, dims_z=P, faithful=faithful)
     assert info.iters == ref[-1].iters and info.errs == ref[-1].errs
     for r in range(P):
         for n in ("C", "Pr", "Vx", "Vy", "Vz", "divV", "dPrdtau"):
