@@ -40,7 +40,7 @@ export @init_parallel_stencil, @parallel, @parallel_indices, @zeros, Data
 export update_τ!, predict_V!, set_cylinder!, update_∇V!, update_dPrdτ!, update_Pr!, compute_res!, correct_V!, advect!
 export bc_x!, bc_y!, bc_z!, bc_zV!, bc_xhydstatic!, bc_x_Vx!, bc_x_Pr!, bc_xVx!, bc_xVyz!
 export init_global_grid, finalize_global_grid, nx_g, ny_g, nz_g, x_g, y_g, z_g, update_halo!, gather!
-export pt_solve!, pt_solve_slab!, maxabs, copy_advect!, predict_fused!, poisson_direct!
+export pt_solve!, pt_solve_slab!, maxabs, copy_advect!, predict_fused!, poisson_direct!, time_step!, reserve_cus!, StepFields, StepParams
 
 const libns3d = get(ENV, "NS3D_LIB", joinpath(@__DIR__, "..", "navierstokes3d_amd", "libns3d.so"))
 const NS3D_STRICT, NS3D_FAST, NS3D_ASYNC = Cint(0), Cint(1), Cint(2)
@@ -307,6 +307,46 @@ function poisson_direct!(Pr, dPrdτ, ∇V, ρ, dt, dx, dy, dz; bc_kind = 0, owns
     check(ccall((:ns3d_poisson_direct_f64, libns3d), Cint, (Ptr{Cvoid}, PF, PF, PF, Ref{PtParams}),
                 _ctx(), ptr(Pr), ptr(dPrdτ), ptr(∇V), p))
 end
+mutable struct StepFields          # struct ns3d_step_fields (include/ns3d.h): device pointers, IN/OUT (the fused step swaps X and X_o)
+    Pr::PF; dPrdtau::PF; divV::PF
+    Vx::PF; Vy::PF; Vz::PF; Vx_o::PF; Vy_o::PF; Vz_o::PF; C::PF; C_o::PF
+    txx::PF; tyy::PF; tzz::PF; txy::PF; txz::PF; tyz::PF
+end
+struct StepParams                  # struct ns3d_step_params (include/ns3d.h), field for field
+    script::Cint; nx::Cint; ny::Cint; nz::Cint
+    mu::Cdouble; rho::Cdouble; g::Cdouble; dt::Cdouble; dtau::Cdouble; damp::Cdouble; dx::Cdouble; dy::Cdouble; dz::Cdouble
+    eps::Cdouble; niter::Cint; nchk::Cint; err_mul::Cdouble; err_div::Cdouble
+    a2::Cdouble; b2::Cdouble; ox::Cdouble; oy::Cdouble; sinb::Cdouble; cosb::Cdouble
+    xco_g::Cdouble; yco_g::Cdouble; zco_g::Cdouble
+    lx::Cdouble; ly::Cdouble; lz::Cdouble
+    owns_inlet::Cint; owns_outlet::Cint; vin::Cdouble
+    faithful::Cint; pressure::Cint; write_stress::Cint
+end
+"""
+    time_step!(f::StepFields, p::StepParams) -> (iters, errs)
+
+The whole time step multi.jl:449-477 (one rank; `p.script = 0`) or gpu.jl:121-142 (`p.script = 1`) in ONE library call
+(`ns3d_time_step_f64`): predictor, set_cylinder!, update_∇V!, the pressure loop with its residual read-backs, correct_V!,
+set_cylinder!, set_bc_Vel!, {X_o .= X; advect!} in their fused forms, enqueued from C.  `f` holds the device pointers of the
+reference's arrays and is updated in place: the step swaps the roles of `Vx`/`Vx_o`, `Vy`/`Vy_o`, `C`/`C_o` (and `Vz`/`Vz_o` unless
+`faithful`) instead of copying — re-wrap your arrays from `f` afterwards (or keep working through `f`).
+"""
+function time_step!(f::StepFields, p::StepParams)
+    cap = p.niter ÷ max(p.nchk, 1) + 1
+    hist = Vector{Cdouble}(undef, cap); it = Ref{Cint}(0); nchecks = Ref{Cint}(0); _sync()
+    check(ccall((:ns3d_time_step_f64, libns3d), Cint,
+                (Ptr{Cvoid}, Ref{StepFields}, Ref{StepParams}, Ref{Cint}, Ptr{Cdouble}, Cint, Ref{Cint}),
+                _ctx(), f, Ref(p), it, hist, cap, nchecks))
+    return Int(it[]), hist[1:nchecks[]]
+end
+"""
+    reserve_cus!(n)
+
+Leave `n` compute units out of this context's launches (`ns3d_reserve_cus`): room for RCCL's send/recv kernels beside a sweep that
+would otherwise hold every CU — the device-side counterpart of the `b_width` the reference reserves "for comm / comp overlap"
+(multi.jl:326) and never uses.  Results do not depend on it.
+"""
+reserve_cus!(n::Integer) = check(ccall((:ns3d_reserve_cus, libns3d), Cint, (Ptr{Cvoid}, Cint), _ctx(), n))
 """
     pt_solve_slab!(Pr, dPrdτ, ∇V, ρ, dt, dτ, damp, dx, dy, dz; …) -> (iters, errs)
 

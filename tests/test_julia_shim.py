@@ -130,6 +130,30 @@ def test_ptparams_struct_layout():
     assert pyfields == cfields
 
 
+def test_step_struct_layouts():
+    """ns3d_step_fields / ns3d_step_params (ns3d_time_step, round 4): the header, the Julia mirrors and the ctypes mirrors agree field for
+    field (name, order, class)."""
+    import ctypes as C
+    from navierstokes3d_amd import lib as L
+    _, txt = header_prototypes()
+    for cname, jname, py in (("ns3d_step_fields", "StepFields", L.StepFields), ("ns3d_step_params", "StepParams", L.StepParams)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), txt).group(1)
+        cfields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            ctype, names = decl.split(" ", 1)
+            for n in names.split(","):
+                n = n.strip()
+                cfields.append((n.lstrip("*"), "ptr" if n.startswith("*") else {"double": "double", "int": "int"}[ctype]))
+        jbody = re.search(r"struct %s(.*?)\nend" % jname, shim_source(), re.S).group(1)
+        jfields = [(n, {"Cdouble": "double", "Cint": "int", "PF": "ptr"}[t]) for n, t in re.findall(r"(\w+)::(\w+)", jbody)]
+        assert jfields == cfields, cname
+        pyfields = [(n, {C.c_double: "double", C.c_int: "int", C.c_void_p: "ptr"}[t]) for n, t in py._fields_]
+        assert pyfields == cfields, cname
+
+
 def test_definitions_are_swallowed_and_calls_forwarded():
     """The two macros the scripts' kernels go through: `@parallel function …` / `@parallel_indices (…) function …` must expand
     to nothing (their bodies use ParallelStencil macros that do not exist here), calls must be forwarded."""
