@@ -115,8 +115,8 @@ int ns3d_set_autotune(ns3d_ctx *ctx, int on);
  *                             such an output is valid input ONLY for a pass with NS3D_PASS_INPUT_OBEYS_BC;
  *   NS3D_PASS_INPUT_OBEYS_BC  promise: the boundary cells of Pr_in equal the boundary rule applied to its interior (true for the
  *                             output of any sweep); level 1 then forms them instead of reading them.  Same bits.
- * Honoured by ns3d_pt_sweep2 (every tile shape); ns3d_pt_sweepn refuses a call with flags set (where deeper passes run the
- * boundary-cell launch is 0.5 % of a pass).  With ns3d_set_pass_chain(ctx, 1) (or NS3D_PASS_CHAIN=1) ns3d_pt_iterate / ns3d_pt_solve
+ * Both honoured by ns3d_pt_sweep2 (every tile shape); ns3d_pt_sweepn honours NS3D_PASS_SKIP_FACES and refuses a call with
+ * NS3D_PASS_INPUT_OBEYS_BC (where deeper passes run the boundary-cell launch is 0.5 % of a pass).  With ns3d_set_pass_chain(ctx, 1) (or NS3D_PASS_CHAIN=1) ns3d_pt_iterate / ns3d_pt_solve
  * chain the TWO-iteration passes of a residual-check block this way by themselves: the first pass of a block reads the caller's
  * cells as they are and the last one writes them, so callers see complete fields.  OFF by default: measured on the reference's
  * 255×153×153 grid the chained passes are 2.5 % (STRICT) / 4 % (FAST) SLOWER than pass + boundary-cell launch — every tile of

@@ -589,17 +589,18 @@ static Plan pick_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
 // one pass of `depth` (2…4, fp32: 5) PT iterations
 template <class T>
 static hipError_t launch_pass(ns3d_ctx *c, hipStream_t s, int depth, const Plan &pl, const T *src, T *dst, const T *dsrc, T *ddst,
-                              const T *divV, const ns3d_pt_params *p, int k0, int k1)
+                              const T *divV, const ns3d_pt_params *p, int k0, int k1, const ns3d_tile_window *win = nullptr,
+                              int more_flags = 0)
 {
     const int mode = mode_of(c, p->dx, p->dy, p->dz);
     c->last_depth = depth;
-    const int flags = c->pass_flags | ((c->reserved_cus / 8) << 8);   // bits 8…: compute units the launch must not count on (in eights)
+    const int flags = c->pass_flags | more_flags | ((c->reserved_cus / 8) << 8);   // bits 8…: compute units the launch must not count on (in eights)
     if (depth == 2) {
         c->last_pt2 = pl.v2;
-        return DISPATCHM(mode, pt_sweep2<T>(s, pl.v2, src, dst, dsrc, ddst, divV, *p, k0, k1, flags));
+        return DISPATCHM(mode, pt_sweep2<T>(s, pl.v2, src, dst, dsrc, ddst, divV, *p, k0, k1, flags, win));
     }
     c->last_ptn = pl.vn;
-    return DISPATCHM(mode, pt_sweepn<T>(s, depth, pl.vn, src, dst, dsrc, ddst, divV, *p, k0, k1, flags));
+    return DISPATCHM(mode, pt_sweepn<T>(s, depth, pl.vn, src, dst, dsrc, ddst, divV, *p, k0, k1, flags, win));
 }
 // iterations of the next pass when `rem` remain until the next residual check / the end
 static int next_depth(const Plan &pl, bool blocked, int rem)
@@ -625,12 +626,18 @@ hipError_t ns3d_enqueue_pt2(ns3d_ctx *c, hipStream_t s, const T *src, T *dst, co
 }
 template <class T>
 hipError_t ns3d_enqueue_pass(ns3d_ctx *c, hipStream_t s, int depth, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV,
-                             const ns3d_pt_params *p, int k0, int k1, int v2, int vn)
+                             const ns3d_pt_params *p, int k0, int k1, int v2, int vn, const ns3d_tile_window *win, int skip_faces)
 {
     Plan pl = lookup_plan<T>(c, mode_of(c, p->dx, p->dy, p->dz), p, k0, k1);
     if (v2 >= 0 && c->pt2_variant <= 0) pl.v2 = v2;        // the caller's own plan; explicit context settings still win
     if (vn >= 0 && c->ptn_variant <= 0) pl.vn = vn;
-    return launch_pass<T>(c, s, depth, pl, src, dst, dsrc, ddst, divV, p, k0, k1);
+    return launch_pass<T>(c, s, depth, pl, src, dst, dsrc, ddst, divV, p, k0, k1, win, skip_faces ? NS3D_PASS_SKIP_FACES : 0);
+}
+template <class T>
+hipError_t ns3d_enqueue_faces_region(ns3d_ctx *c, hipStream_t s, T *Pout, const ns3d_pt_params *p, const int c0[3], const int c1[3],
+                                     int want_core)
+{
+    return DISPATCHG(c, p->dx, p->dy, p->dz, pt_faces_region<T>(s, Pout, *p, c0, c1, want_core));
 }
 template <class T>
 int ns3d_plan_pt_internal(ns3d_ctx *c, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV, const ns3d_pt_params *p,
@@ -680,7 +687,8 @@ hipError_t ns3d_enqueue_advect(ns3d_ctx *c, hipStream_t s, T *Vx, const T *Vx_o,
     template hipError_t ns3d_enqueue_pt2<T>(ns3d_ctx *, hipStream_t, const T *, T *, const T *, T *, const T *,      \
                                             const ns3d_pt_params *, int, int);                                      \
     template hipError_t ns3d_enqueue_pass<T>(ns3d_ctx *, hipStream_t, int, const T *, T *, const T *, T *, const T *, \
-                                             const ns3d_pt_params *, int, int, int, int);                           \
+                                             const ns3d_pt_params *, int, int, int, int, const ns3d_tile_window *, int); \
+    template hipError_t ns3d_enqueue_faces_region<T>(ns3d_ctx *, hipStream_t, T *, const ns3d_pt_params *, const int *, const int *, int); \
     template int ns3d_plan_pt_internal<T>(ns3d_ctx *, const T *, T *, const T *, T *, const T *,                     \
                                           const ns3d_pt_params *, int, int);                                        \
     template hipError_t ns3d_enqueue_pt1<T>(ns3d_ctx *, hipStream_t, const T *, T *, T *, const T *,                 \

@@ -116,7 +116,13 @@ hipError_t ns3d_enqueue_pt2(ns3d_ctx *c, hipStream_t s, const T *src, T *dst, co
 // measurement only, and such entries do not answer unpinned look-ups)
 template <class T>
 hipError_t ns3d_enqueue_pass(ns3d_ctx *c, hipStream_t s, int depth, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV,
-                             const ns3d_pt_params *p, int k0, int k1, int v2 = -1, int vn = -1);
+                             const ns3d_pt_params *p, int k0, int k1, int v2 = -1, int vn = -1, const ns3d_tile_window *win = nullptr,
+                             int skip_faces = 0);
+// win: a sub-rectangle of the plane's tiles, or (win->geom) a query of the tile grid this pass would use — nothing is launched then;
+// skip_faces: no boundary-cell launch behind the sweep (the caller completes them with ns3d_enqueue_faces_region)
+template <class T>
+hipError_t ns3d_enqueue_faces_region(ns3d_ctx *c, hipStream_t s, T *Pout, const ns3d_pt_params *p, const int c0[3], const int c1[3],
+                                     int want_core);
 // the plan phase of ns3d_plan_pt on the context's stream (blocks on its own events); returns the planned depth
 template <class T>
 int ns3d_plan_pt_internal(ns3d_ctx *c, const T *src, T *dst, const T *dsrc, T *ddst, const T *divV, const ns3d_pt_params *p,

@@ -1375,6 +1375,8 @@ struct SweepArgs {
     int bc_kind, owns_outlet, zlo_halo, zhi_halo;
     int k0, k1; // interior planes [k0,k1) handled by this launch
     int kz;     // planes per block
+    int tx0, ty0; // origin of the launch's tile window in the plane's tile grid (0, 0: the whole grid)
+    const ns3d_tile_window *win;  // host side only: the window asked for / the geometry query (ns3d_launch.h); nullptr: everything
     int cus_off;  // host side only: compute units the stream's CU mask leaves out (ns3d_reserve_cus) — the z-chunking counts the rest
     int l1_bc;    // NS3D_PASS_INPUT_OBEYS_BC: level 1 substitutes the boundary rule too and never uses the face cells of its input
     int no_faces; // NS3D_PASS_SKIP_FACES: the y/z boundary cells of the output are not written (no k_pt_faces launch)
@@ -1755,7 +1757,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
     const int nb = gridDim.x, b = blockIdx.x;
     const int q = nb >> 3, rem = nb & 7, xcd = b & 7, loc = b >> 3;
     const int tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
-    const int tx_t = tile % ntx, ty_t = (tile / ntx) % nty, tz_t = tile / (ntx * nty);
+    const int tx_t = a.tx0 + tile % ntx, ty_t = a.ty0 + (tile / ntx) % nty, tz_t = tile / (ntx * nty);     // ntx × nty: the launch's tile window
     const int ox = 1 + tx_t * (TX - 2), oy = 1 + ty_t * (TY - 2);
     const int kb = a.k0 + tz_t * a.kz;
     const int ke = min(kb + a.kz, a.k1);
@@ -2103,6 +2105,60 @@ static hipError_t launch_faces(hipStream_t s, const SweepArgs<T> &a)
     return hipGetLastError();
 }
 
+// The boundary cells k_pt_faces writes (y-face rows of the interior planes, whole z-face planes), restricted by where their SOURCE cell —
+// the interior cell they clamp onto — lies: inside the box [c0, c1) of cells (want_core) or outside it.  A pass that is split into
+// shells and a core (ns3d_mgpu.cpp box_pass) completes the boundary cells in two launches this way, each reading only cells its own
+// sweeps have written, and the second one touching nothing an unpack has filled in the meantime.
+template <class T>
+__global__ __launch_bounds__(256) void k_pt_faces_region(SweepArgs<T> a, int cx0, int cy0, int cz0, int cx1, int cy1, int cz1, int want_core)
+{
+    const int nx = a.nx, ny = a.ny, nz = a.nz;
+    const long nrows = 2l * nx * (nz - 2), nplanes = 2l * nx * ny;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nrows + nplanes) return;
+    int i, j, k;
+    if (q < nrows) { i = (int)(q % nx); const long r = q / nx; j = (r & 1) ? ny - 1 : 0; k = 1 + (int)(r >> 1); }
+    else { const long r = q - nrows; i = (int)(r % nx); const long t = r / nx; j = (int)(t % ny); k = (t / ny) ? nz - 1 : 0; }
+    if ((k == 0 && a.zlo_halo) || (k == nz - 1 && a.zhi_halo)) return;
+    const int ci = min(max(i, 1), nx - 2), cj = min(max(j, 1), ny - 2), ck = min(max(k, 1), nz - 2);
+    const int in_core = (ci >= cx0) & (ci < cx1) & (cj >= cy0) & (cj < cy1) & (ck >= cz0) & (ck < cz1);
+    if (in_core != (want_core != 0)) return;
+    a.Pout[IX3(i, j, k, nx, ny)] = face_value<T>(a, i, j, k);
+}
+template <class T>
+hipError_t pt_faces_region(hipStream_t s, T *Pout, const ns3d_pt_params &p, const int c0[3], const int c1[3], int want_core)
+{
+    SweepArgs<T> a;
+    a.Pin = Pout; a.Pout = Pout; a.D = nullptr; a.Din = nullptr; a.RHS = nullptr;
+    a.g = make_geo<T>(p.dx, p.dy, p.dz);
+    a.rho_dt = (T)p.rho / (T)p.dt; a.dtau = (T)p.dtau; a.one_m_damp = (T)1.0 - (T)p.damp;
+    a.outlet_val = (T)p.outlet_val; a.rho_g = (T)p.rho * (T)p.g;
+    a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
+    a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = p.z_lo_is_halo; a.zhi_halo = p.z_hi_is_halo;
+    a.k0 = 1; a.k1 = p.nz - 1; a.kz = 1; a.l1_bc = 0; a.no_faces = 0; a.cus_off = 0; a.win = nullptr; a.tx0 = a.ty0 = 0;
+    if (p.nx < 3 || p.ny < 3 || p.nz < 3) return hipErrorInvalidValue;
+    const long cells = 2l * p.nx * (p.nz - 2) + 2l * p.nx * p.ny;
+    hipLaunchKernelGGL(k_pt_faces_region<T>, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, a, c0[0], c0[1], c0[2], c1[0], c1[1], c1[2],
+                       want_core);
+    return hipGetLastError();
+}
+
+// The tile window of a launch: (ntx, nty) come in as the plane's full tile grid and go out as the window's extent; false: nothing to launch
+// (an empty window, or a geometry query that has been answered).
+template <class T>
+static bool apply_tile_window(SweepArgs<T> &a, int TX, int TY, int OV, int &ntx, int &nty)
+{
+    a.tx0 = a.ty0 = 0;
+    if (!a.win) return true;
+    if (a.win->geom) { *a.win->geom = ns3d_tile_geom{TX, TY, OV, ntx, nty}; return false; }
+    if (a.win->x1 > a.win->x0) {
+        const int x0 = max(0, min(a.win->x0, ntx)), x1 = max(x0, min(a.win->x1, ntx));
+        const int y0 = max(0, min(a.win->y0, nty)), y1 = max(y0, min(a.win->y1, nty));
+        a.tx0 = x0; a.ty0 = y0; ntx = x1 - x0; nty = y1 - y0;
+    }
+    return ntx > 0 && nty > 0;
+}
+
 // Workgroups of a kernel that one CU holds at a time (registers, LDS, wave slots), and the CUs of the current device.
 static int device_cus()
 {
@@ -2136,7 +2192,8 @@ static hipError_t launch_sweep2(hipStream_t s, SweepArgs<T> &a, int kz)
     auto kern = a.l1_bc ? k_pt_sweep2<T, WX, WY, CPT, NT, MINW, SEPF, true> : k_pt_sweep2<T, WX, WY, CPT, NT, MINW, SEPF, false>;
     constexpr int TX = 64 * WX, TY = CPT * WY;
     const int nk = a.k1 - a.k0;
-    const int ntx = max(1, (a.nx - 4 + (TX - 2) - 1) / (TX - 2)), nty = max(1, (a.ny - 4 + (TY - 2) - 1) / (TY - 2));
+    int ntx = max(1, (a.nx - 4 + (TX - 2) - 1) / (TX - 2)), nty = max(1, (a.ny - 4 + (TY - 2) - 1) / (TY - 2));
+    if (!apply_tile_window<T>(a, TX, TY, 2, ntx, nty)) return hipSuccess;
     if (kz <= 0 || kz > 90) {
         static const int per_cu = workgroups_per_cu((const void *)k_pt_sweep2<T, WX, WY, CPT, NT, MINW, SEPF>, 64 * WX * WY);
         const long slots = (long)max(8, device_cus() - a.cus_off) * per_cu, tiles = (long)ntx * nty;
@@ -2207,7 +2264,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
     const int sw = min(NS3D_TILE_ORDER, ntx - strip * NS3D_TILE_ORDER);
     const int tx_t = strip * NS3D_TILE_ORDER + ins % sw, ty_t = ins / sw;
 #else
-    const int tx_t = tile % ntx, ty_t = (tile / ntx) % nty, tz_t = tile / (ntx * nty);
+    const int tx_t = a.tx0 + tile % ntx, ty_t = a.ty0 + (tile / ntx) % nty, tz_t = tile / (ntx * nty);     // ntx × nty: the launch's tile window
 #endif
     const int ox = 1 + tx_t * (TX - OV), oy = 1 + ty_t * (TY - OV);
     const int kb = a.k0 + tz_t * a.kz;
@@ -2534,9 +2591,10 @@ static hipError_t launch_sweepN(hipStream_t s, SweepArgs<T> &a, int kz)
     if constexpr (!(TX > OV + 2 && TY > OV + 2 && lds <= 160ul * 1024)) {
         return hipErrorInvalidValue;            // tile too small for this many levels, or its planes exceed the 160 KB of LDS
     } else {
-    if (a.l1_bc || a.no_faces) return hipErrorInvalidValue;      // NS3D_PASS_*: the two-iteration sweep only
+    if (a.l1_bc) return hipErrorInvalidValue;      // NS3D_PASS_INPUT_OBEYS_BC: the two-iteration sweep only
     const int nk = a.k1 - a.k0;
-    const int ntx = max(1, (a.nx - 2 - OV + (TX - OV) - 1) / (TX - OV)), nty = max(1, (a.ny - 2 - OV + (TY - OV) - 1) / (TY - OV));
+    int ntx = max(1, (a.nx - 2 - OV + (TX - OV) - 1) / (TX - OV)), nty = max(1, (a.ny - 2 - OV + (TY - OV) - 1) / (TY - OV));
+    if (!apply_tile_window<T>(a, TX, TY, OV, ntx, nty)) return hipSuccess;
     if (kz <= 0) {
         // chunks per tile column that minimise the z-steps the slowest CU marches: rounds of workgroups × (planes per chunk + the
         // 2(NL−1) steps a chunk spends filling its pipeline) — the tail round of an unlucky tile count (1024²: 1026 tiles on 256
@@ -2575,7 +2633,7 @@ static hipError_t launch_sweepN(hipStream_t s, SweepArgs<T> &a, int kz)
     hipLaunchKernelGGL((k_pt_sweepN<T, NL, WX, WY, CPT, PF, MINW>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX, WY, 1), 0, s, a,
                        ntx, nty);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = launch_faces<T>(s, a);
+    if (e == hipSuccess && !a.no_faces) e = launch_faces<T>(s, a);
     return e;
     }
 }
@@ -2640,7 +2698,7 @@ __global__ __launch_bounds__(64 * WY) void k_pt_sweepD(SweepArgs<T> a, int ntx, 
     const int nb = gridDim.x, b = blockIdx.x;
     const int q = nb >> 3, rem = nb & 7, xcd = b & 7, loc = b >> 3;
     const int tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
-    const int tx_t = tile % ntx, ty_t = (tile / ntx) % nty, tz_t = tile / (ntx * nty);
+    const int tx_t = a.tx0 + tile % ntx, ty_t = a.ty0 + (tile / ntx) % nty, tz_t = tile / (ntx * nty);     // ntx × nty: the launch's tile window
     const int ox = 1 + tx_t * (TX - OV), oy = 1 + ty_t * (TY - OV);
     const int kb = a.k0 + tz_t * a.kz;
     const int ke = min(kb + a.kz, a.k1);
@@ -2944,9 +3002,10 @@ static hipError_t launch_sweepD(hipStream_t s, SweepArgs<T> &a, int kz)
         return hipErrorInvalidValue;
     } else {
         const int nk = a.k1 - a.k0;
-        if (a.l1_bc || a.no_faces) return hipErrorInvalidValue;      // NS3D_PASS_*: the two-iteration sweep only
+        if (a.l1_bc) return hipErrorInvalidValue;      // NS3D_PASS_INPUT_OBEYS_BC: the two-iteration sweep only
         if (a.nx < 4 || a.ny < 4 || (size_t)a.nx * a.ny * sizeof(T) >= (1ull << 32)) return hipErrorInvalidValue;   // 32-bit in-plane byte offsets
-        const int ntx = max(1, (a.nx - 2 - OV + (TX - OV) - 1) / (TX - OV)), nty = max(1, (a.ny - 2 - OV + (TY - OV) - 1) / (TY - OV));
+        int ntx = max(1, (a.nx - 2 - OV + (TX - OV) - 1) / (TX - OV)), nty = max(1, (a.ny - 2 - OV + (TY - OV) - 1) / (TY - OV));
+        if (!apply_tile_window<T>(a, TX, TY, OV, ntx, nty)) return hipSuccess;
         if (kz <= 0 || kz > 90) {
             static const int per_cu = workgroups_per_cu((const void *)k_pt_sweepD<T, NL, WY, CPT, NSL, UNR, OPT>, 64 * WY);
             const long slots = (long)max(8, device_cus() - a.cus_off) * per_cu, tiles = (long)ntx * nty;
@@ -2965,7 +3024,7 @@ static hipError_t launch_sweepD(hipStream_t s, SweepArgs<T> &a, int kz)
         const int ntz = (nk + kz - 1) / kz;
         hipLaunchKernelGGL((k_pt_sweepD<T, NL, WY, CPT, NSL, UNR, OPT>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX, WY, 1), 0, s, a, ntx, nty);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = launch_faces<T>(s, a);
+        if (e == hipSuccess && !a.no_faces) e = launch_faces<T>(s, a);
         return e;
     }
 }
@@ -2982,9 +3041,10 @@ static hipError_t launch_sweepD(hipStream_t s, SweepArgs<T> &a, int kz)
 // rows per thread, one wave per SIMD, 64×20/64×24 with 256 threads, 64×48 with 1024 — are no longer instantiated.)
 template <class T>
 hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout, const T *Din, T *Dout, const T *RHS,
-                     const ns3d_pt_params &p, int k0, int k1, int pass_flags)
+                     const ns3d_pt_params &p, int k0, int k1, int pass_flags, const ns3d_tile_window *win)
 {
     SweepArgs<T> a;
+    a.win = win; a.tx0 = a.ty0 = 0;
     a.Pin = Pin; a.Pout = Pout; a.D = Dout; a.Din = Din; a.RHS = RHS;
     a.g = make_geo<T>(p.dx, p.dy, p.dz);
     a.rho_dt = (T)p.rho / (T)p.dt; a.dtau = (T)p.dtau; a.one_m_damp = (T)1.0 - (T)p.damp;
@@ -3056,9 +3116,10 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
 // Two fused PT iterations (Pin,Din) → (Pout,Dout) for the output planes [k0,k1) (k0 = 1, k1 = nz-1: the whole slab).
 template <class T>
 hipError_t pt_sweep2(hipStream_t s, int variant, const T *Pin, T *Pout, const T *Din, T *Dout, const T *RHS,
-                     const ns3d_pt_params &p, int k0, int k1, int pass_flags)
+                     const ns3d_pt_params &p, int k0, int k1, int pass_flags, const ns3d_tile_window *win)
 {
     SweepArgs<T> a;
+    a.win = win; a.tx0 = a.ty0 = 0;
     a.Pin = Pin; a.Pout = Pout; a.D = Dout; a.Din = Din; a.RHS = RHS;
     a.g = make_geo<T>(p.dx, p.dy, p.dz);
     a.rho_dt = (T)p.rho / (T)p.dt; a.dtau = (T)p.dtau; a.one_m_damp = (T)1.0 - (T)p.damp;
@@ -3342,7 +3403,7 @@ hipError_t pt_persist(hipStream_t s, const T *Pin, T *Pout, const T *Din, T *Dou
     a.outlet_val = (T)p.outlet_val; a.rho_g = (T)p.rho * (T)p.g;
     a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
     a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = 0; a.zhi_halo = 0;
-    a.k0 = 1; a.k1 = p.nz - 1; a.kz = 1; a.l1_bc = 0; a.no_faces = 0; a.cus_off = 0;
+    a.k0 = 1; a.k1 = p.nz - 1; a.kz = 1; a.l1_bc = 0; a.no_faces = 0; a.cus_off = 0; a.win = nullptr; a.tx0 = a.ty0 = 0;
     // the iteration is arithmetic on the CUs the grid occupies plus one hand-over: the smallest workgroup the chip still holds
     // all at once spreads the cells over the most CUs.  NS3D_PERSIST_SHAPE=22|42|44 pins a shape (A/B).
     static const int pin = std::getenv("NS3D_PERSIST_SHAPE") ? std::atoi(std::getenv("NS3D_PERSIST_SHAPE")) : 0;
@@ -3366,7 +3427,7 @@ hipError_t pt_sweep(hipStream_t s, int variant, const T *Pin, T *Pout, T *D, con
     a.outlet_val = (T)p.outlet_val; a.rho_g = (T)p.rho * (T)p.g;
     a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
     a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = p.z_lo_is_halo; a.zhi_halo = p.z_hi_is_halo;
-    a.k0 = k0; a.k1 = k1; a.kz = 1; a.l1_bc = 0; a.no_faces = 0; a.cus_off = 0;
+    a.k0 = k0; a.k1 = k1; a.kz = 1; a.l1_bc = 0; a.no_faces = 0; a.cus_off = 0; a.win = nullptr; a.tx0 = a.ty0 = 0;
     if (k1 <= k0) return hipSuccess;
     // variant = family*100 + kz  (kz = planes marched per block; 0 → default); variant 0 = choose by grid size:
     // grids whose four PT arrays stay resident in L2 / Infinity Cache run best with one thread per cell (neighbours are
@@ -3529,9 +3590,10 @@ hipError_t divtest(hipStream_t s, double d, long n, unsigned long long seed, uns
                                     int, int);                                                               \
     template hipError_t pt_persist<T>(hipStream_t, const T *, T *, const T *, T *, const T *, const ns3d_pt_params &, int, ns3d_persist_state *); \
     template hipError_t pt_sweep2<T>(hipStream_t, int, const T *, T *, const T *, T *, const T *,            \
-                                     const ns3d_pt_params &, int, int, int);                                 \
+                                     const ns3d_pt_params &, int, int, int, const ns3d_tile_window *);       \
     template hipError_t pt_sweepn<T>(hipStream_t, int, int, const T *, T *, const T *, T *, const T *,       \
-                                     const ns3d_pt_params &, int, int, int);                                 \
+                                     const ns3d_pt_params &, int, int, int, const ns3d_tile_window *);       \
+    template hipError_t pt_faces_region<T>(hipStream_t, T *, const ns3d_pt_params &, const int *, const int *, int); \
     template hipError_t residual_max_key<T>(hipStream_t, const T *, const T *, const ns3d_pt_params &,       \
                                             unsigned long long *);                                           \
     template hipError_t divtest<T>(hipStream_t, double, long, unsigned long long, unsigned long long *);   \

@@ -6,6 +6,11 @@
 #include "../../include/ns3d.h"
 
 // k_pt_persist's exchange area (face values handed between workgroups) and error word: owned by a context, freed with it
+// A sweep over a sub-rectangle of a plane's tiles (ns3d_mgpu.cpp box_pass: the shells next to decomposed faces first, the core while
+// the exchange runs).  Tiles [x0,x1) × [y0,y1) of the tile grid the launch would otherwise cover; x1 <= x0 means the whole grid.
+// geom != nullptr: nothing is launched — the launcher reports the tile grid this depth / variant / grid would use.
+struct ns3d_tile_geom { int TX, TY, OV, ntx, nty; };      // columns × rows per tile, overlap 2(NL−1), tiles per plane
+struct ns3d_tile_window { int x0, x1, y0, y1; ns3d_tile_geom *geom; };
 struct ns3d_persist_state {
     void *H = nullptr;
     unsigned *err = nullptr;            // device word: ticket of the latest launch in which a bounded wait expired
@@ -86,10 +91,14 @@ struct ns3d_subbox_batch {
                           int n_iters, ns3d_persist_state *);                                                 \
     template <class T>                                                                                       \
     hipError_t pt_sweep2(hipStream_t, int variant, const T *, T *, const T *, T *, const T *,                \
-                         const ns3d_pt_params &, int k0, int k1, int pass_flags);                            \
+                         const ns3d_pt_params &, int k0, int k1, int pass_flags, const ns3d_tile_window *win = nullptr); \
     template <class T>                                                                                       \
     hipError_t pt_sweepn(hipStream_t, int nlev, int variant, const T *, T *, const T *, T *, const T *,      \
-                         const ns3d_pt_params &, int k0, int k1, int pass_flags);                            \
+                         const ns3d_pt_params &, int k0, int k1, int pass_flags, const ns3d_tile_window *win = nullptr); \
+    /* the boundary cells of Pout whose SOURCE cell (the interior cell they clamp onto) lies inside (want_core) or outside the  \
+     * box [c0,c1) of cells: the partial boundary-cell launches of a split pass (box_pass) */                 \
+    template <class T>                                                                                       \
+    hipError_t pt_faces_region(hipStream_t, T *Pout, const ns3d_pt_params &, const int c0[3], const int c1[3], int want_core); \
     template <class T>                                                                                       \
     hipError_t residual_max_key(hipStream_t, const T *, const T *, const ns3d_pt_params &,                   \
                                 unsigned long long *key_dev);                                                \

@@ -897,10 +897,13 @@ ns3d_pt_params box_params(const ns3d_mgpu *m, const MRank &r)
 }
 
 // ghost layers of `arrs[l]` (same list on every rank) from the neighbours' own layers: x, y, z in turn
+// on_comm: the whole chain — pack, exchange, unpack, dimension after dimension — runs on the ranks' communication streams (box_pass
+// with the shells swept there first, the core sweep on the compute streams meanwhile); the caller joins the streams afterwards
 template <class T>
-int box_exchange(ns3d_mgpu *m, const std::vector<std::vector<BoxArr>> &arrs)
+int box_exchange(ns3d_mgpu *m, const std::vector<std::vector<BoxArr>> &arrs, bool on_comm = false)
 {
     const int n = (int)m->loc.size();
+    auto lane = [&](MRank &r) { return on_comm ? r.comm : compute(r); };
     // message buffer: the largest dimension's faces
     for (int l = 0; l < n; ++l) {
         MRank &r = m->loc[l];
@@ -966,13 +969,20 @@ int box_exchange(ns3d_mgpu *m, const std::vector<std::vector<BoxArr>> &arrs)
                 if (!ok) return fail(NS3D_ERR_STATE, "box_exchange: more than %d pieces in one pack", NS3D_SUBBOX_MAX);
             }
             if (d < 2) {
-                hipError_t e = ns3d_enqueue_subbox_copy<T>(r.ctx, compute(r), pack);
+                hipError_t e = ns3d_enqueue_subbox_copy<T>(r.ctx, lane(r), pack);
                 if (e != hipSuccess) return fail(NS3D_ERR_HIP, "ghost pack launch: %s", hipGetErrorString(e));
             }
         }
-        int rc = exchange_begin(m, blocks, d);
+        int rc = exchange_begin(m, blocks, d, on_comm);
         if (rc) return rc;
-        if ((rc = exchange_end(m, d))) return rc;
+        if (!on_comm) { if ((rc = exchange_end(m, d))) return rc; }
+        else if (!m->rccl)      // the next pack overwrites the message buffer: not before the neighbours have pulled this dimension's
+            for (int l = 0; l < n; ++l) {
+                MRank &r = m->loc[l];
+                ns3d_device_guard g(r.device);
+                for (int side = 0; side < 2; ++side)
+                    if (r.nbr[d][side] >= 0) HIPCHK(0, hipStreamWaitEvent(r.comm, m->loc[r.nbr[d][side]].ev_landed, 0));
+            }
         if (d == 2) continue;
         for (int l = 0; l < n; ++l) {
             MRank &r = m->loc[l];
@@ -991,7 +1001,7 @@ int box_exchange(ns3d_mgpu *m, const std::vector<std::vector<BoxArr>> &arrs)
                                           (long)pc.c[0] * pc.c[1], pc.c[0], pc.c[1], pc.c[2]);
             }
             if (!ok) return fail(NS3D_ERR_STATE, "box_exchange: more than %d pieces in one unpack", NS3D_SUBBOX_MAX);
-            hipError_t e = ns3d_enqueue_subbox_copy<T>(r.ctx, compute(r), unpack);
+            hipError_t e = ns3d_enqueue_subbox_copy<T>(r.ctx, lane(r), unpack);
             if (e != hipSuccess) return fail(NS3D_ERR_HIP, "ghost unpack launch: %s", hipGetErrorString(e));
         }
     }
@@ -1063,10 +1073,126 @@ int box_store(ns3d_mgpu *m, T *const *Pr, T *const *D)
     return NS3D_OK;
 }
 
+// The shells first (round 4; the reference reserves b_width = (8,8,4) "for comm / comp overlap", multi.jl:326, and never
+// uses it).  A pass of `its` ≥ 2 iterations is issued in pieces: on the COMMUNICATION stream the tiles / planes that produce every own
+// cell within G+1 layers of a decomposed face — two plane ranges in z, two strips of tile rows, two strips of tile columns (sub-rectangles
+// of the plane's tile grid: ns3d_tile_window) — then the boundary cells whose source cell lies in those shells, then the whole exchange
+// chain x → y → z (packs and unpacks on that stream too); on the COMPUTE stream, at the same time, the core: the remaining tiles of the
+// remaining planes.  The streams join, and the boundary cells whose source lies in the core are completed (k_pt_faces_region: nothing an
+// unpack has written is touched — a boundary cell on a ghost side has its source in a shell).  Same launches' arithmetic, same bits.
+// Taken from ≈40 M cells per rank on (below, and with NS3D_BOX_OVERLAP=0: the whole box, then the exchange — round 3's order).
+template <class T>
+int box_pass_overlapped(ns3d_mgpu *m, int its, bool &done)
+{
+    done = false;
+    // Default by size: the pieces are seven launches instead of one, and on one GPU (virtual ranks, tools/ab/box_overlap_ab.sh) that costs
+    // +44 % at 130³ per rank, +16 % at 258³ on (2,2,2), +0.7 % at 386³, +3 % at 512³ — below ≈40 M cells per rank the pass is bound by
+    // launch and event latencies, not by the bytes the exchange moves, and keeps round 3's order.  NS3D_BOX_OVERLAP=1 / 0 forces it.
+    const char *ev = std::getenv("NS3D_BOX_OVERLAP");
+    const int forced = ev ? std::atoi(ev) : -1;
+    if (forced == 0 || its < 2 || m->P == 1) return NS3D_OK;
+    if (forced < 0 && (long long)m->nx * m->ny * m->nz < 40ll * 1000 * 1000) return NS3D_OK;
+    const int ip = m->loc[0].st.ip, idd = m->loc[0].st.id, idd_out = idd ^ 1;
+    const int n = (int)m->loc.size();
+    struct Split { int c0[3], c1[3], tx0, tx1, ty0, ty1; ns3d_tile_geom ge; ns3d_pt_params pe; };
+    std::vector<Split> sp((size_t)n);
+    // geometry first (no launch yet): every rank must be able to split, or none does
+    for (int l = 0; l < n; ++l) {
+        MRank &r = m->loc[l];
+        const Box<T> b(m, r);
+        Split &q = sp[(size_t)l];
+        q.pe = box_params<T>(m, r);
+        ns3d_tile_window w{0, 0, 0, 0, &q.ge};
+        ns3d_device_guard g(r.device);
+        hipError_t e = ns3d_enqueue_pass<T>(r.ctx, compute(r), its, (const T *)r.st.P[ip], (T *)r.st.P[ip ^ 1], (const T *)r.st.D[idd],
+                                            (T *)r.st.D[idd_out], (const T *)r.st.R, &q.pe, 1, q.pe.nz - 1, r.plan_v2, r.plan_vn, &w, 1);
+        if (e != hipSuccess) { (void)hipGetLastError(); return NS3D_OK; }         // a shape without the query: the plain order
+        const int S[2] = {q.ge.TX - q.ge.OV, q.ge.TY - q.ge.OV}, nt[2] = {q.ge.ntx, q.ge.nty}, half = q.ge.OV / 2;
+        int tlo[2], thi[2];
+        for (int d = 0; d < 3; ++d) {
+            const int k0 = b.g[d][0] + 1, k1 = b.g[d][0] + b.n[d] - 1;            // own inner cells [k0,k1) of the box
+            int lo = r.nbr[d][0] >= 0 ? std::min(k0 + b.G + 1, b.e[d] - 1) : 1, hi = r.nbr[d][1] >= 0 ? std::max(k1 - (b.G + 1), lo) : b.e[d] - 1;
+            if (d < 2) {     // whole tiles: tile t produces the cells [begin(t), begin(t+1))
+                auto begin = [&](int t) { return t <= 0 ? 1 : (t >= nt[d] ? b.e[d] - 1 : 1 + t * S[d] + half); };
+                int a = 0;
+                while (a < nt[d] && begin(a) < lo) ++a;
+                int z = nt[d];
+                if (r.nbr[d][1] >= 0) { z = nt[d] - 1; while (z > a && begin(z) > hi) --z; }
+                if (z < a) z = a;
+                tlo[d] = a; thi[d] = z;
+                lo = begin(a); hi = begin(z);
+            }
+            q.c0[d] = lo; q.c1[d] = std::max(lo, hi);
+        }
+        q.tx0 = tlo[0]; q.tx1 = thi[0]; q.ty0 = tlo[1]; q.ty1 = thi[1];
+    }
+    std::vector<std::vector<BoxArr>> arrs;
+    for (int l = 0; l < n; ++l) {
+        MRank &r = m->loc[l];
+        Split &q = sp[(size_t)l];
+        ns3d_device_guard g(r.device);
+        HIPCHK(0, hipEventRecord(r.ev_pass, compute(r)));
+        HIPCHK(0, hipStreamWaitEvent(r.comm, r.ev_pass, 0));
+        auto piece = [&](hipStream_t st, int k0, int k1, int x0, int x1, int y0, int y1) -> int {
+            if (k1 <= k0 || x1 <= x0 || y1 <= y0) return NS3D_OK;
+            ns3d_tile_window w{x0, x1, y0, y1, nullptr};
+            // the planned tile SHAPE with the z-chunking left to the launcher: a strip of a few tiles must be cut into enough z-chunks to
+            // occupy the chip (a planned "one chunk per tile column" would march 9 tiles through the whole z range on 9 CUs)
+            const int v2 = r.plan_v2 >= 0 ? r.plan_v2 / 100 * 100 : -1, vn = r.plan_vn >= 0 ? r.plan_vn / 100 * 100 : -1;
+            hipError_t e = ns3d_enqueue_pass<T>(r.ctx, st, its, (const T *)r.st.P[ip], (T *)r.st.P[ip ^ 1], (const T *)r.st.D[idd],
+                                                (T *)r.st.D[idd_out], (const T *)r.st.R, &q.pe, k0, k1, v2, vn, &w, 1);
+            return e == hipSuccess ? NS3D_OK : fail(NS3D_ERR_HIP, "box sweep launch: %s", hipGetErrorString(e));
+        };
+        const int nzb = q.pe.nz, ntx = q.ge.ntx, nty = q.ge.nty;
+        int rc;
+        if ((rc = piece(r.comm, 1, q.c0[2], 0, ntx, 0, nty))) return rc;                       // z shells: whole planes
+        if ((rc = piece(r.comm, q.c1[2], nzb - 1, 0, ntx, 0, nty))) return rc;
+        if ((rc = piece(r.comm, q.c0[2], q.c1[2], 0, ntx, 0, q.ty0))) return rc;               // y shells: strips of tile rows
+        if ((rc = piece(r.comm, q.c0[2], q.c1[2], 0, ntx, q.ty1, nty))) return rc;
+        if ((rc = piece(r.comm, q.c0[2], q.c1[2], 0, q.tx0, q.ty0, q.ty1))) return rc;         // x shells: strips of tile columns
+        if ((rc = piece(r.comm, q.c0[2], q.c1[2], q.tx1, ntx, q.ty0, q.ty1))) return rc;
+        hipError_t e = ns3d_enqueue_faces_region<T>(r.ctx, r.comm, (T *)r.st.P[ip ^ 1], &q.pe, q.c0, q.c1, 0);
+        if (e != hipSuccess) return fail(NS3D_ERR_HIP, "box boundary-cell launch: %s", hipGetErrorString(e));
+        if ((rc = piece(compute(r), q.c0[2], q.c1[2], q.tx0, q.tx1, q.ty0, q.ty1))) return rc;  // the core, meanwhile
+        arrs.push_back({{r.st.P[ip ^ 1], false, m->G + 1}, {r.st.D[idd_out], true, m->G}});
+    }
+    int rc = box_exchange<T>(m, arrs, true);
+    if (rc) return rc;
+    for (int l = 0; l < n; ++l) {       // join: the core's stream sees the ghosts; nobody overwrites what a neighbour still pulls
+        MRank &r = m->loc[l];
+        ns3d_device_guard g(r.device);
+        HIPCHK(0, hipEventRecord(r.ev_landed, r.comm));
+        HIPCHK(0, hipStreamWaitEvent(compute(r), r.ev_landed, 0));
+    }
+    if (!m->rccl)
+        for (int l = 0; l < n; ++l) {
+            MRank &r = m->loc[l];
+            ns3d_device_guard g(r.device);
+            for (int d = 0; d < 3; ++d)
+                for (int side = 0; side < 2; ++side)
+                    if (r.nbr[d][side] >= 0) HIPCHK(0, hipStreamWaitEvent(compute(r), m->loc[r.nbr[d][side]].ev_landed, 0));
+        }
+    for (int l = 0; l < n; ++l) {
+        MRank &r = m->loc[l];
+        Split &q = sp[(size_t)l];
+        ns3d_device_guard g(r.device);
+        hipError_t e = ns3d_enqueue_faces_region<T>(r.ctx, compute(r), (T *)r.st.P[ip ^ 1], &q.pe, q.c0, q.c1, 1);
+        if (e != hipSuccess) return fail(NS3D_ERR_HIP, "box boundary-cell launch: %s", hipGetErrorString(e));
+        r.st.ip = ip ^ 1; r.st.id = idd_out;
+    }
+    done = true;
+    return NS3D_OK;
+}
+
 // one pass: `its` (1 … G+1) PT iterations on every local rank's box, then the ghosts of the new state
 template <class T>
 int box_pass(ns3d_mgpu *m, int its)
 {
+    {
+        bool done = false;
+        const int rc = box_pass_overlapped<T>(m, its, done);
+        if (rc || done) return rc;
+    }
     const int ip = m->loc[0].st.ip, idd = m->loc[0].st.id;
     const int idd_out = its >= 2 ? idd ^ 1 : idd;
     std::vector<std::vector<BoxArr>> arrs;

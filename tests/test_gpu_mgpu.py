@@ -295,10 +295,13 @@ def test_deep_ghosts_on_a_cartesian_topology_equal_the_global_pt_solve(hip, dims
         c = cart_coords(r, dims)
         return np.asfortranarray(A[tuple(slice(c[d] * (n[d] - 2), c[d] * (n[d] - 2) + n[d] - shrink) for d in range(3))])
 
-    for deep, force in (("1", 0), ("1", 2), ("1", 3), ("1", 4), ("0", 0)):
+    # overlap: the shell-first order of a pass (round 4: shells and the exchange chain on the communication stream, the core sweep
+    # meanwhile; the library takes it by itself from ≈40 M cells per rank on) forced on and off
+    for deep, force, overlap in (("1", 0, "1"), ("1", 0, "0"), ("1", 2, "1"), ("1", 3, "1"), ("1", 4, "1"), ("1", 4, "0"), ("0", 0, "0")):
         if force > depth:
             continue
         monkeypatch.setenv("NS3D_CART_DEEP", deep)
+        monkeypatch.setenv("NS3D_BOX_OVERLAP", overlap)
         mg = MultiGpu.create([0] * P, *n, "strict", dims=dims, own_streams=OWN_STREAMS)
         mg.set_temporal(depth)
         for c in mg.contexts:
@@ -309,10 +312,10 @@ def test_deep_ghosts_on_a_cartesian_topology_equal_the_global_pt_solve(hip, dims
         p = hip.pt_params(Pr[0], g["rho"], g["dt"], g["dtau"], g["damp"], g["dx"], g["dy"], g["dz"], 0, True, 0.25, 0.0)
         it, errs = mg.pt_solve_slab(Pr, D, R, p, eps, niter, nchk, mul, div)
         mg.sync()
-        assert it == it_ref and errs == errs_ref, (deep, force)
+        assert it == it_ref and errs == errs_ref, (deep, force, overlap)
         for r in range(P):
-            assert np.array_equal(hip.to_numpy(Pr[r]), cut(Pref, r, 0)), (deep, force, r)
-            assert np.array_equal(hip.to_numpy(D[r]), cut(Dref, r, 2)), (deep, force, r)
+            assert np.array_equal(hip.to_numpy(Pr[r]), cut(Pref, r, 0)), (deep, force, overlap, r)
+            assert np.array_equal(hip.to_numpy(D[r]), cut(Dref, r, 2)), (deep, force, overlap, r)
         if deep == "1":
             cap = min([depth] + [n[d] - 2 for d in range(3) if dims[d] > 1])
             assert 1 <= mg.pass_depth() <= cap and (force == 0 or mg.pass_depth() == min(force, cap)), (mg.pass_depth(), force, cap)
