@@ -3376,8 +3376,18 @@ static hipError_t pt_persist_shape(hipStream_t s, const SweepArgs<T> &a, int n_i
     if (ps->ticket == 0u) pa.ticket = ps->ticket = 1u;       // 2³² launches later: tickets start over (0 means "never failed")
     pa.nbx = nbx; pa.nby = nby; pa.nbz = nbz; pa.n_iters = n_iters; pa.xcds = remap ? 8 : 1;
     { const char *fv = std::getenv("NS3D_PERSIST_FAULT"); pa.fault = (fv && *fv == '1') ? 1 : 0; }      // read per launch: a test hook
-    void *kargs[] = {(void *)&pa};
-    e = hipLaunchCooperativeKernel((const void *)k_pt_persist<T, BY, BZ>, dim3((unsigned)blocks), dim3(BX, BY, BZ), kargs, 0, s);
+    // An ORDINARY launch (round 4): the kernel needs its workgroups resident together, not a grid barrier — the grid is sized to fit the
+    // chip (above), and a launch that nevertheless finds CUs taken ends in the bounded waits and the caller's redo, not in a wrong field.
+    // hipLaunchCooperativeKernel costs ≈10 µs more per block: 63×38×38, blocks of 37: 3.78 → 3.49 µs per iteration.
+    // NS3D_PERSIST_PLAIN=0: the cooperative launch (refuses instead of waiting when the grid cannot be resident).
+    static const bool plain = !(std::getenv("NS3D_PERSIST_PLAIN") && *std::getenv("NS3D_PERSIST_PLAIN") == '0');
+    if (plain) {
+        hipLaunchKernelGGL((k_pt_persist<T, BY, BZ>), dim3((unsigned)blocks), dim3(BX, BY, BZ), 0, s, pa);
+        e = hipGetLastError();
+    } else {
+        void *kargs[] = {(void *)&pa};
+        e = hipLaunchCooperativeKernel((const void *)k_pt_persist<T, BY, BZ>, dim3((unsigned)blocks), dim3(BX, BY, BZ), kargs, 0, s);
+    }
     if (e != hipSuccess) return e;
     if ((e = hipEventRecord(ps->ev, s)) != hipSuccess) return e;
     // NS3D_COOP_CHECK=1: check at once (blocking) and fail the launch instead of leaving the redo to the caller's next synchronisation
