@@ -218,9 +218,6 @@ def main():
                     help="compute launches leave this many CUs out (ns3d_reserve_cus: room for RCCL's kernels beside the interior sweep)")
     ap.add_argument("--interior-chunks", type=int, default=int(os.environ.get("NS3D_BENCH_INTERIOR_CHUNKS", "1")),
                     help="N>1: the interior sweep of a z-slab pass in this many launches (ns3d_mgpu_set_interior_chunks)")
-    ap.add_argument("--pass-chain", dest="no_pass_chain", action="store_false", default=os.environ.get("NS3D_PASS_CHAIN") != "1",
-                    help="A/B: two-iteration passes neither write nor read the boundary cells between them (include/ns3d.h NS3D_PASS_*; "
-                         "measured slower on the reference's grid, so off by default, as in ns3d_pt_iterate)")
     ap.add_argument("--no-config-b", action="store_true", default=os.environ.get("NS3D_BENCH_NO_CONFIG_B") == "1",
                     help="N=1: skip the `config_b` object (the same Poisson-only measurement on the reference's own 255x153x153 "
                          "grid and spacings, STRICT and FAST, a few seconds)")
@@ -444,29 +441,16 @@ def run_case(a, world, rank, device, ndev, shared_gpu, p, scaling):
         if slab is not None:
             slab.iterate(n)
             return
-        sched = schedule(n)
-        prev_skipped = False
-        for i, its in enumerate(sched):
+        for its in schedule(n):
             if its == 1:
                 K.pt_sweep(st["Pr"], st["Pb"], st["D"], rhs, pt, 1, nz - 1, ctx=ctx)
                 st["Pr"], st["Pb"] = st["Pb"], st["Pr"]
-                prev_skipped = False
                 continue
-            # the boundary cells between two multi-iteration passes are neither written nor read (what ns3d_pt_iterate does
-            # inside a residual-check block, ns3d_api.cpp enqueue_iters; include/ns3d.h NS3D_PASS_*): the first pass of the
-            # run reads them as they are, the last one writes them
-            flags = 0
-            if not a.no_pass_chain and its == 2:        # two-iteration passes chain (k_pt_sweep2); deeper ones keep their boundary cells
-                nxt_deep = i + 1 < len(sched) and sched[i + 1] == 2
-                flags = (L.NS3D_PASS_INPUT_OBEYS_BC if prev_skipped else 0) | (L.NS3D_PASS_SKIP_FACES if nxt_deep else 0)
-                prev_skipped = nxt_deep
-            ctx.set_pt_pass_flags(flags)
             if its == 2:
                 K.pt_sweep2(st["Pr"], st["Pb"], st["D"], st["D2"], rhs, pt, ctx=ctx)
             else:
                 K.pt_sweepn(its, st["Pr"], st["Pb"], st["D"], st["D2"], rhs, pt, ctx=ctx)
             st["Pr"], st["Pb"], st["D"], st["D2"] = st["Pb"], st["Pr"], st["D2"], st["D"]
-        ctx.set_pt_pass_flags(0)
 
     # plan phase, untimed and outside the warmup count: ns3d_plan_pt times the tile shapes of k_pt_sweep2 / k_pt_sweepN on
     # these arguments, decides how many iterations a pass advances, and the process keeps the winner (same bits either way)
@@ -512,35 +496,20 @@ def run_case(a, world, rank, device, ndev, shared_gpu, p, scaling):
     verified = None
     if not a.no_verify:
         vd = max(passes) if passes else 0
-        nver = vd
         if vd >= 1:
             vctx = ctx
             if world == 1:
                 P0, D0 = st["Pr"], st["D"]
                 Pa, Da = st["Pb"], (st["D2"] if st["D2"] is not None else K.clone(D0))
-                def one_pass(Pi, Po, Di, Do, flags):
-                    ctx.set_pt_pass_flags(flags)
-                    if vd == 2:
-                        K.pt_sweep2(Pi, Po, Di, Do, rhs, pt, ctx=ctx)
-                    else:
-                        K.pt_sweepn(vd, Pi, Po, Di, Do, rhs, pt, ctx=ctx)
-                    ctx.set_pt_pass_flags(0)
                 if vd == 1:
                     Da = K.clone(D0)
                     K.pt_sweep(P0, Pa, Da, rhs, pt, 1, nz - 1, ctx=ctx)
-                elif a.no_pass_chain or vd != 2:
-                    one_pass(P0, Pa, D0, Da, 0)
+                elif vd == 2:
+                    K.pt_sweep2(P0, Pa, D0, Da, rhs, pt, ctx=ctx)
                 else:
-                    # the timed passes are chained (boundary cells neither written nor read in between): check TWO of them, the
-                    # first without its boundary cells, the second forming them — against 2·depth single sweeps
-                    Pm, Dm = K.clone(P0), K.clone(D0)
-                    Pm.fill_(float("nan"))               # whatever the first pass leaves unwritten must not matter
-                    one_pass(P0, Pm, D0, Dm, L.NS3D_PASS_SKIP_FACES)
-                    one_pass(Pm, Pa, Dm, Da, L.NS3D_PASS_INPUT_OBEYS_BC)
-                    del Pm, Dm
-                    nver = 2 * vd
+                    K.pt_sweepn(vd, P0, Pa, D0, Da, rhs, pt, ctx=ctx)
                 halo = lambda X: None
-                verify["against"] = "%d launches of the one-thread-per-cell sweep (k_pt_sweep_naive)" % nver
+                verify["against"] = "%d launches of the one-thread-per-cell sweep (k_pt_sweep_naive)" % vd
             else:
                 P0, D0 = K.zeros((nx, ny, nz), tdt, dev), K.zeros((nx - 2, ny - 2, nz - 2), tdt, dev)
                 Pa, Da = K.zeros((nx, ny, nz), tdt, dev), K.zeros((nx - 2, ny - 2, nz - 2), tdt, dev)
@@ -551,7 +520,7 @@ def run_case(a, world, rank, device, ndev, shared_gpu, p, scaling):
                 verify["against"] = "%d x {one-thread-per-cell sweep; update_halo!(Pr)} per rank" % vd
             vctx.set_pt_variant(100)
             Pq, Pw, Dq = K.clone(P0), K.clone(P0), K.clone(D0)
-            for _ in range(nver):
+            for _ in range(vd):
                 K.pt_sweep(Pq, Pw, Dq, rhs, pt, 1, nz - 1, ctx=vctx)
                 halo(Pw)
                 Pq, Pw = Pw, Pq
@@ -569,7 +538,7 @@ def run_case(a, world, rank, device, ndev, shared_gpu, p, scaling):
                 t = torch.tensor([1.0 if okv else 0.0, 1.0 if bitwise else 0.0, -rel], dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MIN)
                 okv, bitwise, rel = bool(t[0].item()), bool(t[1].item()), -t[2].item()
-            verify.update(iterations=nver, bitwise=bitwise, rel_l2=rel, chained_passes=bool(world == 1 and vd == 2 and not a.no_pass_chain),
+            verify.update(iterations=vd, bitwise=bitwise, rel_l2=rel,
                           criterion="bitwise" if a.mode == "strict" else "rel_l2 <= 1e-6 (BASELINE north_star tolerance)")
             verified = okv
             del Pq, Pw, Dq
@@ -695,7 +664,7 @@ def json_line(a, world, r):
                    "local_grid": r["local_grid"], "global_grid": r["global_grid"],
                    "decomposition": "z-slabs x%d" % world,
                    "transport": r["transport"], "rccl_ranks": r["rccl_ranks"],
-                   "reserved_cus": a.reserve_cus, "interior_chunks": a.interior_chunks, "pass_chain": not a.no_pass_chain,
+                   "reserved_cus": a.reserve_cus, "interior_chunks": a.interior_chunks,
                    "arith_mode": a.mode, "arith_build": r["arith_build"], "variant": a.variant,
                    "pt_depth": its_per_launch, "pt2_variant": r["pt2_variant"],
                    "ptn_variant": r["ptn_variant"], "residual_after_run": r["err"], "finite": r["finite"],

@@ -109,23 +109,6 @@ int ns3d_set_ptn_variant(ns3d_ctx *ctx, int variant);
  * available with float32 fields only (k_pt_sweepN has registers for a fifth level there and nowhere else). */
 int ns3d_set_pt_depth(ns3d_ctx *ctx, int depth);
 int ns3d_set_autotune(ns3d_ctx *ctx, int on);
-/* Boundary cells between passes (round 4).  set_bc_Pr! (multi.jl:175-184, four launches per iteration in the reference) makes every
- * face / edge / corner cell of Pr a function of its interior, so between two multi-iteration passes nobody needs them in memory:
- *   NS3D_PASS_SKIP_FACES      the pass does not write the y/z boundary cells of its output (no boundary-cell launch behind the sweep);
- *                             such an output is valid input ONLY for a pass with NS3D_PASS_INPUT_OBEYS_BC;
- *   NS3D_PASS_INPUT_OBEYS_BC  promise: the boundary cells of Pr_in equal the boundary rule applied to its interior (true for the
- *                             output of any sweep); level 1 then forms them instead of reading them.  Same bits.
- * Both honoured by ns3d_pt_sweep2 (every tile shape); ns3d_pt_sweepn honours NS3D_PASS_SKIP_FACES and refuses a call with
- * NS3D_PASS_INPUT_OBEYS_BC (where deeper passes run the boundary-cell launch is 0.5 % of a pass).  With ns3d_set_pass_chain(ctx, 1) (or NS3D_PASS_CHAIN=1) ns3d_pt_iterate / ns3d_pt_solve
- * chain the TWO-iteration passes of a residual-check block this way by themselves: the first pass of a block reads the caller's
- * cells as they are and the last one writes them, so callers see complete fields.  OFF by default: measured on the reference's
- * 255×153×153 grid the chained passes are 2.5 % (STRICT) / 4 % (FAST) SLOWER than pass + boundary-cell launch — every tile of
- * that grid touches a face, and forming the cells costs more than the launch it saves (profiles/r4_pass_chain_ab.log).
- * ns3d_set_pt_pass_flags sets the flags for the caller's OWN ns3d_pt_sweep2 / ns3d_pt_sweepn calls (bench.py's timed loop). */
-#define NS3D_PASS_INPUT_OBEYS_BC 1
-#define NS3D_PASS_SKIP_FACES 2
-int ns3d_set_pt_pass_flags(ns3d_ctx *ctx, int flags);
-int ns3d_set_pass_chain(ns3d_ctx *ctx, int on);
 int ns3d_last_pt2_variant(const ns3d_ctx *ctx);
 int ns3d_last_ptn_variant(const ns3d_ctx *ctx);   /* tile variant of the latest N-iteration launch */
 int ns3d_last_pt_depth(const ns3d_ctx *ctx);      /* PT iterations of the latest multi-iteration pass; after ns3d_plan_pt: the planned depth */

@@ -116,7 +116,6 @@ ns3d_ctx *ns3d_create(int device, int flags)
     if (const char *ev = std::getenv("NS3D_PT2_VARIANT")) c->pt2_variant = std::atoi(ev);   // experiments without an API call
     c->ptn_variant = 0;
     if (const char *ev = std::getenv("NS3D_PTN_VARIANT")) c->ptn_variant = std::atoi(ev);
-    if (const char *ev = std::getenv("NS3D_PASS_CHAIN")) c->pass_chain = std::atoi(ev) ? 1 : 0;
     c->pt_depth = 0;
     if (const char *ev = std::getenv("NS3D_PT_DEPTH")) c->pt_depth = std::atoi(ev);
     c->autotune = 1;
@@ -271,20 +270,6 @@ int ns3d_set_ptn_variant(ns3d_ctx *c, int v)
 }
 
 int ns3d_persist_faults(const ns3d_ctx *c) { return c ? (int)c->persist.faults : -1; }
-int ns3d_set_pt_pass_flags(ns3d_ctx *c, int flags)
-{
-    if (!c) return fail(NS3D_ERR_ARG, "ns3d_set_pt_pass_flags: null context");
-    if (flags & ~(NS3D_PASS_INPUT_OBEYS_BC | NS3D_PASS_SKIP_FACES)) return fail(NS3D_ERR_ARG, "ns3d_set_pt_pass_flags: unknown flags %d", flags);
-    c->pass_flags = flags;
-    return NS3D_OK;
-}
-int ns3d_set_pass_chain(ns3d_ctx *c, int on)
-{
-    if (!c) return fail(NS3D_ERR_ARG, "ns3d_set_pass_chain: null context");
-    if ((on != 0) != (c->pass_chain != 0)) c->clear_graphs();       // captured blocks hold the other form
-    c->pass_chain = on ? 1 : 0;
-    return NS3D_OK;
-}
 int ns3d_set_pt_depth(ns3d_ctx *c, int depth)
 {
     if (!c) return fail(NS3D_ERR_ARG, "ns3d_set_pt_depth: null context");
@@ -366,9 +351,6 @@ static int ensure_pingpong(ns3d_ctx *c, const ns3d_pt_params *p, T **buf)
         }
         HIPCHK(c, hipMalloc(&c->pingpong, need));
         c->pingpong_bytes = need;
-        // chained passes leave the y/z boundary cells of this buffer unwritten and never use what they read there; zeros keep the
-        // exact-division build's range guard (which tests values as they are loaded) from seeing arbitrary bit patterns
-        HIPCHK(c, hipMemsetAsync(c->pingpong, 0, need, c->stream));
     }
     *buf = (T *)c->pingpong;
     return NS3D_OK;
@@ -451,8 +433,7 @@ static Plan tune_plan(ns3d_ctx *c, hipStream_t s, int mode, const T *src, T *dst
         bool ok = true;
         for (int rep = 0; rep <= timed && ok; ++rep) {     // one untimed launch, then `timed` timed ones
             if (rep == 1) ok = hipEventRecord(c->tune_ev[0], s) == hipSuccess;
-            // timed as the passes inside a block run: without the boundary-cell launch behind the sweep (interior results unchanged)
-            const int tf = ((c->pass_chain && depth == 2) ? NS3D_PASS_SKIP_FACES : 0) | ((c->reserved_cus / 8) << 8);
+            const int tf = (c->reserved_cus / 8) << 8;      // compute units the launch must not count on
             hipError_t e = depth == 2 ? DISPATCHM(mode, pt_sweep2<T>(s, v, src, dst, dsrc, ddst, divV, *p, k0, k1, tf))
                                       : DISPATCHM(mode, pt_sweepn<T>(s, depth, v, src, dst, dsrc, ddst, divV, *p, k0, k1, tf));
             ok = ok && e == hipSuccess;
@@ -594,7 +575,7 @@ static hipError_t launch_pass(ns3d_ctx *c, hipStream_t s, int depth, const Plan 
 {
     const int mode = mode_of(c, p->dx, p->dy, p->dz);
     c->last_depth = depth;
-    const int flags = c->pass_flags | more_flags | ((c->reserved_cus / 8) << 8);   // bits 8…: compute units the launch must not count on (in eights)
+    const int flags = more_flags | ((c->reserved_cus / 8) << 8);   // bits 8…: compute units the launch must not count on (in eights)
     if (depth == 2) {
         c->last_pt2 = pl.v2;
         return DISPATCHM(mode, pt_sweep2<T>(s, pl.v2, src, dst, dsrc, ddst, divV, *p, k0, k1, flags, win));
@@ -777,31 +758,16 @@ static hipError_t enqueue_iters(ns3d_ctx *c, hipStream_t s, int n, bool two, T *
     Plan pl{2, 0, 0, true};
     if (two && n >= 2)
         pl = pick_plan<T>(c, s, mode_of(c, p->dx, p->dy, p->dz), src, dst, dsrc, ddst, divV, p, 1, p->nz - 1, may_tune);
-    // Between two deep passes of a block nobody reads the boundary cells of the iterate: the pass in front does not write its
-    // y/z faces (NS3D_PASS_SKIP_FACES: no k_pt_faces launch — 5.6 µs beside a 52 µs pass at 255×153×153) and the pass behind
-    // forms them from the boundary rule (NS3D_PASS_INPUT_OBEYS_BC).  The first pass of a block reads the caller's cells as they
-    // are; the last one — and any pass in front of a single sweep, which reads them — writes them.  Same bits.
-    const int user_flags = c->pass_flags;
-    bool prev_skipped = false;
     for (int it = 0; it < n && e == hipSuccess;) {
         const int d = next_depth(pl, two, n - it);
         if (d >= 2) {
-            // chained: two-iteration passes only (k_pt_sweep2 has the instantiation; at the sizes where deeper passes run the
-            // boundary-cell launch is 0.5 % of a pass and the deep kernels keep round 3's form)
-            const int rest = n - it - d;
-            const bool next_is_two = d == 2 && rest >= 2 && next_depth(pl, two, rest) == 2;
-            c->pass_flags = (c->pass_chain && d == 2) ? ((prev_skipped ? NS3D_PASS_INPUT_OBEYS_BC : 0) | (next_is_two ? NS3D_PASS_SKIP_FACES : 0)) : 0;
-            prev_skipped = (c->pass_flags & NS3D_PASS_SKIP_FACES) != 0;
             e = launch_pass<T>(c, s, d, pl, src, dst, dsrc, ddst, divV, p, 1, p->nz - 1);
             T *t = dsrc; dsrc = ddst; ddst = t;
-        } else {
-            prev_skipped = false;
+        } else
             e = DISPATCHG(c, p->dx, p->dy, p->dz, pt_sweep<T>(s, c->pt_variant, src, dst, dsrc, divV, *p, 1, p->nz - 1));
-        }
         it += d;
         T *t = src; src = dst; dst = t;
     }
-    c->pass_flags = user_flags;
     return e;
 }
 

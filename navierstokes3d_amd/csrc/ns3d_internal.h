@@ -33,8 +33,6 @@ struct ns3d_ctx {
     int last_pt2;    // variant of the latest two-iteration launch (0: built-in choice by grid)
     int last_ptn;    // variant of the latest N-iteration launch
     int last_depth;  // PT iterations of the latest multi-iteration pass
-    int pass_flags = 0;  // NS3D_PASS_* of the next ns3d_pt_sweep2 / _sweepn launch (ns3d_set_pt_pass_flags; enqueue_iters sets it per pass)
-    int pass_chain = 0;  // ns3d_pt_iterate / ns3d_pt_solve skip the boundary cells between the two-iteration passes of a block (ns3d_set_pass_chain; off: measured slower)
     hipEvent_t tune_ev[2];
     hipEvent_t fence;
     struct BlockGraph {

@@ -1378,8 +1378,7 @@ struct SweepArgs {
     int tx0, ty0; // origin of the launch's tile window in the plane's tile grid (0, 0: the whole grid)
     const ns3d_tile_window *win;  // host side only: the window asked for / the geometry query (ns3d_launch.h); nullptr: everything
     int cus_off;  // host side only: compute units the stream's CU mask leaves out (ns3d_reserve_cus) — the z-chunking counts the rest
-    int l1_bc;    // NS3D_PASS_INPUT_OBEYS_BC: level 1 substitutes the boundary rule too and never uses the face cells of its input
-    int no_faces; // NS3D_PASS_SKIP_FACES: the y/z boundary cells of the output are not written (no k_pt_faces launch)
+    int no_faces; // NS3D_PASS_SKIP_FACES: no k_pt_faces launch behind the sweep (a split pass completes the boundary cells itself: box_pass)
 };
 
 // value stored on the x planes for target plane kk (0-based)
@@ -1733,11 +1732,7 @@ static hipError_t launch_pipe_auto(hipStream_t s, SweepArgs<T> &a, int kz)
 // sweep, or (SEPF) only the x-face cell beside an interior cell, the y/z faces following in k_pt_faces_*.  z planes that
 // are inter-slab halos are not supported here: z-slab ranks pass buffers extended by a second ghost plane (slab.py).
 // =========================================================================================================
-// L1BC (round 4, NS3D_PASS_INPUT_OBEYS_BC): level 1 forms the boundary cells of its INPUT from the boundary rule as level 2 does
-// with those of P¹, instead of reading them — the pass in front then need not write them (NS3D_PASS_SKIP_FACES: no k_pt_faces
-// launch behind its sweep).  A template parameter, not a run-time flag: the L1BC = false instantiation is round 3's kernel, bit
-// for bit and instruction for instruction (a run-time test in the hot loop cost 5 % at 512³ whether it was taken or not).
-template <class T, int WX, int WY, int CPT, bool NT, int MINW = 1, bool SEPF = false, bool L1BC = false>
+template <class T, int WX, int WY, int CPT, bool NT, int MINW = 1, bool SEPF = false>
 __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a, int ntx, int nty)
 {
     constexpr int TX = 64 * WX, TY = CPT * WY, PX = TX + 2;
@@ -1900,26 +1895,12 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
         for (int r = 0; r < CPT; ++r) {
             const int lr = wy * CPT + r;
             const T c = p0c[r];
-            T w = l0[(lr + 1) * PX + lx], e = l0[(lr + 1) * PX + lx + 2];
-            T sv = r == 0 ? l0[lr * PX + lx + 1] : p0c[r - 1 < 0 ? 0 : r - 1];
-            T nv = r == CPT - 1 ? l0[(lr + 2) * PX + lx + 1] : p0c[r + 1 > CPT - 1 ? CPT - 1 : r + 1];
-            T bv = p0m[r], tv = p0p[r];
-            if constexpr (L1BC) {           // the input's boundary cells are formed, not used (they may never have been written)
-                if (tile_on_xy_face) {
-                    const int gjf = oy + lr;
-                    if (xlo_adj) w = xface_val<T>(a, false, c, k1);
-                    if (xhi_adj) e = xface_val<T>(a, true, c, k1);
-                    if (gjf == 1) sv = c;
-                    if (gjf == ny - 2) nv = c;
-                }
-                if constexpr (EDGE) {
-                    if (k1 == 1) bv = c;
-                    if (k1 == nz - 2) tv = c;
-                }
-            }
+            const T w = l0[(lr + 1) * PX + lx], e = l0[(lr + 1) * PX + lx + 2];
+            const T sv = r == 0 ? l0[lr * PX + lx + 1] : p0c[r - 1 < 0 ? 0 : r - 1];
+            const T nv = r == CPT - 1 ? l0[(lr + 2) * PX + lx + 1] : p0c[r + 1 > CPT - 1 ? CPT - 1 : r + 1];
             const T res = decltype(slow_tag)::value
-                              ? poisson_rhs_slow<T>(c, w, e, sv, nv, bv, tv, r0[r], a.rho_dt, g)
-                              : poisson_rhs_nochk<T>(c, w, e, sv, nv, bv, tv, r0[r], a.rho_dt, g);
+                              ? poisson_rhs_slow<T>(c, w, e, sv, nv, p0m[r], p0p[r], r0[r], a.rho_dt, g)
+                              : poisson_rhs_nochk<T>(c, w, e, sv, nv, p0m[r], p0p[r], r0[r], a.rho_dt, g);
             d1n[r] = d0[r] * a.one_m_damp + a.dtau * res;
             p1p[r] = c + a.dtau * d1n[r];
         }
@@ -2039,8 +2020,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
     constexpr int UNR = NS3D_STEP_UNROLL > 0 ? NS3D_STEP_UNROLL : (CPT <= 2 ? 4 : 1);
     int s = 0;
     if constexpr (UNR > 1) {
-        // bulk: s ≥ 2 and plane k2 = kb−2+s in [2, nz−3]; with L1BC level 1's plane k1 = k2+1 must stay below nz−2 as well
-        const int hot_lo = max(2, 4 - kb), hot_hi = min(nsteps, nz - kb - (L1BC ? 1 : 0));
+        const int hot_lo = max(2, 4 - kb), hot_hi = min(nsteps, nz - kb);       // bulk: s ≥ 2 and plane k2 = kb−2+s in [2, nz−3]
         const int h0 = min(nsteps, (hot_lo + 1) & ~1);                          // an even number of edge steps first (parity)
         for (; s + 2 <= h0; s += 2) {
             step(s, std::true_type{});
@@ -2135,7 +2115,7 @@ hipError_t pt_faces_region(hipStream_t s, T *Pout, const ns3d_pt_params &p, cons
     a.outlet_val = (T)p.outlet_val; a.rho_g = (T)p.rho * (T)p.g;
     a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
     a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = p.z_lo_is_halo; a.zhi_halo = p.z_hi_is_halo;
-    a.k0 = 1; a.k1 = p.nz - 1; a.kz = 1; a.l1_bc = 0; a.no_faces = 0; a.cus_off = 0; a.win = nullptr; a.tx0 = a.ty0 = 0;
+    a.k0 = 1; a.k1 = p.nz - 1; a.kz = 1; a.no_faces = 0; a.cus_off = 0; a.win = nullptr; a.tx0 = a.ty0 = 0;
     if (p.nx < 3 || p.ny < 3 || p.nz < 3) return hipErrorInvalidValue;
     const long cells = 2l * p.nx * (p.nz - 2) + 2l * p.nx * p.ny;
     hipLaunchKernelGGL(k_pt_faces_region<T>, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, a, c0[0], c0[1], c0[2], c1[0], c1[1], c1[2],
@@ -2189,7 +2169,6 @@ static int workgroups_per_cu(const void *kernel, int threads)
 template <class T, int WX, int WY, int CPT, bool NT, int MINW = 1, bool SEPF = false>
 static hipError_t launch_sweep2(hipStream_t s, SweepArgs<T> &a, int kz)
 {
-    auto kern = a.l1_bc ? k_pt_sweep2<T, WX, WY, CPT, NT, MINW, SEPF, true> : k_pt_sweep2<T, WX, WY, CPT, NT, MINW, SEPF, false>;
     constexpr int TX = 64 * WX, TY = CPT * WY;
     const int nk = a.k1 - a.k0;
     int ntx = max(1, (a.nx - 4 + (TX - 2) - 1) / (TX - 2)), nty = max(1, (a.ny - 4 + (TY - 2) - 1) / (TY - 2));
@@ -2214,7 +2193,7 @@ static hipError_t launch_sweep2(hipStream_t s, SweepArgs<T> &a, int kz)
     }
     a.kz = kz;
     const int ntz = (nk + kz - 1) / kz;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(ntx * nty * ntz)), dim3(TX, WY, 1), 0, s, a, ntx, nty);
+    hipLaunchKernelGGL((k_pt_sweep2<T, WX, WY, CPT, NT, MINW, SEPF>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX, WY, 1), 0, s, a, ntx, nty);
     hipError_t e = hipGetLastError();
     if (SEPF && e == hipSuccess && !a.no_faces) e = launch_faces<T>(s, a);
     return e;
@@ -2591,7 +2570,6 @@ static hipError_t launch_sweepN(hipStream_t s, SweepArgs<T> &a, int kz)
     if constexpr (!(TX > OV + 2 && TY > OV + 2 && lds <= 160ul * 1024)) {
         return hipErrorInvalidValue;            // tile too small for this many levels, or its planes exceed the 160 KB of LDS
     } else {
-    if (a.l1_bc) return hipErrorInvalidValue;      // NS3D_PASS_INPUT_OBEYS_BC: the two-iteration sweep only
     const int nk = a.k1 - a.k0;
     int ntx = max(1, (a.nx - 2 - OV + (TX - OV) - 1) / (TX - OV)), nty = max(1, (a.ny - 2 - OV + (TY - OV) - 1) / (TY - OV));
     if (!apply_tile_window<T>(a, TX, TY, OV, ntx, nty)) return hipSuccess;
@@ -3002,8 +2980,7 @@ static hipError_t launch_sweepD(hipStream_t s, SweepArgs<T> &a, int kz)
         return hipErrorInvalidValue;
     } else {
         const int nk = a.k1 - a.k0;
-        if (a.l1_bc) return hipErrorInvalidValue;      // NS3D_PASS_INPUT_OBEYS_BC: the two-iteration sweep only
-        if (a.nx < 4 || a.ny < 4 || (size_t)a.nx * a.ny * sizeof(T) >= (1ull << 32)) return hipErrorInvalidValue;   // 32-bit in-plane byte offsets
+            if (a.nx < 4 || a.ny < 4 || (size_t)a.nx * a.ny * sizeof(T) >= (1ull << 32)) return hipErrorInvalidValue;   // 32-bit in-plane byte offsets
         int ntx = max(1, (a.nx - 2 - OV + (TX - OV) - 1) / (TX - OV)), nty = max(1, (a.ny - 2 - OV + (TY - OV) - 1) / (TY - OV));
         if (!apply_tile_window<T>(a, TX, TY, OV, ntx, nty)) return hipSuccess;
         if (kz <= 0 || kz > 90) {
@@ -3052,7 +3029,7 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
     a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
     a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = 0; a.zhi_halo = 0;
     a.k0 = k0; a.k1 = k1; a.kz = 1;
-    a.l1_bc = (pass_flags & NS3D_PASS_INPUT_OBEYS_BC) ? 1 : 0; a.no_faces = (pass_flags & NS3D_PASS_SKIP_FACES) ? 1 : 0;
+    a.no_faces = (pass_flags & NS3D_PASS_SKIP_FACES) ? 1 : 0;
     a.cus_off = ((pass_flags >> 8) & 0xff) * 8;
     if (k1 <= k0) return hipSuccess;
     int shape = variant / 100, kz = variant % 100;
@@ -3075,22 +3052,18 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
     case 12: NS3D_SWN(NLV, 2, 4, 4, true);                                                                  \
     default: return hipErrorInvalidValue;                                                                   \
     }
-    // shapes 31…39: k_pt_sweepD — P⁰ through an LDS-DMA ring.  31: 64×24 columns / 768 threads, two rows per thread, three slots,
-    // four written-out steps per trip; 37: the same with the one general step form; 35: four slots (the DMA one more step ahead);
-    // 32 / 36: 64×32 / 1024 threads (four waves per SIMD), general step form / two written-out steps; 33: 64×33 / 704 threads and
-    // 34: 64×30 / 640 threads with three rows per thread; 38 / 39: 36 / 35 with the centre values of levels ≥ 2 from LDS
-    if (shape >= 31 && shape <= 39) {
+    // shapes 31…38: k_pt_sweepD — P⁰ through an LDS-DMA ring.  38: 64×32 columns / 1024 threads (four waves per SIMD), two rows per thread,
+    // three slots, two written-out steps per trip, centre values of levels ≥ 2 from LDS — the planner's candidate (3800); kept beside it as
+    // the A/B evidence of profiles/r4_levelskip_dma_ab.log: 31: the 64×24 / 768-thread shape of k_pt_sweepN's 28xx with DMA staging, 35: the same
+    // with a four-slot ring (the DMA one more step ahead), 32: 38 with the one general step form and the centres in registers
+    if (shape >= 31 && shape <= 38) {
 #define NS3D_SWD(NLV)                                                                                        \
         switch (shape) {                                                                                     \
         case 31: return launch_sweepD<T, NLV, 12, 2, 3, 4, 0>(s, a, kz);                                     \
         case 32: return launch_sweepD<T, NLV, 16, 2, 3, 1, 0>(s, a, kz);                                     \
-        case 33: return launch_sweepD<T, NLV, 11, 3, 3, 1, 0>(s, a, kz);                                     \
-        case 34: return launch_sweepD<T, NLV, 10, 3, 3, 1, 0>(s, a, kz);                                     \
         case 35: return launch_sweepD<T, NLV, 12, 2, 4, 4, 0>(s, a, kz);                                     \
-        case 36: return launch_sweepD<T, NLV, 16, 2, 3, 2, 0>(s, a, kz);                                     \
         case 38: return launch_sweepD<T, NLV, 16, 2, 3, 2, 1>(s, a, kz);                                     \
-        case 39: return launch_sweepD<T, NLV, 12, 2, 4, 4, 1>(s, a, kz);                                     \
-        default: return launch_sweepD<T, NLV, 12, 2, 3, 1, 0>(s, a, kz);                                     \
+        default: return hipErrorInvalidValue;                                                                \
         }
         if (nlev == 2) { NS3D_SWD(2) } else if (nlev == 3) { NS3D_SWD(3) } else if (nlev == 4) { NS3D_SWD(4) }
         return hipErrorInvalidValue;
@@ -3127,7 +3100,7 @@ hipError_t pt_sweep2(hipStream_t s, int variant, const T *Pin, T *Pout, const T 
     a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
     a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = 0; a.zhi_halo = 0;
     a.k0 = k0; a.k1 = k1; a.kz = 1;
-    a.l1_bc = (pass_flags & NS3D_PASS_INPUT_OBEYS_BC) ? 1 : 0; a.no_faces = (pass_flags & NS3D_PASS_SKIP_FACES) ? 1 : 0;
+    a.no_faces = (pass_flags & NS3D_PASS_SKIP_FACES) ? 1 : 0;
     a.cus_off = ((pass_flags >> 8) & 0xff) * 8;
     if (k1 <= k0) return hipSuccess;
     int shape = variant / 100;
@@ -3413,7 +3386,7 @@ hipError_t pt_persist(hipStream_t s, const T *Pin, T *Pout, const T *Din, T *Dou
     a.outlet_val = (T)p.outlet_val; a.rho_g = (T)p.rho * (T)p.g;
     a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
     a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = 0; a.zhi_halo = 0;
-    a.k0 = 1; a.k1 = p.nz - 1; a.kz = 1; a.l1_bc = 0; a.no_faces = 0; a.cus_off = 0; a.win = nullptr; a.tx0 = a.ty0 = 0;
+    a.k0 = 1; a.k1 = p.nz - 1; a.kz = 1; a.no_faces = 0; a.cus_off = 0; a.win = nullptr; a.tx0 = a.ty0 = 0;
     // the iteration is arithmetic on the CUs the grid occupies plus one hand-over: the smallest workgroup the chip still holds
     // all at once spreads the cells over the most CUs.  NS3D_PERSIST_SHAPE=22|42|44 pins a shape (A/B).
     static const int pin = std::getenv("NS3D_PERSIST_SHAPE") ? std::atoi(std::getenv("NS3D_PERSIST_SHAPE")) : 0;
@@ -3437,7 +3410,7 @@ hipError_t pt_sweep(hipStream_t s, int variant, const T *Pin, T *Pout, T *D, con
     a.outlet_val = (T)p.outlet_val; a.rho_g = (T)p.rho * (T)p.g;
     a.nx = p.nx; a.ny = p.ny; a.nz = p.nz;
     a.bc_kind = p.bc_kind; a.owns_outlet = p.owns_outlet; a.zlo_halo = p.z_lo_is_halo; a.zhi_halo = p.z_hi_is_halo;
-    a.k0 = k0; a.k1 = k1; a.kz = 1; a.l1_bc = 0; a.no_faces = 0; a.cus_off = 0; a.win = nullptr; a.tx0 = a.ty0 = 0;
+    a.k0 = k0; a.k1 = k1; a.kz = 1; a.no_faces = 0; a.cus_off = 0; a.win = nullptr; a.tx0 = a.ty0 = 0;
     if (k1 <= k0) return hipSuccess;
     // variant = family*100 + kz  (kz = planes marched per block; 0 → default); variant 0 = choose by grid size:
     // grids whose four PT arrays stay resident in L2 / Infinity Cache run best with one thread per cell (neighbours are

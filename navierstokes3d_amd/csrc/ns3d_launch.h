@@ -9,6 +9,9 @@
 // A sweep over a sub-rectangle of a plane's tiles (ns3d_mgpu.cpp box_pass: the shells next to decomposed faces first, the core while
 // the exchange runs).  Tiles [x0,x1) × [y0,y1) of the tile grid the launch would otherwise cover; x1 <= x0 means the whole grid.
 // geom != nullptr: nothing is launched — the launcher reports the tile grid this depth / variant / grid would use.
+// pass_flags of pt_sweep2 / pt_sweepn: bit 1 — no boundary-cell launch behind the sweep; bits 8… — compute units (in eights) the stream's
+// CU mask leaves out (ns3d_reserve_cus), which the z-chunking must not count on
+#define NS3D_PASS_SKIP_FACES 2
 struct ns3d_tile_geom { int TX, TY, OV, ntx, nty; };      // columns × rows per tile, overlap 2(NL−1), tiles per plane
 struct ns3d_tile_window { int x0, x1, y0, y1; ns3d_tile_geom *geom; };
 struct ns3d_persist_state {

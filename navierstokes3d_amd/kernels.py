@@ -154,15 +154,6 @@ class Context:
         """Tile shape of the N-iteration sweep (pt_sweepn): shape*100 + kz, 0 = built-in."""
         L.check(self.lib.ns3d_set_ptn_variant(self.handle, int(v)))
 
-    def set_pt_pass_flags(self, flags):
-        """NS3D_PASS_* for this context's own pt_sweep2 / pt_sweepn calls (lib.NS3D_PASS_INPUT_OBEYS_BC | lib.NS3D_PASS_SKIP_FACES):
-        between two multi-iteration passes the boundary cells of the iterate need neither be written nor read."""
-        L.check(self.lib.ns3d_set_pt_pass_flags(self.handle, int(flags)))
-
-    def set_pass_chain(self, on):
-        """pt_iterate / pt_solve chain the passes of a residual-check block with those flags by themselves (default on)."""
-        L.check(self.lib.ns3d_set_pass_chain(self.handle, int(bool(on))))
-
     def set_pt_depth(self, depth):
         """PT iterations per pass over memory in pt_iterate / pt_solve: 0 automatic, 1…4 forced (5: float32 fields only)."""
         L.check(self.lib.ns3d_set_pt_depth(self.handle, int(depth)))

@@ -11,7 +11,6 @@ NS3D_ERR_ARG, NS3D_ERR_HIP, NS3D_ERR_STATE, NS3D_ERR_RCCL = 1, 2, 3, 4
 NS3D_UNIQUE_ID_BYTES = 128
 NS3D_STRICT, NS3D_FAST, NS3D_ASYNC, NS3D_IEEE_DIV = 0x0, 0x1, 0x2, 0x4
 NS3D_BC_MULTI, NS3D_BC_GPU = 0, 1
-NS3D_PASS_INPUT_OBEYS_BC, NS3D_PASS_SKIP_FACES = 1, 2     # include/ns3d.h: boundary cells between multi-iteration passes
 
 
 class Ns3dError(RuntimeError):
@@ -86,7 +85,7 @@ SIGNATURES = {
 }
 CONTEXT_SYMBOLS = ["ns3d_version", "ns3d_last_error", "ns3d_create", "ns3d_destroy", "ns3d_flags",
                    "ns3d_set_stream", "ns3d_use_own_stream", "ns3d_get_stream", "ns3d_sync", "ns3d_reserve_cus", "ns3d_reserved_cus", "ns3d_set_pt_variant",
-                   "ns3d_set_pt2_variant", "ns3d_set_ptn_variant", "ns3d_set_pt_depth", "ns3d_set_pt_pass_flags", "ns3d_set_pass_chain", "ns3d_set_graph_mode", "ns3d_set_autotune", "ns3d_last_pt2_variant", "ns3d_last_ptn_variant", "ns3d_last_pt_depth",
+                   "ns3d_set_pt2_variant", "ns3d_set_ptn_variant", "ns3d_set_pt_depth", "ns3d_set_graph_mode", "ns3d_set_autotune", "ns3d_last_pt2_variant", "ns3d_last_ptn_variant", "ns3d_last_pt_depth",
                    "ns3d_arith_build", "ns3d_cached_graphs", "ns3d_set_persist_mode", "ns3d_persist_faults"]
 
 
@@ -171,8 +170,6 @@ def load():
     lib.ns3d_set_pt2_variant.argtypes = [_P, _I]
     lib.ns3d_set_ptn_variant.argtypes = [_P, _I]
     lib.ns3d_set_pt_depth.argtypes = [_P, _I]
-    lib.ns3d_set_pt_pass_flags.argtypes = [_P, _I]
-    lib.ns3d_set_pass_chain.argtypes = [_P, _I]
     lib.ns3d_set_graph_mode.argtypes = [_P, _I]
     lib.ns3d_set_autotune.argtypes = [_P, _I]
     lib.ns3d_last_pt2_variant.argtypes = [_P]

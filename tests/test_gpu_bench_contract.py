@@ -12,8 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("extra", [[], ["--mode", "fast", "--dtype", "f32", "--no-cpu-baseline", "--no-traffic"],
-                                   ["--steps", "5", "--no-cpu-baseline", "--no-traffic"],
-                                   ["--pass-chain", "--no-cpu-baseline", "--no-traffic"]])
+                                   ["--steps", "5", "--no-cpu-baseline", "--no-traffic"]])
 def test_bench_prints_one_json_line(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--grid", "96", "--steps", "6", "--warmup", "2", "--cpu-iters", "2"] + extra
     out = subprocess.run(cmd, cwd=ROOT, check=True, capture_output=True, text=True, timeout=600).stdout
@@ -27,10 +26,7 @@ def test_bench_prints_one_json_line(extra):
     assert d["value"] > 0 and d["ms_per_step"] > 0 and d["config"]["finite"] is True and "workload" in d["config"]
     # every line certifies itself: one pass of the timed kernel instance against single sweeps, on the device
     v = d["config"]["verify"]
-    # (--pass-chain: TWO chained two-iteration passes, the first without its boundary cells, the second forming them)
-    chained = bool(v.get("chained_passes"))
-    assert chained == ("--pass-chain" in extra and d["config"]["pt_depth"] == 2)
-    assert d["config"]["verified"] is True and v["iterations"] == d["config"]["pt_depth"] * (2 if chained else 1) and v["rel_l2"] <= 1e-6
+    assert d["config"]["verified"] is True and v["iterations"] == d["config"]["pt_depth"] and v["rel_l2"] <= 1e-6
     assert v["bitwise"] is True or "fast" in extra
     assert d["config"]["arith_build"] == ("fast" if "fast" in extra else "strictx")          # dx = 1/96: not a power of two
     assert d["strong"]["value"] == d["value"] and d["strong"]["global_grid"] == d["config"]["global_grid"]
