@@ -234,6 +234,24 @@ hipError_t predict_V(hipStream_t s, T *Vx, T *Vy, T *Vz, const T *txx, const T *
     return hipGetLastError();
 }
 
+// Planes per workgroup for the z-marching window kernels (k_predict_fused, k_advect_win2: one workgroup per CU at a time, three
+// planes of lead-in per chunk).  Large grids keep the fixed chunk; where that leaves fewer than four rounds of workgroups (255×153×153:
+// 40 columns × 3 chunks on 256 CUs) the chunk count is the one with the least rounds × (planes + lead-in).
+static int device_cus();
+static int window_kz(int ncols, int nz, int dflt)
+{
+    const long cus = device_cus();
+    if ((long)ncols * ((nz + dflt - 1) / dflt) >= 4 * cus) return dflt;
+    long best = -1;
+    int best_kz = dflt;
+    for (int c = 1; c <= max(1, nz / 4); ++c) {
+        const int kz = (nz + c - 1) / c;
+        const long chunks = (nz + kz - 1) / kz, rounds = ((long)ncols * chunks + cus - 1) / cus, cost = rounds * (kz + 3);
+        if (best < 0 || cost < best) { best = cost; best_kz = kz; }
+    }
+    return best_kz;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // update_τ! + predict_V! in one pass (round 3): k_predict_fused.  The six stress arrays are temporaries of the
 // predictor (multi.jl:449-451: written by update_τ!, read by predict_V!, nothing else), 72 + 96 B per cell in two kernels
@@ -394,7 +412,8 @@ hipError_t predict_fused(hipStream_t s, T *Vxn, T *Vyn, T *Vzn, const T *Vx, con
     hipError_t ea = hipFuncSetAttribute((const void *)k_predict_fused<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (ea != hipSuccess) return ea;
     const T dt_rho = (T)dt / (T)rho, rho_g = (T)rho * (T)gg;
-    const int kz = nz >= 128 ? 64 : 32;
+    static const int kz_env = std::getenv("NS3D_PREDICT_KZ") ? std::atoi(std::getenv("NS3D_PREDICT_KZ")) : 0;   // A/B
+    const int kz = kz_env > 0 ? kz_env : window_kz(((nx + W::TX - 1) / W::TX) * ((ny + W::TY - 1) / W::TY), nz, nz >= 128 ? 64 : 32);
     const dim3 blk(W::TX, W::TY, 1);
     const dim3 grd((unsigned)((nx + W::TX - 1) / W::TX), (unsigned)((ny + W::TY - 1) / W::TY), (unsigned)((nz + kz - 1) / kz));
     hipLaunchKernelGGL(k_predict_fused<T>, grd, blk, lds, s, Vxn, Vyn, Vzn, Vx, Vy, Vz, (T)mu, dt_rho, rho_g, make_geo<T>(dx, dy, dz), nx,
@@ -1239,7 +1258,8 @@ hipError_t advect(hipStream_t s, T *Vx, const T *Vx_o, T *Vy, const T *Vy_o, T *
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (ea != hipSuccess) return ea;
     static const int kz_env = std::getenv("NS3D_ADVECT_KZ") ? std::atoi(std::getenv("NS3D_ADVECT_KZ")) : 0;
-    const int kz = kz_env > 0 ? kz_env : (nz >= 128 ? 64 : 32);    // planes per workgroup (three of them are the window's lead-in)
+    // planes per workgroup (three more are the window's lead-in)
+    const int kz = kz_env > 0 ? kz_env : window_kz(((nx + W::TX - 1) / W::TX) * ((ny + W::TY - 1) / W::TY), nz, nz >= 128 ? 64 : 32);
     const dim3 blk(W::TX, W::TY, 1);
     const dim3 grd((unsigned)((nx + W::TX - 1) / W::TX), (unsigned)((ny + W::TY - 1) / W::TY), (unsigned)((nz + kz - 1) / kz));
     if (faithful & 1)
