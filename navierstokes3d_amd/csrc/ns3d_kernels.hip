@@ -71,7 +71,10 @@ static Geo<T> make_geo(double dx, double dy, double dz)
 //        q = RN(x·r);   e = x − q·d  (exact, one FMA);   q' = RN(q + e·r)  =  RN(x/d)
 // valid while no intermediate over/underflows, i.e. for 2^-900 < |q| < 2^900 with 2^-100 < d < 2^100 (checked on the
 // host, which also refuses divisors whose significand is all ones); everything else — zeros (sign preserved), huge,
-// tiny, Inf, NaN — takes the plain division.  `ns3d_selftest_exact_div` compares the two on the GPU bit for bit.
+// tiny, Inf, NaN — takes the plain division, behind two branches so that a wave whose only outliers are ZEROS (fields at rest:
+// the cylinder case starts with Vy = Vz = 0 and a uniform Vx) does not run it: the predictor of the 255×153×153 case was three
+// times slower per plane than the power-of-two build before (round 4).  `ns3d_selftest_exact_div` compares the two on the
+// GPU bit for bit.
 template <class T> struct DivLim;
 template <> struct DivLim<double> { static constexpr double lo = 0x1p-900, hi = 0x1p900; };
 template <> struct DivLim<float> { static constexpr float lo = 0x1p-100f, hi = 0x1p100f; };
@@ -82,7 +85,10 @@ __device__ __forceinline__ T div_by_known(T x, T d, T r)
     const T e = __builtin_fma(-q, d, x);
     T q1 = __builtin_fma(e, r, q);
     const T aq = __builtin_fabs(q);
-    if (!(aq > DivLim<T>::lo && aq < DivLim<T>::hi)) q1 = (x == (T)0) ? x : x / d;
+    if (__builtin_expect(!(aq > DivLim<T>::lo && aq < DivLim<T>::hi), 0)) {
+        q1 = x;                                 // ±0 / d = ±0: a wave whose only outliers are zeros skips the division
+        if (x != (T)0) q1 = x / d;
+    }
     return q1;
 }
 __device__ __forceinline__ float div_by_known(float x, float d, float r)
@@ -91,7 +97,10 @@ __device__ __forceinline__ float div_by_known(float x, float d, float r)
     const float e = __builtin_fmaf(-q, d, x);
     float q1 = __builtin_fmaf(e, r, q);
     const float aq = __builtin_fabsf(q);
-    if (!(aq > DivLim<float>::lo && aq < DivLim<float>::hi)) q1 = (x == 0.0f) ? x : x / d;
+    if (__builtin_expect(!(aq > DivLim<float>::lo && aq < DivLim<float>::hi), 0)) {
+        q1 = x;
+        if (x != 0.0f) q1 = x / d;
+    }
     return q1;
 }
 
