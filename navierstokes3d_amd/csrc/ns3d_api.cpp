@@ -868,6 +868,35 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
     // settle the tile choice of the two-iteration sweep now (eagerly, into the scratch buffers): inside a stream capture
     // it could only be looked up
     if (two) (void)pick_plan<T>(c, s, mode_of(c, p->dx, p->dy, p->dz), src, dst, dsrc, ddst, divV, p, 1, p->nz - 1, true);
+    // Small grids (round 4): the WHOLE loop — iterations, residual checks, the decision of :467-469 — as one launch of k_pt_persist.  The
+    // checks' maxima come back through pinned host memory behind one synchronisation; a launch whose bounded waits expired left its
+    // inputs intact and the loop below redoes the solve by launches.  NS3D_PERSIST_SOLVE=0: a launch per residual-check block (A/B).
+    const char *wv = std::getenv("NS3D_PERSIST_SOLVE");         // read per solve: tests flip it
+    const bool whole = !(wv && *wv == '0');
+    if (whole && nchk > 0 && niter >= nchk && niter / nchk <= NS3D_PERSIST_MAXCHK && use_persist<T>(c, p)) {
+        T *dout = ddst;
+        if (!dout && (rc = ensure_pingpong_d<T>(c, p, &dout))) return rc;
+        hipError_t e = DISPATCHG(c, p->dx, p->dy, p->dz,
+                                 pt_persist<T>(s, src, dst, dsrc, dout, divV, *p, niter, &c->persist, nchk, eps, err_mul, err_div));
+        if (e == hipSuccess) {
+            HIPCHK(c, hipStreamSynchronize(s));
+            if (!persist_failed(c)) {
+                const unsigned long long *res = c->persist.res_host;
+                done = (int)res[0];
+                checks = (int)res[1];
+                for (int q = 0; q < checks && q < max_checks && err_hist; ++q) {
+                    double mx;
+                    std::memcpy(&mx, &res[2 + q], sizeof mx);
+                    err_hist[q] = mx * err_mul / err_div;
+                }
+                src = dst; dsrc = dout;
+                iter = niter;                   // nothing left for the loop below
+            }
+        } else if (e != hipErrorInvalidValue)
+            return fail(NS3D_ERR_HIP, "pt_persist launch: %s", hipGetErrorString(e));
+        else
+            (void)hipGetLastError();
+    }
     while (iter < niter) {
         // iterations until the next residual check (multi.jl:464) or the end of the budget
         const int n = nchk > 0 ? std::min(nchk - iter % nchk, niter - iter) : niter - iter;

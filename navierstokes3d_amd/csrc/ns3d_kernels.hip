@@ -3189,6 +3189,15 @@ hipError_t pt_sweep2(hipStream_t s, int variant, const T *Pin, T *Pout, const T 
 // not the 0.5 µs of one hop.  So the automatic choice is narrow (ns3d_api.cpp use_persist) and the gain is 14–22 %; the direct
 // solve (ns3d_direct.hip) is the answer where the iteration count itself is the cost.  Smaller workgroups (64×2×2, 64×4×2) are
 // tried first — they spread the cells over more CUs; runs of blocks per XCD instead of round-robin were slower.
+//
+// Round 4, the whole loop of multi.jl:458-471 in one launch (nchk > 0; ns3d_pt_solve where the form applies): compute_res! after
+// iteration n is the right-hand side iteration n+1 starts from, so a residual check costs a reduction and no stencil.  Every nchk
+// iterations each workgroup leaves max|Rp| of its cells in a pair of its own, workgroup 0 collects the pairs (one per thread),
+// leaves the grid's maximum in a result pair, and one thread per workgroup takes the reference's decision (err < ε or not finite)
+// from it — all workgroups read the same word, so all stop at the same iteration; the maxima and the iteration count go straight
+// to pinned host memory.  No host round trip per check: 63×38×38 in blocks of 37, 3.55 → 2.91 µs per iteration; a time step of
+// config A 2.39 → 1.98 ms (profiles/r4_persist_solve_ab.log).  A first version with one atomicMax + one arrival counter per check
+// was SLOWER than the launches (2.57 ms): 324 read-modify-writes on one address.
 // =========================================================================================================
 template <class T>
 struct PersistArgs {
@@ -3199,6 +3208,16 @@ struct PersistArgs {
     unsigned ticket;            // this launch's number: what an expired wait leaves in the error words
     int nbx, nby, nbz, n_iters, xcds;
     int fault;                  // test hook (NS3D_PERSIST_FAULT=1): workgroup 0 never publishes and the waits give up early
+    // the whole-solve form (nchk > 0): every nchk iterations max|Rp| over the grid is formed INSIDE the launch and every workgroup
+    // takes the reference's decision (multi.jl:466-469) from the same word — see k_pt_persist.  What only the checks need (ε, the
+    // scaling of the error, where the host reads the maxima) sits in device memory behind `red`, read by one thread per check: as
+    // kernel arguments they would be live in scalar registers across the iteration loop, which is at the 106-SGPR limit already.
+    int nchk;
+    unsigned long long *red;    // [2b], [2b+1]: workgroup b's maximum as a value/key pair; [2·MAXWG…]: the grid's; [2·MAXCHK…]: PersistCheck
+};
+struct PersistCheck {
+    double eps, err_mul, err_div;
+    unsigned long long *res;    // pinned host memory: [0] iterations done, [1] checks made, [2+q] key of check q
 };
 __device__ __forceinline__ unsigned long long xkey(unsigned long long id) { return (id + 1ull) * 0x9E3779B97F4A7C15ull; }
 __device__ __forceinline__ unsigned long long xbits(double v) { return (unsigned long long)__double_as_longlong(v); }
@@ -3211,7 +3230,7 @@ template <class T> __device__ __forceinline__ void xpublish(unsigned long long *
     __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(p + 1, w ^ key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-template <class T, class PA> __device__ __forceinline__ T xfetch(const unsigned long long *p, unsigned long long key, const PA &pa)
+template <class PA> __device__ __forceinline__ unsigned long long xfetch_raw(const unsigned long long *p, unsigned long long key, const PA &pa)
 {
     unsigned long long w1 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long w2 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3227,9 +3246,18 @@ template <class T, class PA> __device__ __forceinline__ T xfetch(const unsigned 
             break;
         }
     }
+    return w1;
+}
+template <class T, class PA> __device__ __forceinline__ T xfetch(const unsigned long long *p, unsigned long long key, const PA &pa)
+{
     T v;
-    xunbits(w1, v);
+    xunbits(xfetch_raw(p, key, pa), v);
     return v;
+}
+__device__ __forceinline__ void xpublish_raw(unsigned long long *p, unsigned long long w, unsigned long long key)
+{
+    __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 1, w ^ key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <class T, int BY, int BZ>
@@ -3279,8 +3307,15 @@ __global__ __launch_bounds__(64 * BY * BZ) void k_pt_persist(PersistArgs<T> pa)
     const T f_s = ylo_adj ? a.Pin[pc - sy] : (T)0, f_n = yhi_adj ? a.Pin[pc + sy] : (T)0;
     const T f_b = zlo_adj ? a.Pin[pc - sz] : (T)0, f_t = zhi_adj ? a.Pin[pc + sz] : (T)0;
     __syncthreads();
-    int cur = 0;
-    for (int it = 0; it < pa.n_iters; ++it) {
+    int cur = 0, it = 0, nchecks = 0;
+    const int tid = (lz * BY + ly) * BX + lx;
+    __shared__ unsigned long long red_w[BY * BZ];
+    __shared__ int red_flag;
+    int next_check = pa.nchk > 0 ? pa.nchk : -1;
+    for (;; ++it) {
+        // compute_res! after iteration `it` is the right-hand side the NEXT iteration starts from: the check costs a reduction, no stencil
+        const bool check = it == next_check;
+        if (it == pa.n_iters && !check) break;
         const T *__restrict__ l = Lp[cur];
         T w = l[ctr - 1], e = l[ctr + 1], sv = l[ctr - PX], nv = l[ctr + PX], bv = l[ctr - PX * PY], tv = l[ctr + PX * PY];
         const bool first = it == 0;
@@ -3291,11 +3326,65 @@ __global__ __launch_bounds__(64 * BY * BZ) void k_pt_persist(PersistArgs<T> pa)
         if (zlo_adj) bv = first ? f_b : c;
         if (zhi_adj) tv = first ? f_t : c;
         const T res = poisson_rhs<T>(c, w, e, sv, nv, bv, tv, rv, a.rho_dt, g);
+        if (check) {
+            // maximum(abs.(Rp)) (multi.jl:466, NaN-propagating key as k_residual_max) over the grid, with the hand-over's own
+            // mechanism (value/key word pairs, no read-modify-write: 324 same-address atomics per check cost ≈40 µs): every workgroup
+            // leaves its maximum in its own pair, workgroup 0 collects them — a pair per thread — and leaves the grid's maximum in the
+            // result pair, which one thread per workgroup waits for (bounded) and takes the decision of :467-469 from
+            next_check += pa.nchk;
+            const unsigned long long ckey = xkey(pa.epoch + (unsigned long long)it) ^ 0x5DEECE66Dull;
+            unsigned long long key = act ? abs_key((double)res) : 0ull;
+            key = wave_max_u64(key);
+            if ((tid & 63) == 0) red_w[tid >> 6] = key;
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long v = 0ull;
+#pragma unroll
+                for (int q = 0; q < BY * BZ; ++q) v = red_w[q] > v ? red_w[q] : v;
+                xpublish_raw(pa.red + 2 * (size_t)b, v, ckey);
+            }
+            unsigned long long *const result = pa.red + 2 * (size_t)NS3D_PERSIST_MAXWG;
+            if (b == 0) {
+                unsigned long long v = 0ull;
+                for (int j = tid; j < (int)gridDim.x; j += BX * BY * BZ) {
+                    const unsigned long long u = xfetch_raw(pa.red + 2 * (size_t)j, ckey, pa);
+                    v = u > v ? u : v;
+                }
+                v = wave_max_u64(v);
+                __syncthreads();                 // red_w has been read by thread 0
+                if ((tid & 63) == 0) red_w[tid >> 6] = v;
+                __syncthreads();
+                if (tid == 0) {
+                    v = 0ull;
+#pragma unroll
+                    for (int q = 0; q < BY * BZ; ++q) v = red_w[q] > v ? red_w[q] : v;
+                    xpublish_raw(result, v, ckey);
+                }
+            }
+            if (tid == 0) {
+                unsigned long long kall = xfetch_raw(result, ckey, pa);
+                // a wait that expired anywhere (the launch is void, the host redoes it): leave now instead of waiting out every
+                // remaining hand-over
+                const bool expired = __hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pa.ticket;
+                if (expired) kall = 0x7FF8000000000000ull;
+                const volatile PersistCheck *pc_ = (const volatile PersistCheck *)(pa.red + 2 * NS3D_PERSIST_MAXCHK);
+                const double eps = pc_->eps, err = __longlong_as_double((long long)kall) * pc_->err_mul / pc_->err_div;     // multi.jl:466
+                if (b == 0 && nchecks < NS3D_PERSIST_MAXCHK)
+                    __hip_atomic_store(pc_->res + 2 + nchecks, kall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                red_flag = expired ? 2 : (eps >= 0.0 && (err < eps || !__builtin_isfinite(err))) ? 1 : 0;                  // :467-469
+            }
+            __syncthreads();
+            const int flag = red_flag;
+            if (flag == 2) break;
+            ++nchecks;
+            if (flag == 1 || it == pa.n_iters) break;
+        }
         d = d * a.one_m_damp + a.dtau * res;
         c = c + a.dtau * d;
         T *__restrict__ ln = Lp[cur ^ 1];
         ln[ctr] = c;
-        const bool last = it + 1 == pa.n_iters;
+        // the faces are handed over unless nothing follows: neither an iteration nor a check
+        const bool last = it + 1 == pa.n_iters && it + 1 != next_check;
         if (!last) {
             const unsigned long long key = xkey(pa.epoch + (unsigned long long)it);
             unsigned long long *__restrict__ hp = Hme + 2 * (size_t)((it & (R - 1)) * FACE);
@@ -3328,6 +3417,11 @@ __global__ __launch_bounds__(64 * BY * BZ) void k_pt_persist(PersistArgs<T> pa)
         a.D[dc] = d;
         store_with_bc<T>(a, gi, gj, gk, c);
     }
+    if (pa.nchk > 0 && b == 0 && tid == 0) {
+        unsigned long long *res_host = ((const volatile PersistCheck *)(pa.red + 2 * NS3D_PERSIST_MAXCHK))->res;
+        __hip_atomic_store(res_host, (unsigned long long)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(res_host + 1, (unsigned long long)nchecks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // the exchange area and the error word live with the caller's context (ns3d_persist_state, freed with it); a launch on another
@@ -3337,15 +3431,19 @@ static hipError_t persist_scratch(ns3d_persist_state *st, hipStream_t s, size_t 
     hipError_t e;
     if (!st->ev) {
         if ((e = hipEventCreateWithFlags(&st->ev, hipEventDisableTiming)) != hipSuccess) return e;
-        if ((e = hipHostMalloc((void **)&st->err_host, 64, hipHostMallocMapped)) != hipSuccess) return e;
+        if ((e = hipHostMalloc((void **)&st->err_host, 64 + (2 + NS3D_PERSIST_MAXCHK + 8) * sizeof(unsigned long long), hipHostMallocMapped)) != hipSuccess) return e;
         *st->err_host = 0u;
         if ((e = hipHostGetDevicePointer((void **)&st->err_host_dev, st->err_host, 0)) != hipSuccess) return e;
+        st->res_host = (unsigned long long *)((char *)st->err_host + 64);
+        st->res_host_dev = (unsigned long long *)((char *)st->err_host_dev + 64);
     } else if ((e = hipStreamWaitEvent(s, st->ev, 0)) != hipSuccess) return e;      // the previous launch, whatever stream it ran on
     if (st->bytes < bytes) {
         if (st->H) { if ((e = hipEventSynchronize(st->ev)) != hipSuccess) return e; (void)hipFree(st->H); st->H = nullptr; st->bytes = 0; }
-        if ((e = hipMalloc(&st->H, bytes + 64)) != hipSuccess) return e;
-        if ((e = hipMemset(st->H, 0, bytes + 64)) != hipSuccess) return e;
+        const size_t red_bytes = (2 * (size_t)NS3D_PERSIST_MAXCHK + 8) * sizeof(unsigned long long);
+        if ((e = hipMalloc(&st->H, bytes + 64 + red_bytes)) != hipSuccess) return e;
+        if ((e = hipMemset(st->H, 0, bytes + 64 + red_bytes)) != hipSuccess) return e;
         st->err = (unsigned *)((char *)st->H + bytes);
+        st->red = (unsigned long long *)((char *)st->H + bytes + 64);
         st->bytes = bytes;
     }
     return hipSuccess;
@@ -3354,7 +3452,8 @@ static hipError_t persist_scratch(ns3d_persist_state *st, hipStream_t s, size_t 
 // n fused PT iterations (Pin, D) → (Pout, D) in one cooperative launch; hipErrorInvalidValue where the form does not apply
 // (z-slab halo planes, more workgroups than the chip holds at once): the caller then takes the launch-per-iteration path
 template <class T, int BY, int BZ>
-static hipError_t pt_persist_shape(hipStream_t s, const SweepArgs<T> &a, int n_iters, ns3d_persist_state *ps)
+static hipError_t pt_persist_shape(hipStream_t s, const SweepArgs<T> &a, int n_iters, ns3d_persist_state *ps, int nchk = 0,
+                                   double eps = -1.0, double err_mul = 1.0, double err_div = 1.0)
 {
     constexpr int BX = 64, R = 4, FACE = 2 * BX * BZ + 2 * BX * BY + 2 * BY * BZ;
     const int nbx = (a.nx - 2 + BX - 1) / BX, nby = (a.ny - 2 + BY - 1) / BY, nbz = (a.nz - 2 + BZ - 1) / BZ;
@@ -3377,6 +3476,17 @@ static hipError_t pt_persist_shape(hipStream_t s, const SweepArgs<T> &a, int n_i
     pa.ticket = ++ps->ticket;
     if (ps->ticket == 0u) pa.ticket = ps->ticket = 1u;       // 2³² launches later: tickets start over (0 means "never failed")
     pa.nbx = nbx; pa.nby = nby; pa.nbz = nbz; pa.n_iters = n_iters; pa.xcds = remap ? 8 : 1;
+    pa.nchk = nchk; pa.red = ps->red;
+    if (nchk > 0) {
+        const int nblk = n_iters / nchk;
+        if (nblk > NS3D_PERSIST_MAXCHK) return hipErrorInvalidValue;
+        if (blocks > NS3D_PERSIST_MAXWG) return hipErrorInvalidValue;
+        // the checks' parameters: staged in the pinned block (the previous launch that read them has been synchronised with by whoever
+        // read its results)
+        PersistCheck *stage = (PersistCheck *)(ps->res_host + 2 + NS3D_PERSIST_MAXCHK);
+        stage->eps = eps; stage->err_mul = err_mul; stage->err_div = err_div; stage->res = ps->res_host_dev;
+        if ((e = hipMemcpyAsync(ps->red + 2 * NS3D_PERSIST_MAXCHK, stage, sizeof(PersistCheck), hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+    }
     { const char *fv = std::getenv("NS3D_PERSIST_FAULT"); pa.fault = (fv && *fv == '1') ? 1 : 0; }      // read per launch: a test hook
     // An ORDINARY launch (round 4): the kernel needs its workgroups resident together, not a grid barrier — the grid is sized to fit the
     // chip (above), and a launch that nevertheless finds CUs taken ends in the bounded waits and the caller's redo, not in a wrong field.
@@ -3405,7 +3515,7 @@ static hipError_t pt_persist_shape(hipStream_t s, const SweepArgs<T> &a, int n_i
 
 template <class T>
 hipError_t pt_persist(hipStream_t s, const T *Pin, T *Pout, const T *Din, T *Dout, const T *RHS, const ns3d_pt_params &p, int n_iters,
-                      ns3d_persist_state *st)
+                      ns3d_persist_state *st, int nchk, double eps, double err_mul, double err_div)
 {
     if (n_iters < 1 || n_iters > 60000 || p.z_lo_is_halo || p.z_hi_is_halo) return hipErrorInvalidValue;
     SweepArgs<T> a;
@@ -3420,12 +3530,12 @@ hipError_t pt_persist(hipStream_t s, const T *Pin, T *Pout, const T *Din, T *Dou
     // all at once spreads the cells over the most CUs.  NS3D_PERSIST_SHAPE=22|42|44 pins a shape (A/B).
     static const int pin = std::getenv("NS3D_PERSIST_SHAPE") ? std::atoi(std::getenv("NS3D_PERSIST_SHAPE")) : 0;
     if (Pin == nullptr) st = nullptr;                    // no arrays: only say whether the form applies to this grid
-    if (pin == 22) return pt_persist_shape<T, 2, 2>(s, a, n_iters, st);
-    if (pin == 42) return pt_persist_shape<T, 4, 2>(s, a, n_iters, st);
-    if (pin == 44) return pt_persist_shape<T, 4, 4>(s, a, n_iters, st);
-    if (pt_persist_shape<T, 2, 2>(s, a, n_iters, nullptr) == hipSuccess) return pt_persist_shape<T, 2, 2>(s, a, n_iters, st);
-    if (pt_persist_shape<T, 4, 2>(s, a, n_iters, nullptr) == hipSuccess) return pt_persist_shape<T, 4, 2>(s, a, n_iters, st);
-    return pt_persist_shape<T, 4, 4>(s, a, n_iters, st);
+    if (pin == 22) return pt_persist_shape<T, 2, 2>(s, a, n_iters, st, nchk, eps, err_mul, err_div);
+    if (pin == 42) return pt_persist_shape<T, 4, 2>(s, a, n_iters, st, nchk, eps, err_mul, err_div);
+    if (pin == 44) return pt_persist_shape<T, 4, 4>(s, a, n_iters, st, nchk, eps, err_mul, err_div);
+    if (pt_persist_shape<T, 2, 2>(s, a, n_iters, nullptr) == hipSuccess) return pt_persist_shape<T, 2, 2>(s, a, n_iters, st, nchk, eps, err_mul, err_div);
+    if (pt_persist_shape<T, 4, 2>(s, a, n_iters, nullptr) == hipSuccess) return pt_persist_shape<T, 4, 2>(s, a, n_iters, st, nchk, eps, err_mul, err_div);
+    return pt_persist_shape<T, 4, 4>(s, a, n_iters, st, nchk, eps, err_mul, err_div);
 }
 
 template <class T>
@@ -3600,7 +3710,8 @@ hipError_t divtest(hipStream_t s, double d, long n, unsigned long long seed, uns
                                   const T *, double, double, double, double, int, int, int, int, int, int);  \
     template hipError_t pt_sweep<T>(hipStream_t, int, const T *, T *, T *, const T *, const ns3d_pt_params &,\
                                     int, int);                                                               \
-    template hipError_t pt_persist<T>(hipStream_t, const T *, T *, const T *, T *, const T *, const ns3d_pt_params &, int, ns3d_persist_state *); \
+    template hipError_t pt_persist<T>(hipStream_t, const T *, T *, const T *, T *, const T *, const ns3d_pt_params &, int, ns3d_persist_state *, \
+                                      int, double, double, double);                                             \
     template hipError_t pt_sweep2<T>(hipStream_t, int, const T *, T *, const T *, T *, const T *,            \
                                      const ns3d_pt_params &, int, int, int, const ns3d_tile_window *);       \
     template hipError_t pt_sweepn<T>(hipStream_t, int, int, const T *, T *, const T *, T *, const T *,       \

@@ -26,7 +26,13 @@ struct ns3d_persist_state {
     unsigned faults = 0;                // launches found failed (and redone by the launch-per-iteration path) so far
     hipEvent_t ev = nullptr;            // recorded behind every launch: a launch on ANOTHER stream waits for it (two grids must
                                         // not meet in the same slots) — no stream handle is kept
+    // the whole-solve form (residual checks inside the launch): a value/key pair per workgroup on the device, and what the host reads
+    // after synchronising — [0] iterations done, [1] checks made, [2+q] the key of max|Rp| at check q — in pinned host memory
+    unsigned long long *red = nullptr;
+    unsigned long long *res_host = nullptr, *res_host_dev = nullptr;
 };
+#define NS3D_PERSIST_MAXCHK 2048
+#define NS3D_PERSIST_MAXWG 1024        /* < MAXCHK: the workgroups' pairs, the result pair and the parameters share one block */
 
 // k_subbox_copy: one cx·cy·cz block between two column-major arrays (pitches in elements), and a batch of them for one launch
 #define NS3D_SUBBOX_MAX 8
@@ -91,7 +97,8 @@ struct ns3d_subbox_batch {
                              double g, double dt, double dx, double dy, double dz, int, int, int);           \
     template <class T>                                                                                       \
     hipError_t pt_persist(hipStream_t, const T *, T *, const T *, T *, const T *, const ns3d_pt_params &,    \
-                          int n_iters, ns3d_persist_state *);                                                 \
+                          int n_iters, ns3d_persist_state *, int nchk = 0, double eps = -1.0, double err_mul = 1.0,   \
+                          double err_div = 1.0);                                                              \
     template <class T>                                                                                       \
     hipError_t pt_sweep2(hipStream_t, int variant, const T *, T *, const T *, T *, const T *,                \
                          const ns3d_pt_params &, int k0, int k1, int pass_flags, const ns3d_tile_window *win = nullptr); \

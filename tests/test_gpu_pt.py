@@ -942,7 +942,7 @@ def test_graph_cache_ignores_struct_padding(hip, oracle):
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("grid", [(24, 15, 15), (70, 6, 7), (63, 38, 38), (131, 21, 35), (66, 7, 6), (5, 4, 3), (3, 3, 3), (200, 66, 30)])
-def test_pt_persist_equals_single_sweeps(hip, oracle, grid, dtype):
+def test_pt_persist_equals_single_sweeps(hip, oracle, grid, dtype, monkeypatch):
     """k_pt_persist (a whole block of PT iterations in one cooperative launch, the grid resident on the chip, faces handed
     between workgroups after every iteration): forced on (ns3d_set_persist_mode 1) against forced off, pt_iterate for several
     counts and pt_solve with residual checks and early exits — identical fields, counts and residual histories; both boundary
@@ -966,14 +966,19 @@ def test_pt_persist_equals_single_sweeps(hip, oracle, grid, dtype):
                 res.append((hip.to_numpy(dP), hip.to_numpy(dD)))
             assert np.array_equal(res[0][0], res[1][0], equal_nan=True) and np.array_equal(res[0][1], res[1][1], equal_nan=True), (grid, bc, n)
         for eps, niter, nchk in ((-1.0, 57, 14), (1e-30, 45, 7), (5e4, 400, 13)):
+            # on: the whole loop in one launch (round 4: residual checks and the decision inside k_pt_persist), then a launch per
+            # residual-check block (NS3D_PERSIST_SOLVE=0); off: a launch per iteration
             res = []
-            for ctx in (on, off):
+            for ctx, whole in ((on, "1"), (on, "0"), (off, "1")):
+                monkeypatch.setenv("NS3D_PERSIST_SOLVE", whole)
                 dP, dD = hip.from_numpy(Pr0), hip.from_numpy(d0)
                 it, errs = hip.pt_solve(dP, dD, drhs, _params(hip, dP, g, *bc), eps, niter, nchk, 0.36, 1000.0, ctx=ctx)
                 torch.cuda.synchronize()
                 res.append((it, errs, hip.to_numpy(dP), hip.to_numpy(dD)))
-            assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1], equal_nan=True), (grid, bc, eps)
-            assert np.array_equal(res[0][2], res[1][2], equal_nan=True) and np.array_equal(res[0][3], res[1][3], equal_nan=True)
+            monkeypatch.delenv("NS3D_PERSIST_SOLVE")
+            for r in res[:2]:
+                assert r[0] == res[2][0] and np.array_equal(r[1], res[2][1], equal_nan=True), (grid, bc, eps)
+                assert np.array_equal(r[2], res[2][2], equal_nan=True) and np.array_equal(r[3], res[2][3], equal_nan=True)
     if grid == (63, 38, 38) and dtype == "f64":
         Pr, d = Pr0.copy(order="F"), d0.copy(order="F")
         _oracle_iters(oracle, Pr, d, rhs, g, 8, 0, True, 0.25)
@@ -1055,15 +1060,19 @@ def test_pt_persist_expired_hand_over_is_detected_and_the_block_redone(hip, orac
     torch.cuda.synchronize()
     assert ctx.persist_faults() == 1
     ctx.close()
-    # (3) ns3d_pt_solve: the check rides on the residual read-back; counts and residual history equal a run without the cooperative form
+    # (3) ns3d_pt_solve, the whole loop as one launch (the error word is read behind the launch's one synchronisation), and (4) a launch
+    # per residual-check block (the check rides on the residual read-back): counts and residual history equal a run without the
+    # cooperative form
     res = []
-    for persist in (1, 0):
+    for persist, whole in ((1, "1"), (0, "1"), (1, "0")):
+        monkeypatch.setenv("NS3D_PERSIST_SOLVE", whole)
         ctx = hip.Context(0, "strict"); ctx.set_persist_mode(persist); ctx.set_graph_mode(0)
         dP, dD = hip.from_numpy(Pr0), hip.from_numpy(d0)
         it, errs = hip.pt_solve(dP, dD, drhs, _params(hip, dP, g, *bc), -1.0, 45, 7, 0.36, 1000.0, ctx=ctx)
         torch.cuda.synchronize()
         res.append((it, errs, hip.to_numpy(dP), hip.to_numpy(dD), ctx.persist_faults()))
         ctx.close()
-    assert res[0][4] == 1 and res[1][4] == 0
-    assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and np.isfinite(res[0][1]).all()
-    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
+    assert res[0][4] == 1 and res[1][4] == 0 and res[2][4] == 1
+    for r in (res[0], res[2]):
+        assert r[0] == res[1][0] and r[1] == res[1][1] and np.isfinite(r[1]).all()
+        assert np.array_equal(r[2], res[1][2]) and np.array_equal(r[3], res[1][3])
