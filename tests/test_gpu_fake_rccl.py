@@ -309,3 +309,7 @@ def test_bench_gpus_n_over_the_rccl_arm(hip, gpus):
     planes = -(-126 // gpus) + 2                                    # ImplicitGlobalGrid: nz_g = P·(nz_loc − 2) + 2 ≥ 128
     assert d["strong"]["verified"] is True and d["strong"]["planes_per_rank"] == planes
     assert d["strong"]["global_grid"] == [128, 128, gpus * (planes - 2) + 2]
+    # the plan phase's collective trial of the overlap knobs (CUs left to the exchange, interior chunks): one choice for all ranks
+    t = d["config"]["overlap_trial"]
+    assert t["chosen"] in t["candidates_cus_chunks"] and len(t["ms_per_iteration"]) == len(t["candidates_cus_chunks"]) == 3
+    assert [d["config"]["reserved_cus"], d["config"]["interior_chunks"]] == t["chosen"]
