@@ -99,47 +99,53 @@ __global__ __launch_bounds__(256) void k_gemm_f64(GemmArgs g)
 // (16 consecutive i or j for each of 4 consecutive k) and both store patterns (threads running along k where k is the contiguous
 // direction in memory, along i / j otherwise) stay within two-way bank conflicts.  Per stage a wave issues 32 MFMAs (2 048 flop
 // each) for 24 LDS reads; every element of the large operand is fetched once per workgroup column.
-__global__ __launch_bounds__(256) void k_gemm_f64_lds(GemmArgs g)
+// Round 4: the tile is a template — WI×WJ waves, each UI×VJ MFMA tiles (TI = 16·WI·UI along i, TJ = 16·WJ·VJ along j) — and OCC asks
+// the compiler for that many waves per SIMD: the 128×64 form used 118 + 64 registers = two workgroups per CU, so the 714 workgroups
+// of the 253-wide transform ran as 512 + 202; at three per CU they are resident together.
+template <int WI, int WJ, int UI, int VJ, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_gemm_f64_lds(GemmArgs g)
 {
-    constexpr int TI = 128, TJ = 64, KT = 16, PA = TI + 2, PB = TJ + 2;
+    static_assert(WI * WJ == 4, "four waves");
+    constexpr int TI = 16 * WI * UI, TJ = 16 * WJ * VJ, KT = 16, PA = TI + 2, PB = TJ + 2, NA = TI * KT / 256, NB = TJ * KT / 256;
+    static_assert(TI * KT % 256 == 0 && TJ * KT % 256 == 0, "whole elements per thread");
     __shared__ double As[2][KT * PA];
     __shared__ double Bs[2][KT * PB];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wi = wave & 1, wj = wave >> 1;
+    const int wi = wave % WI, wj = wave / WI;
     const int ti = (int)blockIdx.x * TI, tj = (int)blockIdx.y * TJ;
     const double *__restrict__ A = g.A + (long)blockIdx.z * g.batchA;
     const double *__restrict__ B = g.B + (long)blockIdx.z * g.batchB;
     double *__restrict__ C = g.C + (long)blockIdx.z * g.batchC;
     const int r = lane & 15, kq = lane >> 4;
-    // which element of a tile this thread moves (eight of A, four of B per stage): along k where k is contiguous in memory
+    // which element of a tile this thread moves (NA of A, NB of B per stage): along k where k is contiguous in memory
     const bool a_kfast = g.sak == 1 && g.sai != 1, b_kfast = g.sbk == 1 && g.sbj != 1;
-    int ai[8], ak[8], bj[4], bk[4];
+    int ai[NA], ak[NA], bj[NB], bk[NB];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < NA; ++q) {
         if (a_kfast) { ak[q] = tid & 15; ai[q] = (tid >> 4) + 16 * q; }
-        else { ai[q] = tid & 127; ak[q] = (tid >> 7) + 2 * q; }
+        else { const int e = tid + 256 * q; ai[q] = e % TI; ak[q] = e / TI; }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NB; ++q) {
         if (b_kfast) { bk[q] = tid & 15; bj[q] = (tid >> 4) + 16 * q; }
-        else { bj[q] = tid & 63; bk[q] = (tid >> 6) + 4 * q; }
+        else { const int e = tid + 256 * q; bj[q] = e % TJ; bk[q] = e / TJ; }
     }
-    f64x4 acc[4][2];
+    f64x4 acc[UI][VJ];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < UI; ++u)
 #pragma unroll
-        for (int v = 0; v < 2; ++v) acc[u][v] = (f64x4){0.0, 0.0, 0.0, 0.0};
-    double ra[8], rb[4];
+        for (int v = 0; v < VJ; ++v) acc[u][v] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    double ra[NA], rb[NB];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NA; ++q) {
             const int i = ti + ai[q], k = k0 + ak[q];
             const bool ok = i < g.M && k < g.K;
             const double v = A[(long)(ok ? i : 0) * g.sai + (long)(ok ? k : 0) * g.sak];
             ra[q] = ok ? v : 0.0;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NB; ++q) {
             const int j = tj + bj[q], k = k0 + bk[q];
             const bool ok = j < g.N && k < g.K;
             const double v = B[(long)(ok ? k : 0) * g.sbk + (long)(ok ? j : 0) * g.sbj];
@@ -148,9 +154,9 @@ __global__ __launch_bounds__(256) void k_gemm_f64_lds(GemmArgs g)
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) As[buf][ak[q] * PA + ai[q]] = ra[q];
+        for (int q = 0; q < NA; ++q) As[buf][ak[q] * PA + ai[q]] = ra[q];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Bs[buf][bk[q] * PB + bj[q]] = rb[q];
+        for (int q = 0; q < NB; ++q) Bs[buf][bk[q] * PB + bj[q]] = rb[q];
     };
     fetch(0);
     stash(0);
@@ -162,29 +168,37 @@ __global__ __launch_bounds__(256) void k_gemm_f64_lds(GemmArgs g)
         const double *__restrict__ as = As[cur], *__restrict__ bs = Bs[cur];
 #pragma unroll
         for (int kk = 0; kk < KT / 4; ++kk) {
-            double av[4], bv[2];
+            double av[UI], bv[VJ];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) av[u] = as[(4 * kk + kq) * PA + wi * 64 + 16 * u + r];
+            for (int u = 0; u < UI; ++u) av[u] = as[(4 * kk + kq) * PA + wi * (16 * UI) + 16 * u + r];
 #pragma unroll
-            for (int v = 0; v < 2; ++v) bv[v] = bs[(4 * kk + kq) * PB + wj * 32 + 16 * v + r];
+            for (int v = 0; v < VJ; ++v) bv[v] = bs[(4 * kk + kq) * PB + wj * (16 * VJ) + 16 * v + r];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < UI; ++u)
 #pragma unroll
-                for (int v = 0; v < 2; ++v) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[v], av[u], acc[u][v], 0, 0, 0);
+                for (int v = 0; v < VJ; ++v) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[v], av[u], acc[u][v], 0, 0, 0);
         }
         if (more) stash(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < UI; ++u)
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+        for (int v = 0; v < VJ; ++v)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int i = ti + wi * 64 + 16 * u + r, j = tj + wj * 32 + 16 * v + kq + 4 * q;
+                const int i = ti + wi * (16 * UI) + 16 * u + r, j = tj + wj * (16 * VJ) + 16 * v + kq + 4 * q;
                 if (i < g.M && j < g.N) C[(long)i * g.sci + (long)j * g.scj] = acc[u][v][q];
             }
+}
+
+template <int WI, int WJ, int UI, int VJ, int OCC>
+static void launch_gemm_lds(hipStream_t s, const GemmArgs &g, int batch)
+{
+    constexpr int TI = 16 * WI * UI, TJ = 16 * WJ * VJ;
+    hipLaunchKernelGGL((k_gemm_f64_lds<WI, WJ, UI, VJ, OCC>), dim3((unsigned)((g.M + TI - 1) / TI), (unsigned)((g.N + TJ - 1) / TJ), (unsigned)batch),
+                       dim3(256), 0, s, g);
 }
 
 hipError_t gemm(hipStream_t s, const double *A, const double *B, double *C, int M, int N, int K, long sai, long sak, long sbk,
@@ -192,9 +206,14 @@ hipError_t gemm(hipStream_t s, const double *A, const double *B, double *C, int 
 {
     GemmArgs g{A, B, C, M, N, K, sai, sak, sbk, sbj, sci, scj, bA, bB, bC};
     static const bool simple_only = std::getenv("NS3D_GEMM_SIMPLE") && *std::getenv("NS3D_GEMM_SIMPLE") == '1';     // A/B
-    if (M >= 32 && N >= 16 && !simple_only)
-        hipLaunchKernelGGL(k_gemm_f64_lds, dim3((unsigned)((M + 127) / 128), (unsigned)((N + 63) / 64), (unsigned)batch), dim3(256), 0, s, g);
-    else
+    // NS3D_GEMM_SHAPE=0 (A/B): 128×64 as round 3 built it (118 + 64 registers: two workgroups per CU); default: the same tile at three
+    // per CU (168 registers, 10 spilled outside the MFMA loop).  255×153×153 step with the direct solve 1.29 → 1.19 ms; a 128×80 tile
+    // (<4,1,2,5>: 151 columns in two tiles instead of three) spilled 33 registers and lost: 1.80 ms (profiles/r4_step_cost.log).
+    static const int shape_env = std::getenv("NS3D_GEMM_SHAPE") ? std::atoi(std::getenv("NS3D_GEMM_SHAPE")) : -1;
+    if (M >= 32 && N >= 16 && !simple_only) {
+        if (shape_env == 0) launch_gemm_lds<2, 2, 4, 2, 1>(s, g, batch);
+        else launch_gemm_lds<2, 2, 4, 2, 3>(s, g, batch);
+    } else
         hipLaunchKernelGGL(k_gemm_f64, dim3((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64), (unsigned)batch), dim3(256), 0, s, g);
     return hipGetLastError();
 }
