@@ -730,6 +730,13 @@ static int pt_iterate_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_p
     return NS3D_OK;
 }
 
+// NS3D_BC_FUSED=0 (read per call: tests compare the two forms): set_bc_Vel! / set_bc_Pr! rule by rule, a launch each, as rounds 1-3
+static bool bc_fused_enabled()
+{
+    const char *v = std::getenv("NS3D_BC_FUSED");
+    return !(v && *v == '0');
+}
+
 // ---- the PT loop of multi.jl:458-471 ----------------------------------------------------------------------
 // enqueue exactly n iterations on stream s (two per pass where allowed) and leave the result pointers in src/dsrc
 template <class T>
@@ -1093,6 +1100,14 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
         CHECK_CTX(c); CHECK_PTRS(Pr); CHECK_GRID(nx, ny, nz, 2);                                             \
         hipError_t e = hipSuccess;                                                                           \
         hipStream_t s = c->stream;                                                                           \
+        if (bc_kind != NS3D_BC_MULTI && bc_kind != NS3D_BC_GPU) return fail(NS3D_ERR_ARG, "ns3d_set_bc_Pr: bad bc_kind %d", bc_kind); \
+        if (bc_fused_enabled()) {       /* the whole sequence as one gather launch (k_bc_fused) */          \
+            e = DISPATCH(c, bc_fused<T>(s, 1, bc_kind, Pr, (T *)nullptr, (T *)nullptr, nx, ny, nz, owns_outlet, outlet_val, \
+                                        (double)((T)rho * (T)g), dz, nz_arg));                               \
+            if (e != hipErrorInvalidValue) return finish(c, e, "set_bc_Pr");                                 \
+            (void)hipGetLastError();                                                                         \
+            e = hipSuccess;                                                                                  \
+        }                                                                                                    \
         if (bc_kind == NS3D_BC_MULTI) { /* multi.jl:176-181 */                                               \
             e = DISPATCH(c, bc_plane<T>(s, 0, Pr, nx, ny, nz, 0, 0, 0, 0));                                  \
             if (e == hipSuccess) e = DISPATCH(c, bc_plane<T>(s, 1, Pr, nx, ny, nz, 0, 0, 0, 0));             \
@@ -1111,6 +1126,13 @@ static int pt_solve_impl(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_
         CHECK_CTX(c); CHECK_PTRS(Vx, Vy, Vz); CHECK_GRID(nx, ny, nz, 2);                                     \
         hipStream_t s = c->stream;                                                                           \
         hipError_t e = hipSuccess;                                                                           \
+        if (bc_kind != NS3D_BC_MULTI && bc_kind != NS3D_BC_GPU) return fail(NS3D_ERR_ARG, "ns3d_set_bc_Vel: bad bc_kind %d", bc_kind); \
+        if (bc_fused_enabled()) {       /* the whole sequence as one gather launch (k_bc_fused) */          \
+            e = DISPATCH(c, bc_fused<T>(s, 0, bc_kind, Vx, Vy, Vz, nx, ny, nz, bc_kind == NS3D_BC_MULTI && owns_inlet, vin, 0.0, 0.0, 0)); \
+            if (e != hipErrorInvalidValue) return finish(c, e, "set_bc_Vel");                                \
+            (void)hipGetLastError();                                                                         \
+            e = hipSuccess;                                                                                  \
+        }                                                                                                    \
         struct { int which; T *A; int sx, sy, sz; } seq[9];                                                  \
         int n = 0;                                                                                           \
         if (bc_kind == NS3D_BC_MULTI) { /* multi.jl:157-163 */                                               \

@@ -117,19 +117,33 @@ __global__ __launch_bounds__(256, OCC) void k_gemm_f64_lds(GemmArgs g)
     const double *__restrict__ B = g.B + (long)blockIdx.z * g.batchB;
     double *__restrict__ C = g.C + (long)blockIdx.z * g.batchC;
     const int r = lane & 15, kq = lane >> 4;
-    // which element of a tile this thread moves (NA of A, NB of B per stage): along k where k is contiguous in memory
+    // which element of a tile this thread moves (NA of A, NB of B per stage): along k where k is contiguous in memory.  Each element
+    // has its pointer (advanced by a stage per fetch: two additions instead of two 64-bit multiplications — the SQ counters of round 3's
+    // form showed 8.5 VALU instructions per MFMA, most of them this index arithmetic), its LDS position and a validity bit, all
+    // computed once; only the last, partial stage checks k (wave-uniform branch).
     const bool a_kfast = g.sak == 1 && g.sai != 1, b_kfast = g.sbk == 1 && g.sbj != 1;
-    int ai[NA], ak[NA], bj[NB], bk[NB];
+    const double *pa[NA], *pb[NB];
+    int sa[NA], sb[NB];
+    unsigned okm = 0u;                                        // bit q: A element q inside M; bit NA+q: B element q inside N
+    auto a_k = [&](int q) { return a_kfast ? (tid & 15) : (tid + 256 * q) / TI; };
+    auto b_k = [&](int q) { return b_kfast ? (tid & 15) : (tid + 256 * q) / TJ; };
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
-        if (a_kfast) { ak[q] = tid & 15; ai[q] = (tid >> 4) + 16 * q; }
-        else { const int e = tid + 256 * q; ai[q] = e % TI; ak[q] = e / TI; }
+        const int il = a_kfast ? (tid >> 4) + 16 * q : (tid + 256 * q) % TI, kl = a_k(q);
+        const bool ok = ti + il < g.M;
+        okm |= (ok ? 1u : 0u) << q;
+        pa[q] = A + (long)(ok ? ti + il : 0) * g.sai + (long)kl * g.sak;
+        sa[q] = kl * PA + il;
     }
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
-        if (b_kfast) { bk[q] = tid & 15; bj[q] = (tid >> 4) + 16 * q; }
-        else { const int e = tid + 256 * q; bj[q] = e % TJ; bk[q] = e / TJ; }
+        const int jl = b_kfast ? (tid >> 4) + 16 * q : (tid + 256 * q) % TJ, kl = b_k(q);
+        const bool ok = tj + jl < g.N;
+        okm |= (ok ? 1u : 0u) << (NA + q);
+        pb[q] = B + (long)kl * g.sbk + (long)(ok ? tj + jl : 0) * g.sbj;
+        sb[q] = kl * PB + jl;
     }
+    const long stepa = (long)KT * g.sak, stepb = (long)KT * g.sbk;
     f64x4 acc[UI][VJ];
 #pragma unroll
     for (int u = 0; u < UI; ++u)
@@ -137,26 +151,31 @@ __global__ __launch_bounds__(256, OCC) void k_gemm_f64_lds(GemmArgs g)
         for (int v = 0; v < VJ; ++v) acc[u][v] = (f64x4){0.0, 0.0, 0.0, 0.0};
     double ra[NA], rb[NB];
     auto fetch = [&](int k0) {
+        if (k0 + KT <= g.K) {                                 // a whole stage: every k is inside
 #pragma unroll
-        for (int q = 0; q < NA; ++q) {
-            const int i = ti + ai[q], k = k0 + ak[q];
-            const bool ok = i < g.M && k < g.K;
-            const double v = A[(long)(ok ? i : 0) * g.sai + (long)(ok ? k : 0) * g.sak];
-            ra[q] = ok ? v : 0.0;
-        }
+            for (int q = 0; q < NA; ++q) { const double v = *pa[q]; ra[q] = (okm >> q) & 1u ? v : 0.0; pa[q] += stepa; }
 #pragma unroll
-        for (int q = 0; q < NB; ++q) {
-            const int j = tj + bj[q], k = k0 + bk[q];
-            const bool ok = j < g.N && k < g.K;
-            const double v = B[(long)(ok ? k : 0) * g.sbk + (long)(ok ? j : 0) * g.sbj];
-            rb[q] = ok ? v : 0.0;
+            for (int q = 0; q < NB; ++q) { const double v = *pb[q]; rb[q] = (okm >> (NA + q)) & 1u ? v : 0.0; pb[q] += stepb; }
+        } else {                                              // the last, partial stage: rows beyond K are zeros, never loaded
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                const bool ok = ((okm >> q) & 1u) && k0 + a_k(q) < g.K;
+                const double v = *(ok ? pa[q] : A);
+                ra[q] = ok ? v : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const bool ok = ((okm >> (NA + q)) & 1u) && k0 + b_k(q) < g.K;
+                const double v = *(ok ? pb[q] : B);
+                rb[q] = ok ? v : 0.0;
+            }
         }
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < NA; ++q) As[buf][ak[q] * PA + ai[q]] = ra[q];
+        for (int q = 0; q < NA; ++q) As[buf][sa[q]] = ra[q];
 #pragma unroll
-        for (int q = 0; q < NB; ++q) Bs[buf][bk[q] * PB + bj[q]] = rb[q];
+        for (int q = 0; q < NB; ++q) Bs[buf][sb[q]] = rb[q];
     };
     fetch(0);
     stash(0);

@@ -14,6 +14,7 @@
 // Layout: packed column-major, x fastest — a wave64 spans 64 consecutive x (512 B of fp64 per row).
 // All of these are HBM-bound 7-point-class stencils: no MFMA anywhere.
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -785,6 +786,109 @@ hipError_t bc_plane(hipStream_t s, int which, T *A, int sx, int sy, int sz, doub
     }
     const dim3 blk(64, 4, 1);
     hipLaunchKernelGGL(k_bc_plane<T>, grid3(U, V, 1, blk), blk, 0, s, which, A, sx, sy, sz, (T)a, (T)b, (T)c, nz_arg);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// set_bc_Vel! / set_bc_Pr! as ONE launch (round 4).  The reference applies bc_x!, bc_y!, bc_z! (+ a constant or hydrostatic plane) one
+// after the other (multi.jl:156-169, 175-181; gpu.jl:264-286): 8-9 launches of a few µs each per call, 12 per time step.  Every rule
+// is a copy from the neighbouring cell or a constant, and the later rules read what the earlier ones wrote only on edges and corners,
+// where the chain of copies ends at the interior cell with the boundary indices clamped — in the dimensions that HAVE a copy rule.  So
+// the whole sequence is a gather: boundary cell (i,j,k) ← A[clamp i, clamp j, clamp k] read from cells no rule writes, then the
+// overrides in the sequence's own order (bc_zV!'s zero bottom plane; Vx[1,:,:] = vin / Pr[end,:,:] = val / the hydrostatic x planes,
+// which come last and cover whole planes).  Extents below 3 in a copied dimension keep the launch-per-rule path (the two faces
+// would read each other).  Same values on every cell: tests/test_gpu_kernels.py compares both paths with the oracle.
+// ---------------------------------------------------------------------------------------------------------
+template <class T>
+struct BcArr {
+    T *A;
+    int sx, sy, sz;
+    int copy;           // bit d: dimension d has the copy rule
+    int zv;             // bc_zV!: plane 0 = 0, top plane copies (gpu.jl:239-243)
+    int xlo, xhi;       // 0 nothing, 1 constant, 2 hydrostatic (+100 on the low side; gpu.jl:252-261)
+    T xlo_val, xhi_val, hyd_a, hyd_b;
+    int hyd_nz;
+};
+template <class T>
+struct BcArgs { BcArr<T> arr[3]; int narr; };
+template <class T>
+__device__ __forceinline__ void bc_cell(const BcArr<T> &b, int i, int j, int k)
+{
+    T v;
+    const bool lo = i == 0 && b.xlo, hi = i == b.sx - 1 && b.xhi;
+    if (b.zv && k == 0) v = (T)0;
+    else if (lo || hi) {
+        const int mode = lo ? b.xlo : b.xhi;
+        if (mode == 1) v = lo ? b.xlo_val : b.xhi_val;
+        else {
+            const T h = (b.hyd_a * ((T)(b.hyd_nz - (k + 1)) + (T)0.5)) * b.hyd_b;
+            v = lo ? h + (T)100 : h;
+        }
+    } else {
+        const int ci = (b.copy & 1) ? min(max(i, 1), b.sx - 2) : i, cj = (b.copy & 2) ? min(max(j, 1), b.sy - 2) : j;
+        const int ck = ((b.copy & 4) || b.zv) ? min(max(k, 1), b.sz - 2) : k;
+        v = b.A[IX3(ci, cj, ck, b.sx, b.sy)];
+    }
+    b.A[IX3(i, j, k, b.sx, b.sy)] = v;
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_bc_fused(BcArgs<T> g)
+{
+    const int a = blockIdx.z / 3, d = blockIdx.z % 3;
+    const BcArr<T> &b = g.arr[a];
+    const bool applies = d == 0 ? ((b.copy & 1) || b.xlo || b.xhi) : d == 1 ? (b.copy & 2) != 0 : ((b.copy & 4) || b.zv);
+    if (!applies) return;
+    const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y * blockDim.y + threadIdx.y;
+    if (d == 0) {
+        if (u >= b.sy || v >= b.sz) return;
+        if ((b.copy & 1) || b.xlo) bc_cell<T>(b, 0, u, v);
+        if ((b.copy & 1) || b.xhi) bc_cell<T>(b, b.sx - 1, u, v);
+    } else if (d == 1) {
+        if (u >= b.sx || v >= b.sz) return;
+        bc_cell<T>(b, u, 0, v);
+        bc_cell<T>(b, u, b.sy - 1, v);
+    } else {
+        if (u >= b.sx || v >= b.sy) return;
+        bc_cell<T>(b, u, v, 0);
+        bc_cell<T>(b, u, v, b.sz - 1);
+    }
+}
+// the fields of set_bc_Vel! (narr = 3: Vx, Vy, Vz) or set_bc_Pr! (narr = 1); hipErrorInvalidValue: an extent the gather form does not cover
+template <class T>
+hipError_t bc_fused(hipStream_t s, int what, int bc_kind, T *A0, T *A1, T *A2, int nx, int ny, int nz, int owns, double val, double rho_g,
+                    double dz, int nz_arg)
+{
+    BcArgs<T> g;
+    std::memset((void *)&g, 0, sizeof g);
+    auto set = [&](int q, T *A, int sx, int sy, int sz, int copy, int zv) {
+        g.arr[q].A = A; g.arr[q].sx = sx; g.arr[q].sy = sy; g.arr[q].sz = sz; g.arr[q].copy = copy; g.arr[q].zv = zv;
+    };
+    if (what == 0) {                    // set_bc_Vel!
+        g.narr = 3;
+        if (bc_kind == NS3D_BC_MULTI) { // multi.jl:157-166
+            set(0, A0, nx + 1, ny, nz, 7, 0); set(1, A1, nx, ny + 1, nz, 5, 0); set(2, A2, nx, ny, nz + 1, 3, 0);
+            if (owns) { g.arr[0].xlo = 1; g.arr[0].xlo_val = (T)val; }
+        } else {                        // gpu.jl:265-276
+            set(0, A0, nx + 1, ny, nz, 3, 1); set(1, A1, nx, ny + 1, nz, 3, 1); set(2, A2, nx, ny, nz + 1, 3, 1);
+        }
+    } else {                            // set_bc_Pr!
+        g.narr = 1;
+        if (bc_kind == NS3D_BC_MULTI) { // multi.jl:176-181
+            set(0, A0, nx, ny, nz, 7, 0);
+            if (owns) { g.arr[0].xhi = 1; g.arr[0].xhi_val = (T)val; }
+        } else {                        // gpu.jl:282-284
+            set(0, A0, nx, ny, nz, 6, 0);
+            g.arr[0].xlo = g.arr[0].xhi = 2; g.arr[0].hyd_a = (T)rho_g; g.arr[0].hyd_b = (T)dz; g.arr[0].hyd_nz = nz_arg;
+        }
+    }
+    int mu = 0, mv = 0;
+    for (int q = 0; q < g.narr; ++q) {
+        const BcArr<T> &b = g.arr[q];
+        if (((b.copy & 1) && b.sx < 3) || ((b.copy & 2) && b.sy < 3) || (((b.copy & 4) || b.zv) && b.sz < 3)) return hipErrorInvalidValue;
+        mu = max(mu, max(b.sx, b.sy)); mv = max(mv, max(b.sy, b.sz));
+    }
+    const dim3 blk(64, 4, 1);
+    hipLaunchKernelGGL(k_bc_fused<T>, dim3((unsigned)((mu + 63) / 64), (unsigned)((mv + 3) / 4), (unsigned)(3 * g.narr)), blk, 0, s, g);
     return hipGetLastError();
 }
 
@@ -3706,6 +3810,7 @@ hipError_t divtest(hipStream_t s, double d, long n, unsigned long long seed, uns
     template hipError_t correct_V<T>(hipStream_t, T *, T *, T *, const T *, double, double, double, double,  \
                                      double, int, int, int);                                                 \
     template hipError_t bc_plane<T>(hipStream_t, int, T *, int, int, int, double, double, double, int);      \
+    template hipError_t bc_fused<T>(hipStream_t, int, int, T *, T *, T *, int, int, int, int, double, double, double, int); \
     template hipError_t advect<T>(hipStream_t, T *, const T *, T *, const T *, T *, const T *, T *,          \
                                   const T *, double, double, double, double, int, int, int, int, int, int);  \
     template hipError_t pt_sweep<T>(hipStream_t, int, const T *, T *, T *, const T *, const ns3d_pt_params &,\

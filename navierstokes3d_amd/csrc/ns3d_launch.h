@@ -86,6 +86,11 @@ struct ns3d_subbox_batch {
     /* which: 0 bc_x 1 bc_y 2 bc_z 3 bc_zV 4 bc_xhydstatic 5 bc_x_Vx 6 bc_x_Pr */                            \
     template <class T>                                                                                       \
     hipError_t bc_plane(hipStream_t, int which, T *, int, int, int, double a, double b, double c, int nz_arg);\
+    /* set_bc_Vel! (what 0: A0..A2 = Vx, Vy, Vz) or set_bc_Pr! (what 1: A0 = Pr) as one gather launch; hipErrorInvalidValue where an \
+     * extent is too small for that form (the caller then launches rule by rule) */                           \
+    template <class T>                                                                                       \
+    hipError_t bc_fused(hipStream_t, int what, int bc_kind, T *A0, T *A1, T *A2, int nx, int ny, int nz, int owns, double val, \
+                        double rho_g, double dz, int nz_arg);                                                \
     template <class T>                                                                                       \
     hipError_t advect(hipStream_t, T *, const T *, T *, const T *, T *, const T *, T *, const T *, double,   \
                       double, double, double, int, int, int, int, int koff, int nzg);                        \

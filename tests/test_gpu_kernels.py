@@ -174,10 +174,13 @@ def test_bc_planes(hip, oracle, grid):
     _run_both(hip, oracle, "bc_x_Pr", ["c"], (0.0,), grid, "strict", [0])
 
 
-@pytest.mark.parametrize("grid", GRIDS)
-def test_set_bc_sequences(hip, oracle, grid):
-    """Order matters on edges/corners: multi.jl x→y→z→outlet, gpu.jl y→z→x-hydrostatic."""
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("grid", GRIDS + [(6, 2, 3), (2, 5, 2), (3, 3, 3)])
+def test_set_bc_sequences(hip, oracle, grid, fused, monkeypatch):
+    """Order matters on edges/corners: multi.jl x→y→z→outlet, gpu.jl y→z→x-hydrostatic.  Both forms of the library:
+    the whole sequence as one gather launch (k_bc_fused, round 4) and rule by rule (NS3D_BC_FUSED=0; also what extents below 3 take)."""
     import torch
+    monkeypatch.setenv("NS3D_BC_FUSED", fused)
     nx, ny, nz = grid
     g = geometry(*grid)
     ctx = hip.Context(0, "strict")
