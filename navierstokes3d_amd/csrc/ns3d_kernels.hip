@@ -1865,6 +1865,98 @@ static hipError_t launch_pipe_auto(hipStream_t s, SweepArgs<T> &a, int kz)
 // sweep, or (SEPF) only the x-face cell beside an interior cell, the y/z faces following in k_pt_faces_*.  z planes that
 // are inter-slab halos are not supported here: z-slab ranks pass buffers extended by a second ghost plane (slab.py).
 // =========================================================================================================
+// ---- the boundary cells a tile can form from its OWN output (round 4: "fold", epilogue form) ------------------------------------
+// k_pt_faces is a 5 µs launch behind a 48 µs sweep on the reference's 255×153×153 grid (9 % of every pass).  Storing the boundary
+// cells from inside the z-march cost more than that (SGPR pressure in the hot loop, profiles/r4_pass_chain_ab.log).  Here the march is
+// untouched: AFTER it, a workgroup whose tile touches a y face or whose z-chunk holds plane 1 / nz−2 waits for its own stores
+// (barrier: workgroup-scope release/acquire) and writes the y-face rows of its planes and the z-face plane over its columns — the
+// same gather as k_pt_faces (face_value_own: index clamp, outlet / hydrostatic planes), whose source cells are all cells this
+// workgroup stored; they are read past the L1 (agent-scope loads), which never held these lines.
+__device__ __forceinline__ double ld_own(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ float ld_own(const float *p)
+{
+    return __uint_as_float(__hip_atomic_load((const unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+template <class T>
+__device__ __forceinline__ T face_value_own(const SweepArgs<T> &a, int i, int j, int k)
+{
+    const int nx = a.nx, ny = a.ny, nz = a.nz;
+    if (a.bc_kind == NS3D_BC_GPU) {
+        if (i == 0) return xface_val<T>(a, false, (T)0, k);
+        if (i == nx - 1) return xface_val<T>(a, true, (T)0, k);
+    } else if (i == nx - 1 && a.owns_outlet) return a.outlet_val;
+    const int ci = min(max(i, 1), nx - 2), cj = min(max(j, 1), ny - 2), ck = min(max(k, 1), nz - 2);
+    return ld_own(&a.Pout[IX3(ci, cj, ck, nx, ny)]);
+}
+// x0…x1, y0…y1: the interior cells the tile stored (inclusive); kb…ke−1 its planes; tid / nthr: the workgroup's threads
+template <class T>
+__device__ __forceinline__ void fold_faces(const SweepArgs<T> &a, int x0, int x1, int y0, int y1, int kb, int ke, int tid, int nthr)
+{
+    const int nx = a.nx, ny = a.ny, nz = a.nz;
+    const bool ylo = y0 == 1, yhi = y1 == ny - 2;
+    const bool zlo = kb == 1 && !a.zlo_halo, zhi = ke == nz - 1 && !a.zhi_halo;
+    if (!(ylo || yhi || zlo || zhi)) return;                // workgroup-uniform
+    __syncthreads();
+    const int xa = x0 == 1 ? 0 : x0, xb = x1 == nx - 2 ? nx - 1 : x1;     // with the x-face cells where the tile holds their neighbour
+    const int wx = xb - xa + 1;
+    // eight cells per thread and trip: the gathers are issued together, then the stores (one load latency per trip, not one per cell)
+    constexpr int U = 8;
+    if (ylo || yhi) {
+        const int rows = (ylo ? 1 : 0) + (yhi ? 1 : 0), nk = ke - kb, n = wx * nk * rows;
+        for (int base = tid; base < n; base += nthr * U) {
+            T v[U];
+            idx_t at[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = base + u * nthr;
+                if (q < n) {
+                    const int i = xa + q % wx, r = q / wx, k = kb + r % nk;
+                    const int j = (rows == 2 ? r / nk == 0 : ylo) ? 0 : ny - 1;
+                    at[u] = IX3(i, j, k, nx, ny);
+                    v[u] = face_value_own<T>(a, i, j, k);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (base + u * nthr < n) a.Pout[at[u]] = v[u];
+        }
+    }
+    if (zlo || zhi) {
+        const int ya = y0 == 1 ? 0 : y0, yb = y1 == ny - 2 ? ny - 1 : y1, wy_ = yb - ya + 1;
+        const int planes = (zlo ? 1 : 0) + (zhi ? 1 : 0), n = wx * wy_ * planes;
+        for (int base = tid; base < n; base += nthr * U) {
+            T v[U];
+            idx_t at[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = base + u * nthr;
+                if (q < n) {
+                    const int i = xa + q % wx, r = q / wx, j = ya + r % wy_;
+                    const int k = (planes == 2 ? r / wy_ == 0 : zlo) ? 0 : nz - 1;
+                    at[u] = IX3(i, j, k, nx, ny);
+                    v[u] = face_value_own<T>(a, i, j, k);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (base + u * nthr < n) a.Pout[at[u]] = v[u];
+        }
+    }
+}
+
+// boundary cells formed by the tiles themselves (fold_faces) where a separate k_pt_faces launch is a visible share of the pass:
+// NS3D_FOLD_FACES=1/0 forces; default: grids up to NS3D_FOLD_MAX_CELLS — whole-grid launches only (no tile window, faces wanted)
+template <class T>
+static bool fold_wanted(const SweepArgs<T> &a)
+{
+    static const int fold_env = std::getenv("NS3D_FOLD_FACES") ? std::atoi(std::getenv("NS3D_FOLD_FACES")) : -1;
+    if (a.no_faces == 1 || a.win != nullptr) return false;
+    return fold_env >= 0 ? fold_env == 1 : (long)a.nx * a.ny * a.nz <= NS3D_FOLD_MAX_CELLS;
+}
+
 template <class T, int WX, int WY, int CPT, bool NT, int MINW = 1, bool SEPF = false>
 __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a, int ntx, int nty)
 {
@@ -2166,6 +2258,14 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweep2(SweepArgs<T> a
             }
     }
     for (; s < nsteps; ++s) step(s, std::true_type{});
+    if constexpr (SEPF) {
+        if (a.no_faces == NS3D_FACES_FOLDED) {
+            // the interior cells this tile stored: columns lx = 1 … TX−2 (and the one beside an x face), rows lr = 1 … TY−2 likewise
+            const int x0 = ox <= 1 ? 1 : ox + 1, x1 = min(ox + TX - 2 + (ox + TX - 1 == nx - 2 ? 1 : 0), nx - 2);
+            const int y0 = oy <= 1 ? 1 : oy + 1, y1 = min(oy + TY - 2 + (oy + TY - 1 == ny - 2 ? 1 : 0), ny - 2);
+            if (x0 <= x1 && y0 <= y1) fold_faces<T>(a, x0, x1, y0, y1, kb, ke, tid, 64 * WX * WY);
+        }
+    }
 }
 
 // ---- y- and z-face cells of P² as separate launches (used with the SEPF form of k_pt_sweep2) ----------------------
@@ -2326,6 +2426,7 @@ static hipError_t launch_sweep2(hipStream_t s, SweepArgs<T> &a, int kz)
     }
     a.kz = kz;
     const int ntz = (nk + kz - 1) / kz;
+    if (SEPF && a.no_faces != 1) a.no_faces = fold_wanted<T>(a) ? NS3D_FACES_FOLDED : 0;
     hipLaunchKernelGGL((k_pt_sweep2<T, WX, WY, CPT, NT, MINW, SEPF>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX, WY, 1), 0, s, a, ntx, nty);
     hipError_t e = hipGetLastError();
     if (SEPF && e == hipSuccess && !a.no_faces) e = launch_faces<T>(s, a);
@@ -2350,7 +2451,7 @@ static hipError_t launch_sweep2(hipStream_t s, SweepArgs<T> &a, int kz)
 // =========================================================================================================
 // PF: where the loads of the next step are issued — 0: between and after the levels; 1 (EARLY): before level 1.  (Loads two
 // steps ahead through a second set of staging registers were measured and dropped: no gain, 16 more registers.)
-template <class T, int NL, int WX, int WY, int CPT, int PF, int MINW = 1>
+template <class T, int NL, int WX, int WY, int CPT, int PF, int MINW = 1, bool FOLD = false>
 __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a, int ntx, int nty)
 {
     static_assert(NL >= 2 && NL <= 5, "levels");
@@ -2693,9 +2794,14 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
             }
     }
     for (; s < nsteps; ++s) step(s, std::true_type{});
+    if constexpr (FOLD) {       // the boundary cells next to this tile's own output, instead of a k_pt_faces launch (fold_faces)
+        const int x0 = tile_x_lo ? 1 : ox + NL - 1, x1 = tile_x_hi ? nx - 2 : ox + TX - NL;
+        const int y0 = tile_y_lo ? 1 : oy + NL - 1, y1 = tile_y_hi ? ny - 2 : oy + TY - NL;
+        if (x0 <= x1 && y0 <= y1) fold_faces<T>(a, x0, x1, y0, y1, kb, ke, tid, 64 * WX * WY);
+    }
 }
 
-template <class T, int NL, int WX, int WY, int CPT, int PF, int MINW = 1>
+template <class T, int NL, int WX, int WY, int CPT, int PF, int MINW = 1, bool FOLD = false>
 static hipError_t launch_sweepN(hipStream_t s, SweepArgs<T> &a, int kz)
 {
     constexpr int TX = 64 * WX, TY = CPT * WY, OV = 2 * (NL - 1);
@@ -2710,7 +2816,7 @@ static hipError_t launch_sweepN(hipStream_t s, SweepArgs<T> &a, int kz)
         // chunks per tile column that minimise the z-steps the slowest CU marches: rounds of workgroups × (planes per chunk + the
         // 2(NL−1) steps a chunk spends filling its pipeline) — the tail round of an unlucky tile count (1024²: 1026 tiles on 256
         // CUs) costs a whole chunk, so such grids want shorter chunks
-        static const int per_cu = workgroups_per_cu((const void *)k_pt_sweepN<T, NL, WX, WY, CPT, PF, MINW>, 64 * WX * WY);
+        static const int per_cu = workgroups_per_cu((const void *)k_pt_sweepN<T, NL, WX, WY, CPT, PF, MINW, FOLD>, 64 * WX * WY);
         const long slots = (long)max(8, device_cus() - a.cus_off) * per_cu, tiles = (long)ntx * nty;
         const int cmax = max(1, nk / (6 * NL));
         long best_c = 1, best_cost = -1;
@@ -2722,7 +2828,7 @@ static hipError_t launch_sweepN(hipStream_t s, SweepArgs<T> &a, int kz)
         }
         kz = (int)((nk + best_c - 1) / best_c);
     } else if (kz > 90) {
-        static const int per_cu = workgroups_per_cu((const void *)k_pt_sweepN<T, NL, WX, WY, CPT, PF, MINW>, 64 * WX * WY);
+        static const int per_cu = workgroups_per_cu((const void *)k_pt_sweepN<T, NL, WX, WY, CPT, PF, MINW, FOLD>, 64 * WX * WY);
         const long slots = (long)max(8, device_cus() - a.cus_off) * per_cu, tiles = (long)ntx * nty;
         const int want = kz - 90;
         const int cmax = max(1, nk / (6 * NL));              // short chunks are mostly pipeline fill (2(NL−1) steps each)
@@ -2741,10 +2847,10 @@ static hipError_t launch_sweepN(hipStream_t s, SweepArgs<T> &a, int kz)
     }
     a.kz = kz;
     const int ntz = (nk + kz - 1) / kz;
-    hipLaunchKernelGGL((k_pt_sweepN<T, NL, WX, WY, CPT, PF, MINW>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX, WY, 1), 0, s, a,
+    hipLaunchKernelGGL((k_pt_sweepN<T, NL, WX, WY, CPT, PF, MINW, FOLD>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX, WY, 1), 0, s, a,
                        ntx, nty);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess && !a.no_faces) e = launch_faces<T>(s, a);
+    if (e == hipSuccess && !a.no_faces && !FOLD) e = launch_faces<T>(s, a);
     return e;
     }
 }
@@ -3180,7 +3286,8 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
     case 22: if constexpr (sizeof(T) == 4) { NS3D_SWN(NLV, 1, 12, 4, true); } else return hipErrorInvalidValue; /* fp32: 64×48, 768 threads = three waves per SIMD */ \
     case 23: NS3D_SWN(NLV, 1, 12, 2, true);  /* 64×24, 768 threads, two rows per thread: three waves per SIMD */ \
     case 24: if constexpr (sizeof(T) == 4 || NS3D_SHAPE24_F64) { NS3D_SWN(NLV, 1, 16, 2, true); } else return hipErrorInvalidValue; /* fp32: 64×32, 1024 threads = four waves per SIMD (fp64 spills: A/B with -DNS3D_SHAPE24_F64=1) */ \
-    case 28: NS3D_SWN(NLV, 1, 12, 2, false);                                                                     \
+    case 28: if (fold_wanted<T>(a)) return launch_sweepN<T, NLV, 1, 12, 2, false, 1, true>(s, a, kz);       /* small grids: boundary cells folded in */ \
+             NS3D_SWN(NLV, 1, 12, 2, false);                                                                \
     case 11: NS3D_SWN(NLV, 1, 8, 4, true);                                                                  \
     case 12: NS3D_SWN(NLV, 2, 4, 4, true);                                                                  \
     default: return hipErrorInvalidValue;                                                                   \

@@ -12,6 +12,8 @@
 // pass_flags of pt_sweep2 / pt_sweepn: bit 1 — no boundary-cell launch behind the sweep; bits 8… — compute units (in eights) the stream's
 // CU mask leaves out (ns3d_reserve_cus), which the z-chunking must not count on
 #define NS3D_PASS_SKIP_FACES 2
+#define NS3D_FACES_FOLDED 2             /* SweepArgs::no_faces: the sweep kernel forms the boundary cells itself (fold_faces) */
+#define NS3D_FOLD_MAX_CELLS 20000000L   /* … by default on grids up to this many cells */
 struct ns3d_tile_geom { int TX, TY, OV, ntx, nty; };      // columns × rows per tile, overlap 2(NL−1), tiles per plane
 struct ns3d_tile_window { int x0, x1, y0, y1; ns3d_tile_geom *geom; };
 struct ns3d_persist_state {
