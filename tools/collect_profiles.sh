@@ -35,7 +35,7 @@ python3 tools/collect_traffic.py --out $O/${TAG}_traffic_512.json --runs 4:2300,
 python3 tools/collect_traffic.py --out $O/${TAG}_traffic_512_f32.json --runs 5:2400,4:2400,4:2200,3:100,2:1100 --modes strict --dtype f32 2>&1 | tail -3
 python3 tools/kernel_rates.py > $O/${TAG}_kernel_rates_512.jsonl 2>/dev/null; grep -c kernel $O/${TAG}_kernel_rates_512.jsonl
 python3 tools/run_config.py --script multi --nx 63 --nt 20 > $O/${TAG}_config_a_63x38x38.json 2>/dev/null; tail -c 300 $O/${TAG}_config_a_63x38x38.json; echo
-python3 tools/run_config.py --script multi --nx 255 --nt 3 --marginal 5 --compare-fast --compare-direct > $O/${TAG}_config_b_multi_255x153x153.json 2>/dev/null; tail -c 300 $O/${TAG}_config_b_multi_255x153x153.json; echo
+python3 tools/run_config.py --script multi --nx 255 --nt 3 --marginal 40 --compare-fast --compare-direct > $O/${TAG}_config_b_multi_255x153x153.json 2>/dev/null; tail -c 300 $O/${TAG}_config_b_multi_255x153x153.json; echo
 python3 tools/run_config.py --script gpu --nx 255 --nt 3 > $O/${TAG}_config_b_gpujl_255x153x153.json 2>/dev/null; tail -c 300 $O/${TAG}_config_b_gpujl_255x153x153.json; echo
 python3 tools/cart_rates.py > $O/${TAG}_cart_rates.jsonl 2> $O/${TAG}_cart_rates.err; cat $O/${TAG}_cart_rates.jsonl
 # pressure solve: the reference's PT loop against the direct solve (outside parity), the reference's own grids
@@ -46,3 +46,7 @@ for nzl in 66 130 258; do python3 tools/ab/slab_overhead.py --nz-local $nzl --ra
 NS3D_RCCL_LIB=$PWD/tests/fake_rccl/libfake_rccl.so FAKE_RCCL_ARENA_MB=64 python3 bench.py --gpus 2 --grid 256 --steps 40 --warmup 4 --transport rccl > $O/${TAG}_bench_2ranks_fake_rccl.json 2> $O/${TAG}_bench_2ranks_fake_rccl.err; cut -c1-400 $O/${TAG}_bench_2ranks_fake_rccl.json
 # SQ counters of the two windowed once-per-step kernels (two --pmc passes each over tools/kernel_rates.py)
 { bash tools/ab/kernel_sq.sh k_advect_win2; bash tools/ab/kernel_sq.sh k_predict_fused; } > $O/${TAG}_window_kernels_sq.log 2>&1; cat $O/${TAG}_window_kernels_sq.log
+# a further time step of the two reference cases (wall, >= 40 steps: 5-step differences scatter), and the kernels of the direct-solve step
+{ python3 tools/ab/step_cost.py --steps 100; python3 tools/ab/step_cost.py --steps 40 --pressure pt --nx 63; python3 tools/ab/step_cost.py --steps 10 --pressure pt; } > $O/${TAG}_step_cost_wall.log 2>&1; cat $O/${TAG}_step_cost_wall.log
+rm -rf /tmp/ns3d_kt; rocprofv3 --kernel-trace --stats -f csv -d /tmp/ns3d_kt -o kt -- python3 tools/ab/step_cost.py --steps 100 > /dev/null 2>> $O/${TAG}_rocprof.err
+f=$(find /tmp/ns3d_kt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/${TAG}_step_cost_kernel_stats.csv
