@@ -256,7 +256,9 @@ typedef struct ns3d_step_params {
      * grids (no z halo flags).  All-Neumann problems (no outlet): the zero-mean solution. */                \
     int ns3d_poisson_direct_##S(ns3d_ctx *, T *Pr, T *dPrdtau, const T *divV, const ns3d_pt_params *p);      \
     /* ---- host sequences of the reference, one call each ---- */                                           \
-    /* set_bc_Pr!  multi.jl:175-181 (kind 0, without the halo update) / gpu.jl:281-286 (kind 1) */           \
+    /* set_bc_Pr!  multi.jl:175-181 (kind 0, without the halo update) / gpu.jl:281-286 (kind 1).  Both set_bc_* run the      \
+     * reference's rule sequence as ONE gather launch (same values on every cell, edges and corners included;                \
+     * NS3D_BC_FUSED=0 or an extent below 3: a launch per rule) */                                            \
     int ns3d_set_bc_Pr_##S(ns3d_ctx *, T *Pr, int bc_kind, int owns_outlet, double outlet_val, double dz,    \
                            int nz_arg, double g, double rho, int nx, int ny, int nz);                        \
     /* set_bc_Vel! multi.jl:156-166 (kind 0, without the halo update) / gpu.jl:264-279 (kind 1) */           \
