@@ -40,6 +40,13 @@ struct GemmArgs {
     int M, N, K;
     long sai, sak, sbk, sbj, sci, scj;
     long batchA, batchB, batchC;
+    // what the LDS-staged kernel does with a finished element instead of C(i,j) = acc (round 4: two pointwise passes folded into the
+    // products that feed them):  1: C(i,j) = acc / (λx[i mod mx] + λy[i / mx] + λz[j]), 0 where the sum is 0 (k_direct_scale);
+    // 2 / 3: the element is interior cell (i, j mod my, j / my) of the double / float pressure array `out` (k_direct_scatter)
+    int epi;
+    const double *l0, *l1, *l2;
+    void *out;
+    int e_mx, e_my, e_nx, e_ny;
 };
 __global__ __launch_bounds__(256) void k_gemm_f64(GemmArgs g)
 {
@@ -208,7 +215,18 @@ __global__ __launch_bounds__(256, OCC) void k_gemm_f64_lds(GemmArgs g)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int i = ti + wi * (16 * UI) + 16 * u + r, j = tj + wj * (16 * VJ) + 16 * v + kq + 4 * q;
-                if (i < g.M && j < g.N) C[(long)i * g.sci + (long)j * g.scj] = acc[u][v][q];
+                if (i < g.M && j < g.N) {
+                    const double a = acc[u][v][q];
+                    if (g.epi == 0) C[(long)i * g.sci + (long)j * g.scj] = a;
+                    else if (g.epi == 1) {
+                        const double lam = g.l0[i % g.e_mx] + g.l1[i / g.e_mx] + g.l2[j];
+                        C[(long)i * g.sci + (long)j * g.scj] = lam != 0.0 ? a / lam : 0.0;
+                    } else {
+                        const long at = (long)(i + 1) + (long)g.e_nx * ((long)(j % g.e_my + 1) + (long)g.e_ny * (j / g.e_my + 1));
+                        if (g.epi == 2) ((double *)g.out)[at] = a;
+                        else ((float *)g.out)[at] = (float)a;
+                    }
+                }
             }
 }
 
@@ -221,9 +239,10 @@ static void launch_gemm_lds(hipStream_t s, const GemmArgs &g, int batch)
 }
 
 hipError_t gemm(hipStream_t s, const double *A, const double *B, double *C, int M, int N, int K, long sai, long sak, long sbk,
-                long sbj, long sci, long scj, int batch = 1, long bA = 0, long bB = 0, long bC = 0)
+                long sbj, long sci, long scj, int batch = 1, long bA = 0, long bB = 0, long bC = 0, const GemmArgs *epi = nullptr)
 {
-    GemmArgs g{A, B, C, M, N, K, sai, sak, sbk, sbj, sci, scj, bA, bB, bC};
+    GemmArgs g{A, B, C, M, N, K, sai, sak, sbk, sbj, sci, scj, bA, bB, bC, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+    if (epi) { g.epi = epi->epi; g.l0 = epi->l0; g.l1 = epi->l1; g.l2 = epi->l2; g.out = epi->out; g.e_mx = epi->e_mx; g.e_my = epi->e_my; g.e_nx = epi->e_nx; g.e_ny = epi->e_ny; }
     static const bool simple_only = std::getenv("NS3D_GEMM_SIMPLE") && *std::getenv("NS3D_GEMM_SIMPLE") == '1';     // A/B
     // NS3D_GEMM_SHAPE=0 (A/B): 128×64 as round 3 built it (118 + 64 registers: two workgroups per CU); default: the same tile at three
     // per CU (168 registers, 10 spilled outside the MFMA loop).  255×153×153 step with the direct solve 1.29 → 1.19 ms; a 128×80 tile
@@ -232,8 +251,10 @@ hipError_t gemm(hipStream_t s, const double *A, const double *B, double *C, int 
     if (M >= 32 && N >= 16 && !simple_only) {
         if (shape_env == 0) launch_gemm_lds<2, 2, 4, 2, 1>(s, g, batch);
         else launch_gemm_lds<2, 2, 4, 2, 3>(s, g, batch);
-    } else
+    } else {
+        if (g.epi) return hipErrorInvalidValue;              // the register-only kernel has no epilogue: the caller runs the pointwise pass
         hipLaunchKernelGGL(k_gemm_f64, dim3((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64), (unsigned)batch), dim3(256), 0, s, g);
+    }
     return hipGetLastError();
 }
 
@@ -390,18 +411,43 @@ int poisson_direct(ns3d_ctx *c, T *Pr, T *D, const T *divV, const ns3d_pt_params
     // forward: x (Vxᵀ·U), y (U_k·Vy per plane), z (U·Vz)
     if (e == hipSuccess) e = gemm(s, pl->V[0], W0, W1, mx, my * mz, mx, /*A(a,i)=Vx[i+a·mx]*/ mx, 1, /*B*/ 1, mx, /*C*/ 1, mx);
     if (e == hipSuccess) e = gemm(s, W1, pl->V[1], W0, mx, my, my, 1, mx, 1, my, 1, mx, mz, mxy, 0, mxy);
-    if (e == hipSuccess) e = gemm(s, W0, pl->V[2], W1, (int)mxy, mz, mz, 1, mxy, 1, mz, 1, mxy);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_direct_scale, grd, blk, 0, s, W1, pl->lam[0], pl->lam[1], pl->lam[2], mx, my, mz);
-        e = hipGetLastError();
+    // … the division by the eigenvalue sums rides on the store of the z product, the scatter into Pr on the store of the last one
+    // (NS3D_DIRECT_FUSED=0, or extents the LDS-staged kernel does not take: the pointwise kernels as before — same values)
+    static const bool fused = !(std::getenv("NS3D_DIRECT_FUSED") && *std::getenv("NS3D_DIRECT_FUSED") == '0');
+    GemmArgs ep{};
+    ep.epi = 1; ep.l0 = pl->lam[0]; ep.l1 = pl->lam[1]; ep.l2 = pl->lam[2]; ep.e_mx = mx; ep.e_my = my;
+    bool scaled = false;
+    if (e == hipSuccess && fused) {
+        e = gemm(s, W0, pl->V[2], W1, (int)mxy, mz, mz, 1, mxy, 1, mz, 1, mxy, 1, 0, 0, 0, &ep);
+        if (e == hipErrorInvalidValue) { (void)hipGetLastError(); e = hipSuccess; } else scaled = true;
+    }
+    if (e == hipSuccess && !scaled) {
+        e = gemm(s, W0, pl->V[2], W1, (int)mxy, mz, mz, 1, mxy, 1, mz, 1, mxy);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_direct_scale, grd, blk, 0, s, W1, pl->lam[0], pl->lam[1], pl->lam[2], mx, my, mz);
+            e = hipGetLastError();
+        }
     }
     // backward: z (Û·Vzᵀ), y (Û_k·Vyᵀ), x (Vx·Û)
     if (e == hipSuccess) e = gemm(s, W1, pl->V[2], W0, (int)mxy, mz, mz, 1, mxy, /*B(c,k)=Vz[k+c·mz]*/ mz, 1, 1, mxy);
     if (e == hipSuccess) e = gemm(s, W0, pl->V[1], W1, mx, my, my, 1, mx, my, 1, 1, mx, mz, mxy, 0, mxy);
-    if (e == hipSuccess) e = gemm(s, pl->V[0], W1, W0, mx, my * mz, mx, 1, mx, 1, mx, 1, mx);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_direct_scatter<T>, grd, blk, 0, s, Pr, D, W0, nx, ny, nz);
-        e = hipGetLastError();
+    bool scattered = false;
+    if (e == hipSuccess && fused) {
+        GemmArgs es{};
+        es.epi = sizeof(T) == 8 ? 2 : 3; es.out = (void *)Pr; es.e_mx = mx; es.e_my = my; es.e_nx = nx; es.e_ny = ny;
+        e = gemm(s, pl->V[0], W1, W0, mx, my * mz, mx, 1, mx, 1, mx, 1, mx, 1, 0, 0, 0, &es);
+        if (e == hipErrorInvalidValue) { (void)hipGetLastError(); e = hipSuccess; }
+        else {
+            scattered = true;
+            if (e == hipSuccess) e = hipMemsetAsync(D, 0, (size_t)mxy * mz * sizeof(T), s);       // the pseudo-velocity of a converged state
+        }
+    }
+    if (e == hipSuccess && !scattered) {
+        e = gemm(s, pl->V[0], W1, W0, mx, my * mz, mx, 1, mx, 1, mx, 1, mx);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_direct_scatter<T>, grd, blk, 0, s, Pr, D, W0, nx, ny, nz);
+            e = hipGetLastError();
+        }
     }
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(NS3D_ERR_HIP, "ns3d_poisson_direct launch: %s", hipGetErrorString(e)); }
     return NS3D_OK;
