@@ -469,6 +469,25 @@ __device__ __forceinline__ T poisson_rhs(T c, T w, T e, T s, T n, T b, T t, T dv
     return lap - rho_dt * dv;
 }
 
+// Two rows of an fp32 thread at once (k_pt_sweepN with two rows per thread, builds whose divisions are multiplications): the same
+// operations in the same order on both lanes of v_pk_add_f32 / v_pk_mul_f32 — IEEE per lane, so the bits are those of poisson_rhs.
+#if NS3D_FASTMATH || defined(NS3D_POW2_RECIP)
+#define NS3D_VEC2 1
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// (templated on the geometry type and fed through casts only so that the fp64 instantiations of the kernels, which never reach it, parse)
+template <class A, class B> __device__ __forceinline__ f32x2 mk2(A a, B b) { return f32x2{(float)a, (float)b}; }
+template <class G>
+__device__ __forceinline__ f32x2 poisson_rhs_v2(f32x2 c, f32x2 w, f32x2 e, f32x2 s, f32x2 n, f32x2 b, f32x2 t, f32x2 dv, float rho_dt, const G &g)
+{
+    const f32x2 d2x = (e - c) - (c - w);
+    const f32x2 d2y = (n - c) - (c - s);
+    const f32x2 d2z = (t - c) - (c - b);
+    const f32x2 lap = (d2x * (float)g.rdx2 + d2y * (float)g.rdy2) + d2z * (float)g.rdz2;
+    return lap - rho_dt * dv;
+}
+#else
+#define NS3D_VEC2 0
+#endif
 // Hot-kernel form: the same value as poisson_rhs, evaluated without branches.  In the exact-reciprocal STRICT build
 // every x/d/d is two divisor-known-in-advance divisions in straight-line code; `ok` is cleared for the lanes whose
 // dividend is outside the range in which that sequence is proven exact (|x| ∉ (2^-700, 2^700), Inf, NaN — zeros are
@@ -2515,6 +2534,9 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
     // valid row ever reads, so it may skip level ℓ's arithmetic and the publish of its Pˡ: with 12 waves × 2 rows, waves 0 and 11
     // skip levels 3 and 4 of an interior tile, 4 of 48 wave-levels.  Same bits (138 sweepN tests) — and the same time: the pass
     // is not bound by the instructions it issues (profiles/r4_levelskip_dma_ab.log), so the default build leaves it out.
+#ifndef NS3D_PACK_F32
+#define NS3D_PACK_F32 1      /* fp32 two-row shapes of k_pt_sweepN: both rows through v_pk_* (A/B: -DNS3D_PACK_F32=0) */
+#endif
 #ifndef NS3D_LEVEL_SKIP
 #define NS3D_LEVEL_SKIP 0
 #endif
@@ -2632,6 +2654,20 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
         {
             const T *__restrict__ l0 = L0[cur];
             auto level1 = [&](auto slow_tag) {
+#if NS3D_VEC2
+                if constexpr (NS3D_PACK_F32 && sizeof(T) == 4 && CPT == 2 && !decltype(slow_tag)::value) {
+                    // fp32, two rows per thread: both rows through the packed instructions (same operations, same order per lane)
+                    const int lr = wy * CPT;
+                    const f32x2 c = mk2(p0c[0], p0c[1]);
+                    const f32x2 w = mk2(l0[(lr + 1) * PX + lx], l0[(lr + 2) * PX + lx]), e = mk2(l0[(lr + 1) * PX + lx + 2], l0[(lr + 2) * PX + lx + 2]);
+                    const f32x2 sv = mk2(l0[lr * PX + lx + 1], p0c[0]), nv = mk2(p0c[1], l0[(lr + 3) * PX + lx + 1]);
+                    const f32x2 res = poisson_rhs_v2(c, w, e, sv, nv, mk2(p0m[0], p0m[1]), mk2(p0p[0], p0p[1]), mk2(rr[0][0], rr[0][1]), (float)a.rho_dt, g);
+                    const f32x2 dn = mk2(d0[0], d0[1]) * (float)a.one_m_damp + (float)a.dtau * res;
+                    const f32x2 fr = c + (float)a.dtau * dn;
+                    dnew[0] = dn.x; dnew[1] = dn.y; fresh[0] = fr.x; fresh[1] = fr.y;
+                    return;
+                }
+#endif
 #pragma unroll
                 for (int r = 0; r < CPT; ++r) {
                     const int lr = wy * CPT + r;
@@ -2670,6 +2706,40 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
                 const T *__restrict__ ll = LN[l - 2][cur];
                 const bool zlo = EDGE && (kl == 1), zhi = EDGE && (kl == nz - 2);
                 auto level = [&](auto slow_tag) {
+#if NS3D_VEC2
+                    if constexpr (NS3D_PACK_F32 && sizeof(T) == 4 && CPT == 2 && !decltype(slow_tag)::value) {
+                        // fp32, two rows per thread: operands gathered per row (boundary rule included), arithmetic on both rows at once
+                        T cs[2], ws[2], es[2], ss[2], ns[2], bs[2], ts[2];
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            const int lr = wy * CPT + r;
+                            const T c = pc[l - 2][r];
+                            T w = ll[lr * TX + max(lx - 1, 0)], e = ll[lr * TX + min(lx + 1, TX - 1)];
+                            T sv = r == 0 ? ll[max(lr - 1, 0) * TX + lx] : pc[l - 2][0];
+                            T nv = r == 1 ? ll[min(lr + 1, TY - 1) * TX + lx] : pc[l - 2][1];
+                            T bv = pm[l - 2][r], tv = fresh[r];
+                            if (tile_on_xy_face) {
+                                const int gjf = oy + lr;
+                                if (xlo_adj) w = xface_val<T>(a, false, c, kl);
+                                if (xhi_adj) e = xface_val<T>(a, true, c, kl);
+                                if (gjf == 1) sv = c;
+                                if (gjf == ny - 2) nv = c;
+                            }
+                            if constexpr (EDGE) {
+                                if (zlo) bv = c;
+                                if (zhi) tv = c;
+                            }
+                            cs[r] = c; ws[r] = w; es[r] = e; ss[r] = sv; ns[r] = nv; bs[r] = bv; ts[r] = tv;
+                        }
+                        const f32x2 c = mk2(cs[0], cs[1]);
+                        const f32x2 res = poisson_rhs_v2(c, mk2(ws[0], ws[1]), mk2(es[0], es[1]), mk2(ss[0], ss[1]), mk2(ns[0], ns[1]),
+                                                         mk2(bs[0], bs[1]), mk2(ts[0], ts[1]), mk2(rr[l - 1][0], rr[l - 1][1]), (float)a.rho_dt, g);
+                        const f32x2 dn = mk2(dc[l - 2][0], dc[l - 2][1]) * (float)a.one_m_damp + (float)a.dtau * res;
+                        const f32x2 pn = c + (float)a.dtau * dn;
+                        out_d[0] = dn.x; out_d[1] = dn.y; out_p[0] = pn.x; out_p[1] = pn.y;
+                        return;
+                    }
+#endif
 #pragma unroll
                     for (int r = 0; r < CPT; ++r) {
                         const int lr = wy * CPT + r;
