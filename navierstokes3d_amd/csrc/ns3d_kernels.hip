@@ -2534,6 +2534,12 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
     // valid row ever reads, so it may skip level ℓ's arithmetic and the publish of its Pˡ: with 12 waves × 2 rows, waves 0 and 11
     // skip levels 3 and 4 of an interior tile, 4 of 48 wave-levels.  Same bits (138 sweepN tests) — and the same time: the pass
     // is not bound by the instructions it issues (profiles/r4_levelskip_dma_ab.log), so the default build leaves it out.
+// DIAGNOSTIC builds only (WRONG results; tools/ab/ablate.sh): what part of a pass is whose — bit 1: the step's global loads replaced by
+// register values, bit 2: its stores behind a condition that never holds, bit 4: no LDS publishes, neighbours read from registers,
+// bit 8: no barrier per z-step
+#ifndef NS3D_ABL
+#define NS3D_ABL 0
+#endif
 #ifndef NS3D_PACK_F32
 #define NS3D_PACK_F32 1      /* fp32 two-row shapes of k_pt_sweepN: both rows through v_pk_* (A/B: -DNS3D_PACK_F32=0) */
 #endif
@@ -2628,6 +2634,12 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
 #ifdef NS3D_LOAD_PRIO       // A/B: the waves that are about to issue the next step's loads go first
             __builtin_amdgcn_s_setprio(3);
 #endif
+#if NS3D_ABL & 1
+            (void)Pn; (void)ka;
+#pragma unroll
+            for (int r = 0; r < CPT; ++r) { p0n[r] = p0m[r]; d0n[r] = d0[r]; r0n[r] = rr[0][r]; }
+            hAn = hA; hBn = hB; hCn = hC;
+#else
 #pragma unroll
             for (int r = 0; r < CPT; ++r) {
                 p0n[r] = Pn[poff[r]];
@@ -2637,6 +2649,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
             if (hasA) hAn = Pn[offA];
             if (hasB) hBn = Pn[offB];
             if (hasC) hCn = Pn[offC];
+#endif
 #ifdef NS3D_LOAD_PRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
@@ -2672,9 +2685,14 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
                 for (int r = 0; r < CPT; ++r) {
                     const int lr = wy * CPT + r;
                     const T c = p0c[r];
+#if NS3D_ABL & 4
+                    (void)lr; (void)l0;
+                    const T w = c * (T)0.5, e = c * (T)0.25, sv = p0m[r] * (T)0.5, nv = p0p[r] * (T)0.5;
+#else
                     const T w = l0[(lr + 1) * PX + lx], e = l0[(lr + 1) * PX + lx + 2];
                     const T sv = r == 0 ? l0[lr * PX + lx + 1] : p0c[r - 1 < 0 ? 0 : r - 1];
                     const T nv = r == CPT - 1 ? l0[(lr + 2) * PX + lx + 1] : p0c[r + 1 > CPT - 1 ? CPT - 1 : r + 1];
+#endif
                     const T res = decltype(slow_tag)::value
                                       ? poisson_rhs_slow<T>(c, w, e, sv, nv, p0m[r], p0p[r], rr[0][r], a.rho_dt, g)
                                       : poisson_rhs_nochk<T>(c, w, e, sv, nv, p0m[r], p0p[r], rr[0][r], a.rho_dt, g);
@@ -2692,7 +2710,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
             const int kl = k1 - (l - 1);
             T *__restrict__ npub = LN[l - 2][cur ^ 1];
             // publish Pˡ⁻¹ of the plane just produced (x/y neighbours of level l in the NEXT step)
-            if (act[l - 1]) {
+            if (act[l - 1] && (!(NS3D_ABL & 4) || a.nx < 0)) {
 #pragma unroll
                 for (int r = 0; r < CPT; ++r) npub[(wy * CPT + r) * TX + lx] = fresh[r];
             }
@@ -2744,9 +2762,14 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
                     for (int r = 0; r < CPT; ++r) {
                         const int lr = wy * CPT + r;
                         const T c = pc[l - 2][r];
+#if NS3D_ABL & 4
+                        (void)ll;
+                        T w = c * (T)0.5, e = c * (T)0.25, sv = pm[l - 2][r] * (T)0.5, nv = fresh[r] * (T)0.5;
+#else
                         T w = ll[lr * TX + max(lx - 1, 0)], e = ll[lr * TX + min(lx + 1, TX - 1)];
                         T sv = r == 0 ? ll[max(lr - 1, 0) * TX + lx] : pc[l - 2][r - 1 < 0 ? 0 : r - 1];
                         T nv = r == CPT - 1 ? ll[min(lr + 1, TY - 1) * TX + lx] : pc[l - 2][r + 1 > CPT - 1 ? CPT - 1 : r + 1];
+#endif
                         T bv = pm[l - 2][r], tv = fresh[r];
                         if (tile_on_xy_face) {      // boundary rule substituted where the stencil touches a face of Pˡ⁻¹
                             const int gjf = oy + lr;
@@ -2772,7 +2795,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
                     T *__restrict__ Dk = D + (idx_t)(kl - 1) * dsz;
 #pragma unroll
                     for (int r = 0; r < CPT; ++r) {
-                        if (outc[r]) {
+                        if (outc[r] && (!(NS3D_ABL & 2) || a.nx < 0)) {
                             st_stream<T, true>(Dk + doff[r], out_d[r]);
                             const int gj = oy + wy * CPT + r;
                             T *__restrict__ po = a.Pout + (idx_t)kl * sz + gj * nx + gi;
@@ -2808,18 +2831,24 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
                     rr[0][r] = r0n[r];
                 } else {
                     (void)d0n; (void)r0n;
+#if NS3D_ABL & 1
+                    (void)ka; d0[r] = dnew[r]; rr[0][r] = rr[1][r];
+#else
                     d0[r] = ld_stream<T, true>(Din + (idx_t)(ka - 1) * dsz + doff[r]);
                     rr[0][r] = ld_stream<T, true>(RHS + (idx_t)ka * sz + roff[r]);
+#endif
                 }
             }
         }
         // ---------------- publish plane k1+1 of P⁰ ----------------
         T *__restrict__ n0 = L0[cur ^ 1];
+        if (!(NS3D_ABL & 4) || a.nx < 0) {
 #pragma unroll
         for (int r = 0; r < CPT; ++r) n0[(wy * CPT + r + 1) * PX + lx + 1] = p0p[r];
         if (hasA) n0[ldsA] = hA;
         if (hasB) n0[ldsB] = hB;
         if (hasC) n0[ldsC] = hC;
+        }
 #if NS3D_HAS_SLOW_PATH
         if (hasA) bad |= !val_ok<T>(hA);
         if (hasB) bad |= !val_ok<T>(hB);
@@ -2829,7 +2858,7 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
 #pragma unroll
         for (int r = 0; r < CPT; ++r) { p0m[r] = p0c[r]; p0c[r] = p0p[r]; p0p[r] = p0n[r]; }
         hA = hAn; hB = hBn; hC = hCn;
-#ifdef NS3D_NO_STEP_BARRIER     // A/B (WRONG results): what the one barrier per z-step costs a CU that holds a single workgroup
+#if defined(NS3D_NO_STEP_BARRIER) || (NS3D_ABL & 8)     // A/B (WRONG results): what the one barrier per z-step costs a CU that holds a single workgroup
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the wave's own LDS traffic only
 #else
         __syncthreads();
