@@ -8,7 +8,7 @@ cd $GRAFT_REPO_ROOT
 for i in 1 2; do
 for l in tools/ab/libns3d_abl*.so; do
   n=$(basename $l .so)
-  NS3D_LIB=$PWD/$l timeout -k 10 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-strong --no-verify --depth 4 --variantn 2800 2>/dev/null | python3 -c "
+  NS3D_LIB=$PWD/$l timeout -k 10 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-strong --no-verify ${ABL_ARGS:---depth 4 --variantn 2800} 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$n', 'run $i', 'ms per pass', round(d['roofline']['kernel_ms'], 4), 'Mcells*iter/s', round(d['value']))"
 done
