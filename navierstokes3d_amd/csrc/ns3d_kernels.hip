@@ -2474,8 +2474,14 @@ template <class T, int NL, int WX, int WY, int CPT, int PF, int MINW = 1, bool F
 __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a, int ntx, int nty)
 {
     static_assert(NL >= 2 && NL <= 5, "levels");
-    static_assert(PF == 0 || PF == 1, "PF");
-    constexpr bool EARLY = PF == 1;
+    static_assert(PF == 0 || PF == 1 || PF == 2, "PF");
+    constexpr bool EARLY = PF >= 1;
+    // PF == 2 (round 4, fp32 A/B shape 25): the loads run TWO z-steps ahead — a second set of staging registers (q-set) holds what the
+    // next step consumes while this step's loads fill the n-set; profiles/r4_ablation_512.log: in fp32 arithmetic and memory are equal
+    // and overlap badly with one step (1.9 µs) of distance
+    constexpr bool AHEAD2 = PF == 2;
+    constexpr int QN = AHEAD2 ? CPT : 1;
+    T p0q[QN], d0q[QN], r0q[QN], hAq = (T)0, hBq = (T)0, hCq = (T)0;
     constexpr int TX = 64 * WX, TY = CPT * WY, PX = TX + 2, OV = 2 * (NL - 1);
     static_assert(TX > OV + 2 && TY > OV + 2, "tile too small for this many levels");
     __shared__ T L0[2][(TY + 2) * PX];       // P⁰ plane with halo ring: element (lx+1, lr+1)
@@ -2615,6 +2621,19 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
         if (hasA) hA = Pp[offA];
         if (hasB) hB = Pp[offB];
         if (hasC) hC = Pp[offC];
+        if constexpr (AHEAD2) {                 // what step 0 would have loaded: plane kfirst+2 of P⁰, d⁰/∇V of plane kfirst+1
+            const T *__restrict__ Pn = P + (idx_t)min(max(k1 + 2, 0), nz - 1) * sz;
+            const int kq = min(max(k1 + 1, 1), nz - 2);
+#pragma unroll
+            for (int r = 0; r < CPT; ++r) {
+                p0q[r] = Pn[poff[r]];
+                d0q[r] = ld_stream<T, true>(Din + (idx_t)(kq - 1) * dsz + doff[r]);
+                r0q[r] = ld_stream<T, true>(RHS + (idx_t)kq * sz + roff[r]);
+            }
+            if (hasA) hAq = Pn[offA];
+            if (hasB) hBq = Pn[offB];
+            if (hasC) hCq = Pn[offC];
+        }
     }
     __syncthreads();
 
@@ -2628,8 +2647,8 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
         // ---------------- the loads of the next step: plane k1+2 of P⁰ (+ halo ring), d⁰/∇V of plane k1+1 ----------------
         T p0n[CPT], d0n[CPT], r0n[CPT], hAn = (T)0, hBn = (T)0, hCn = (T)0;
         auto issue_next = [&]() {
-            const int kp = min(max(k1 + 2, 0), nz - 1);
-            const int ka = min(max(k1 + 1, 1), nz - 2);
+            const int kp = min(max(k1 + 2 + (AHEAD2 ? 1 : 0), 0), nz - 1);
+            const int ka = min(max(k1 + 1 + (AHEAD2 ? 1 : 0), 1), nz - 2);
             const T *__restrict__ Pn = P + (idx_t)kp * sz;
 #ifdef NS3D_LOAD_PRIO       // A/B: the waves that are about to issue the next step's loads go first
             __builtin_amdgcn_s_setprio(3);
@@ -2826,7 +2845,10 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
             for (int r = 0; r < CPT; ++r) {
 #pragma unroll
                 for (int l = NL - 1; l >= 1; --l) rr[l][r] = rr[l - 1][r];
-                if constexpr (EARLY) {
+                if constexpr (AHEAD2) {
+                    d0[r] = d0q[r]; rr[0][r] = r0q[r];
+                    d0q[r] = d0n[r]; r0q[r] = r0n[r];
+                } else if constexpr (EARLY) {
                     d0[r] = d0n[r];
                     rr[0][r] = r0n[r];
                 } else {
@@ -2855,9 +2877,16 @@ __global__ __launch_bounds__(64 * WX * WY, MINW) void k_pt_sweepN(SweepArgs<T> a
         if (hasC) bad |= !val_ok<T>(hC);
         if (bad) Lbad = 1;
 #endif
+        if constexpr (AHEAD2) {
+#pragma unroll
+            for (int r = 0; r < CPT; ++r) { p0m[r] = p0c[r]; p0c[r] = p0p[r]; p0p[r] = p0q[r]; p0q[r] = p0n[r]; }
+            hA = hAq; hB = hBq; hC = hCq;
+            hAq = hAn; hBq = hBn; hCq = hCn;
+        } else {
 #pragma unroll
         for (int r = 0; r < CPT; ++r) { p0m[r] = p0c[r]; p0c[r] = p0p[r]; p0p[r] = p0n[r]; }
         hA = hAn; hB = hBn; hC = hCn;
+        }
 #if defined(NS3D_NO_STEP_BARRIER) || (NS3D_ABL & 8)     // A/B (WRONG results): what the one barrier per z-step costs a CU that holds a single workgroup
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the wave's own LDS traffic only
 #else
@@ -3385,6 +3414,7 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
     case 22: if constexpr (sizeof(T) == 4) { NS3D_SWN(NLV, 1, 12, 4, true); } else return hipErrorInvalidValue; /* fp32: 64×48, 768 threads = three waves per SIMD */ \
     case 23: NS3D_SWN(NLV, 1, 12, 2, true);  /* 64×24, 768 threads, two rows per thread: three waves per SIMD */ \
     case 24: if constexpr (sizeof(T) == 4 || NS3D_SHAPE24_F64) { NS3D_SWN(NLV, 1, 16, 2, true); } else return hipErrorInvalidValue; /* fp32: 64×32, 1024 threads = four waves per SIMD (fp64 spills: A/B with -DNS3D_SHAPE24_F64=1) */ \
+    case 25: if constexpr (sizeof(T) == 4) { NS3D_SWN(NLV, 1, 16, 2, 2); } else return hipErrorInvalidValue;   /* fp32 A/B: shape 24 with the loads two steps ahead */ \
     case 28: if (fold_wanted<T>(a)) return launch_sweepN<T, NLV, 1, 12, 2, false, 1, true>(s, a, kz);       /* small grids: boundary cells folded in */ \
              NS3D_SWN(NLV, 1, 12, 2, false);                                                                \
     case 11: NS3D_SWN(NLV, 1, 8, 4, true);                                                                  \
@@ -3417,6 +3447,7 @@ hipError_t pt_sweepn(hipStream_t s, int nlev, int variant, const T *Pin, T *Pout
                 // 3.2–3.7 ms per pass against 1.39), six levels in fp32 too (44: 1.89 ms) — profiles/r3_pace_order_ab.log
         if constexpr (sizeof(T) == 4) {
             if (shape == 24) NS3D_SWN(5, 1, 16, 2, true);
+            if (shape == 25) NS3D_SWN(5, 1, 16, 2, 2);
         }
         return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;

@@ -406,7 +406,9 @@ def test_pt2_first_use_tuning(hip, oracle):
 # ---- deeper temporal blocking: N PT iterations per pass over memory (k_pt_sweepN) -------------------------------
 SHAPESN = [0, 100, 200, 600, 1100, 1200, 1600, 2200, 103, 207, 1105, 2203, 616, 192, 94, 2300, 2400, 2800, 2305, 2391, 2891, 2807,
            # k_pt_sweepD (round 4): the planes of P⁰ through an LDS-DMA ring — every shape, chunked / one chunk / short chunks
-           3100, 3191, 3105, 3200, 3207, 3500, 3591, 3506, 3800, 3807, 3891]
+           3100, 3191, 3105, 3200, 3207, 3500, 3591, 3506, 3800, 3807, 3891,
+           # fp32 only (round 4, A/B): the 1024-thread shape with the loads two z-steps ahead
+           2500, 2507]
 
 
 def _sweepn_all_shapes(hip, ctx, nlev, Pr0, d0, rhs, p, Pr, d, what, k0=None, k1=None, cmp=np.array_equal):
